@@ -1,0 +1,130 @@
+/*
+ * crdb_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of CockroachDB's vectorized hash path, used as the
+ * parity oracle and as the "port" CPU baseline.  Nothing in the product path
+ * (cockroach_amd/, include/, host/) may include, link or call this; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Every function cites the reference file:line it follows
+ * (paths relative to the reference checkout, pkg/...).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - memhash64 / initHash / finalizeHash / TupleHashDistributor: pinned by the
+ *     reference's known-answer test routers_test.go:698-781 ({273,252,287,212}).
+ *   - hash table First/Next/Same/Visited/HeadID: pinned by the worked examples
+ *     in hashtable.go:512-625, hashtable_tmpl.go:584-731, hash_aggregator.go:288-352.
+ *   - join / aggregation results: pinned by the literal case tables of
+ *     hashjoiner_test.go:50-925, aggregators_test.go:186-785,
+ *     hash_aggregator_test.go:34-397 (transcribed to tests/golden/*.json).
+ *   - memhash over byte strings / float hashing: the reference holds no literal
+ *     vector => exact hash VALUES for bytes/floats are "parity unpinned"
+ *     (pinned only through join/agg results and memhash(8B)==memhash64).
+ */
+#ifndef CRDB_ORACLE_H
+#define CRDB_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* canonical type families handled (pkg/col/typeconv/typeconv.go:30) */
+enum { ORA_BOOL = 0, ORA_INT16 = 1, ORA_INT32 = 2, ORA_INT64 = 3, ORA_FLOAT64 = 4, ORA_BYTES = 5 };
+
+/* descpb.JoinType (pkg/sql/catalog/descpb/join_type.proto:13-83) */
+enum {
+  ORA_INNER = 0, ORA_LEFT_OUTER = 1, ORA_RIGHT_OUTER = 2, ORA_FULL_OUTER = 3,
+  ORA_LEFT_SEMI = 4, ORA_LEFT_ANTI = 5, ORA_INTERSECT_ALL = 6, ORA_EXCEPT_ALL = 7,
+  ORA_RIGHT_SEMI = 8, ORA_RIGHT_ANTI = 9
+};
+
+/* execinfrapb.AggregatorSpec_Func (pkg/sql/execinfrapb/processors_sql.proto:778-791) */
+enum {
+  ORA_ANY_NOT_NULL = 0, ORA_AVG = 1, ORA_BOOL_AND = 2, ORA_BOOL_OR = 3, ORA_COUNT = 5,
+  ORA_MAX = 7, ORA_MIN = 8, ORA_SUM = 10, ORA_SUM_INT = 11, ORA_COUNT_ROWS = 14
+};
+
+/* A borrowed column: fixed-width values dense in `data`; BYTES as Arrow-style
+ * offsets[n+1] into `data`.  `valid` is a validity bitmap with the same bit
+ * convention as coldata.Nulls (pkg/col/coldata/nulls.go:184-201): LSB-first,
+ * bit=1 => value present.  valid==NULL => no NULLs. */
+typedef struct ora_col {
+  int32_t type;
+  int32_t _pad;
+  const void *data;
+  const uint8_t *valid;
+  const uint32_t *offsets;
+} ora_col;
+
+typedef struct ora_agg_spec {
+  int32_t func;       /* ORA_* aggregate */
+  int32_t col;        /* input column ordinal, -1 for COUNT_ROWS */
+  int32_t filter_col; /* BOOL column ordinal or -1 (FILTER clause) */
+  int32_t _pad;
+} ora_agg_spec;
+
+typedef struct ora_result ora_result;
+
+/* --- hashing (colexechash/hash.go, hash_utils.go, hash_utils.eg.go) --- */
+uint64_t ora_memhash(const void *p, uint64_t seed, uint64_t s);
+uint64_t ora_memhash64(uint64_t v, uint64_t seed);
+/* initHash(init) -> rehash per column -> finalizeHash(nbuckets) (nbuckets==0: skip finalize).
+ * sel==NULL => rows 0..n-1; otherwise out[i] is the hash of row sel[i]. */
+void ora_hash_cols32(const ora_col *cols, int ncols, int64_t n, const int64_t *sel,
+                     uint32_t init, uint32_t nbuckets, uint32_t *out);
+void ora_hash_cols64(const ora_col *cols, int ncols, int64_t n, const int64_t *sel,
+                     uint64_t init, uint64_t nbuckets, uint64_t *out);
+
+/* TupleHashDistributor.Distribute (colexechash/hash_utils.go:163-208), applied
+ * batch-at-a-time: dest[i] = output index of row i; counts[p] += 1. */
+void ora_distribute(const ora_col *cols, int ncols, const int32_t *hash_cols, int nhash,
+                    int64_t n, uint64_t init, int32_t num_outputs, int32_t batch_size,
+                    int32_t *dest, int64_t *counts);
+
+/* --- hash joiner (colexecjoin/hashjoiner.go, hashjoiner_tmpl.go) ---
+ * Runs build (right) then probe (left) batch-at-a-time (batch_size tuples per
+ * Next()).  Output: left columns then right columns per JoinType.MakeOutputTypes.
+ * right_eq_cols_are_key is the planner hint; MakeHashJoinerSpec overrides apply. */
+ora_result *ora_hash_join(int32_t join_type,
+                          const ora_col *left, int nleft_cols, int64_t nleft,
+                          const ora_col *right, int nright_cols, int64_t nright,
+                          const int32_t *left_eq, const int32_t *right_eq, int neq,
+                          int32_t right_eq_cols_are_key,
+                          int32_t batch_size, uint32_t initial_buckets);
+
+/* --- hash aggregator (colexec/hash_aggregator.go, hash_aggregator_tmpl.go,
+ * colexecagg/hash_*_agg.eg.go).  One output column per aggregation, one row
+ * per group in bucket-creation order.  Returns NULL with *err set (1 =
+ * ErrIntOutOfRange) on SUM_INT overflow. */
+ora_result *ora_hash_agg(const ora_col *cols, int ncols, int64_t n,
+                         const int32_t *group_cols, int ngroup,
+                         const ora_agg_spec *aggs, int naggs,
+                         int32_t batch_size, int32_t max_buffered, uint32_t initial_buckets,
+                         int32_t *err);
+
+/* --- result access --- */
+int32_t ora_result_ncols(const ora_result *r);
+int64_t ora_result_nrows(const ora_result *r);
+/* fills `out` with a borrowed view valid until ora_result_free */
+void ora_result_col(const ora_result *r, int32_t i, ora_col *out);
+void ora_result_free(ora_result *r);
+
+/* --- test hooks for the reference's worked examples (injectable hash) ---
+ * When n>0, ComputeBuckets uses hashes[j] for int64 key value vals[j]
+ * (hashtable.go:522 "h(-5)=1, h(-6)=1, ..."; hashtable_tmpl.go:594 "h(i)=i%2"). */
+void ora_test_set_hash_table(const int64_t *vals, const uint32_t *hashes, int n);
+/* Debug dump of the last join's hash table state (keyID-indexed, length nright+1),
+ * and of HeadID after the last probed batch. Any pointer may be NULL. */
+void ora_test_last_join_state(uint32_t *first, int32_t *nfirst, uint32_t *next, uint32_t *same,
+                              uint8_t *visited, int64_t *nkeys, uint32_t *head_id, int32_t *nhead);
+/* Debug dump of the aggregator's hash table after the run: First/Next of BuildScratch. */
+void ora_test_last_agg_state(uint32_t *first, int32_t *nfirst, uint32_t *next, int64_t *nkeys);
+
+/* --- KV codec (storage/enginepb/decode.go, util/encoding/encoding.go,
+ * colfetcher/cfetcher.go, colencoding) -- see crdb_kv.c --- */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

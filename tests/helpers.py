@@ -1,0 +1,234 @@
+"""Shared helpers for the parity tests: fixture loading, tuple <-> column
+conversion and the unordered (multiset) verifier the reference uses
+(colexectestutils/utils.go:1411-1430,1522-1538: sort both sides, floats within
+abs 1e-6, NaN == NaN)."""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+
+from cockroach_amd import coldata as cd
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+JOIN_TYPE = {"INNER": 0, "LEFT_OUTER": 1, "RIGHT_OUTER": 2, "FULL_OUTER": 3, "LEFT_SEMI": 4, "LEFT_ANTI": 5,
+             "INTERSECT_ALL": 6, "EXCEPT_ALL": 7, "RIGHT_SEMI": 8, "RIGHT_ANTI": 9}
+AGG_FUNC = {"ANY_NOT_NULL": 0, "AVG": 1, "BOOL_AND": 2, "BOOL_OR": 3, "CONCAT_AGG": 4, "COUNT": 5, "MAX": 7,
+            "MIN": 8, "SUM": 10, "SUM_INT": 11, "COUNT_ROWS": 14}
+FLOAT_ABS_TOL = 1e-6      # colexectestutils/utils.go:1416
+FLOAT_REL_TOL = 1e-9
+
+
+def load_cases(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)["cases"]
+
+
+def type_id(name):
+    # DECIMAL columns of the reference's aggregation tables are run as FLOAT64
+    # (apd arithmetic is outside the GPU path); the expected
+    # values are compared with the float tolerance.
+    if name == "decimal":
+        return cd.FLOAT64
+    return cd.TYPE_BY_NAME[name]
+
+
+def _coerce(typ, v):
+    if v is None:
+        return None
+    if typ == cd.FLOAT64:
+        return float(v)
+    if typ == cd.BYTES:
+        return v.encode() if isinstance(v, str) else bytes(v)
+    if typ == cd.BOOL:
+        return bool(v)
+    return int(v)
+
+
+def tuples_to_vecs(tuples, types):
+    """list of rows -> list[Vec] (one per column)."""
+    tids = [type_id(t) if isinstance(t, str) else t for t in types]
+    cols = []
+    for c, t in enumerate(tids):
+        cols.append(cd.Vec.from_values(t, [_coerce(t, row[c]) for row in tuples]))
+    return cols
+
+
+def vecs_to_tuples(vecs, nrows=None):
+    if not vecs:
+        return [tuple() for _ in range(nrows or 0)]
+    cols = [v.to_values() for v in vecs]
+    return [tuple(col[i] for col in cols) for i in range(len(vecs[0]))]
+
+
+def _sort_key(row):
+    key = []
+    for v in row:
+        if v is None:
+            key.append((0, 0))
+        elif isinstance(v, float) and math.isnan(v):
+            key.append((1, 0))
+        elif isinstance(v, (bytes, str)):
+            key.append((3, v if isinstance(v, bytes) else v.encode()))
+        elif isinstance(v, bool):
+            key.append((2, int(v)))
+        else:
+            key.append((2, round(float(v), 5) if isinstance(v, float) else v))
+    return key
+
+
+def _val_eq(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    if isinstance(a, (bytes, str)) or isinstance(b, (bytes, str)):
+        a = a.encode() if isinstance(a, str) else a
+        b = b.encode() if isinstance(b, str) else b
+        return a == b
+    if isinstance(a, float) or isinstance(b, float):
+        a, b = float(a), float(b)
+        if math.isnan(a) or math.isnan(b):
+            return math.isnan(a) and math.isnan(b)
+        return abs(a - b) <= max(FLOAT_ABS_TOL, FLOAT_REL_TOL * max(abs(a), abs(b)))
+    return a == b
+
+
+def assert_same_multiset(actual, expected, msg=""):
+    """UnorderedVerifier (colexectestutils/utils.go:1522-1538)."""
+    actual = [tuple(r) for r in actual]
+    expected = [tuple(r) for r in expected]
+    assert len(actual) == len(expected), f"{msg}: row count {len(actual)} != {len(expected)}\nactual={actual[:20]}\nexpected={expected[:20]}"
+    a = sorted(actual, key=_sort_key)
+    e = sorted(expected, key=_sort_key)
+    for ra, re_ in zip(a, e):
+        assert len(ra) == len(re_), f"{msg}: arity {ra} vs {re_}"
+        for x, y in zip(ra, re_):
+            assert _val_eq(x, y), f"{msg}: {ra} != {re_}\nactual={a[:20]}\nexpected={e[:20]}"
+
+
+# ---------------------------------------------------------------------------
+# join cases
+# ---------------------------------------------------------------------------
+def left_in_output(jt):
+    return jt not in ("RIGHT_SEMI", "RIGHT_ANTI")
+
+
+def right_in_output(jt):
+    return jt not in ("LEFT_SEMI", "LEFT_ANTI", "INTERSECT_ALL", "EXCEPT_ALL")
+
+
+def mirror_case(c):
+    """joinTestCase.mirror (joiner_utils_test.go:77-104): LEFT SEMI/ANTI -> RIGHT SEMI/ANTI."""
+    if c["join_type"] not in ("LEFT_SEMI", "LEFT_ANTI"):
+        return None
+    m = dict(c)
+    m["description"] = c["description"] + " (mirror)"
+    m["join_type"] = "RIGHT_SEMI" if c["join_type"] == "LEFT_SEMI" else "RIGHT_ANTI"
+    for a, b in (("left", "right"), ("left_types", "right_types"), ("left_out", "right_out"),
+                 ("left_eq", "right_eq"), ("left_eq_cols_are_key", "right_eq_cols_are_key")):
+        m[a], m[b] = c[b], c[a]
+    return m
+
+
+def join_cases():
+    cases = []
+    for f in ("hashjoiner_cases.json", "mergejoiner_cases.json"):
+        for c in load_cases(f):
+            if not c["supported"]:
+                continue
+            c = dict(c)
+            c["id"] = f.split("_")[0] + ":" + c["description"]
+            cases.append(c)
+            m = mirror_case(c)
+            if m is not None:
+                m["id"] = c["id"] + " (mirror)"
+                cases.append(m)
+    return cases
+
+
+def _eval_on_expr(expr, row):
+    import re
+    py = re.sub(r"@(\d+)", lambda m: f"r[{int(m.group(1)) - 1}]", expr).replace("AND", "and")
+    try:
+        return bool(eval(py, {"r": row}))  # noqa: S307 - fixture expressions only
+    except TypeError:  # NULL operand -> not true
+        return False
+
+
+def project_join_output(case, out_rows):
+    """Apply ON filter (planned as a filter above the joiner, execplan.go:1331)
+    and the PostProcessSpec projection (hashjoiner_test.go:939-968)."""
+    jt = case["join_type"]
+    if case.get("on_expr"):
+        out_rows = [r for r in out_rows if _eval_on_expr(case["on_expr"], r)]
+    proj = list(case["left_out"]) if left_in_output(jt) else []
+    roff = len(case["left_types"]) if left_in_output(jt) else 0
+    if right_in_output(jt) or not left_in_output(jt):
+        proj += [roff + c for c in case["right_out"]]
+    return [tuple(r[i] for i in proj) for r in out_rows]
+
+
+def expected_join_rows(case):
+    types = []
+    jt = case["join_type"]
+    if left_in_output(jt):
+        types += [case["left_types"][i] for i in case["left_out"]]
+    if right_in_output(jt) or not left_in_output(jt):
+        types += [case["right_types"][i] for i in case["right_out"]]
+    rows = []
+    for r in case["expected"]:
+        rows.append(tuple(_coerce(type_id(t), v) for t, v in zip(types, r)))
+    return rows
+
+
+# ---------------------------------------------------------------------------
+# aggregation cases
+# ---------------------------------------------------------------------------
+SUPPORTED_AGGS = {"ANY_NOT_NULL", "AVG", "BOOL_AND", "BOOL_OR", "COUNT", "MAX", "MIN", "SUM", "SUM_INT", "COUNT_ROWS"}
+
+
+def agg_cases():
+    out = []
+    for f in ("aggregator_cases.json", "hash_aggregator_cases.json"):
+        for c in load_cases(f):
+            if c["has_unsupported_values"]:
+                continue
+            c = dict(c)
+            c["id"] = f.split("_cases")[0] + ":" + c["name"]
+            out.append(c)
+    return out
+
+
+def prepare_agg_case(c):
+    """Returns (cols, group_cols, aggs[(func, col, filter)], expected_rows) keeping
+    only the aggregations in scope (no DISTINCT, no CONCAT_AGG, SUM/AVG over
+    float only); expected columns are projected accordingly."""
+    types = [type_id(t) for t in c["types"]]
+    cols = tuples_to_vecs(c["input"], types)
+    keep, aggs = [], []
+    for i, fn in enumerate(c["agg_fns"]):
+        if fn not in SUPPORTED_AGGS:
+            continue
+        if c.get("agg_distinct") and c["agg_distinct"][i]:
+            continue
+        col = c["agg_cols"][i][0] if c["agg_cols"][i] else -1
+        if fn in ("SUM", "AVG") and types[col] != cd.FLOAT64:
+            continue  # SUM/AVG over INT => DECIMAL result (apd), out of scope
+        flt = c["agg_filter"][i] if c.get("agg_filter") else -1
+        keep.append(i)
+        aggs.append((AGG_FUNC[fn], col, flt))
+    expected = []
+    for r in c["expected"]:
+        row = []
+        for i in keep:
+            v = r[i]
+            if isinstance(v, str) and c["agg_fns"][i] in ("AVG", "SUM", "MIN", "MAX") and \
+                    c["types"][c["agg_cols"][i][0]] == "decimal":
+                v = float(v)
+            if isinstance(v, str):
+                v = v.encode()
+            row.append(v)
+        expected.append(tuple(row))
+    return cols, list(c["group_cols"]), aggs, expected
