@@ -1,0 +1,146 @@
+"""ctypes loader for libcrgpu.so (the C-ABI declared in include/crgpu.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is
+visible, every entry point raises.  This mirrors the Go-side cgo stub of
+INTEGRATION.md one-to-one (same structs, same field order).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrgpu.so")
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM, ERR_INT_OUT_OF_RANGE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = range(8)
+
+
+class CrgpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"crgpu status {code}: {msg}")
+        self.code = code
+
+
+class DCol(C.Structure):  # crgpu_dcol
+    _fields_ = [("type", C.c_int32), ("_pad", C.c_int32), ("data", C.c_void_p), ("valid", C.c_void_p),
+                ("offsets", C.c_void_p)]
+
+
+class DevResult(C.Structure):  # crgpu_dev_result
+    _fields_ = [("n", C.c_int64), ("ncols", C.c_int32), ("_pad", C.c_int32), ("cols", C.POINTER(DCol))]
+
+
+class JoinSpec(C.Structure):  # crgpu_join_spec
+    _fields_ = [("join_type", C.c_int32), ("right_eq_cols_are_key", C.c_int32), ("n_left_cols", C.c_int32),
+                ("n_right_cols", C.c_int32), ("left_types", C.POINTER(C.c_int32)),
+                ("right_types", C.POINTER(C.c_int32)), ("n_eq", C.c_int32), ("_pad", C.c_int32),
+                ("left_eq", C.POINTER(C.c_int32)), ("right_eq", C.POINTER(C.c_int32))]
+
+
+class AggDesc(C.Structure):  # crgpu_agg_desc
+    _fields_ = [("func", C.c_int32), ("col", C.c_int32), ("filter_col", C.c_int32), ("distinct", C.c_int32)]
+
+
+class AggSpec(C.Structure):  # crgpu_agg_spec
+    _fields_ = [("n_cols", C.c_int32), ("n_group", C.c_int32), ("types", C.POINTER(C.c_int32)),
+                ("group_cols", C.POINTER(C.c_int32)), ("n_aggs", C.c_int32), ("_pad", C.c_int32),
+                ("aggs", C.POINTER(AggDesc))]
+
+
+class Col(C.Structure):  # crgpu_col (host, coldata layout)
+    _fields_ = [("type", C.c_int32), ("maybe_has_nulls", C.c_int32), ("data", C.c_void_p), ("nulls", C.c_void_p),
+                ("bytes_buf", C.c_void_p), ("bytes_buf_len", C.c_int64)]
+
+
+class Batch(C.Structure):  # crgpu_batch
+    _fields_ = [("length", C.c_int64), ("sel", C.c_void_p), ("ncols", C.c_int32), ("_pad", C.c_int32),
+                ("cols", C.POINTER(Col))]
+
+
+class OutCol(C.Structure):  # crgpu_out_col
+    _fields_ = [("type", C.c_int32), ("has_nulls", C.c_int32), ("data", C.c_void_p), ("nulls", C.c_void_p),
+                ("bytes_buf", C.c_void_p), ("bytes_buf_cap", C.c_int64), ("bytes_buf_len", C.c_int64)]
+
+
+class OutBatch(C.Structure):  # crgpu_out_batch
+    _fields_ = [("capacity", C.c_int64), ("length", C.c_int64), ("ncols", C.c_int32), ("_pad", C.c_int32),
+                ("cols", C.POINTER(OutCol))]
+
+
+# every symbol include/crgpu.h declares: (name, restype, argtypes)
+_VP, _I32, _I64, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+SYMBOLS = [
+    ("crgpu_init", _I32, [_I32]),
+    ("crgpu_shutdown", None, []),
+    ("crgpu_last_error", C.c_char_p, []),
+    ("crgpu_mem_usage", _I64, []),
+    ("crgpu_prof_enable", None, [_I32]),
+    ("crgpu_prof_reset", None, []),
+    ("crgpu_prof_get", _I32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    ("crgpu_dev_malloc", _I32, [C.POINTER(_VP), C.c_size_t]),
+    ("crgpu_dev_free", None, [_VP]),
+    ("crgpu_dev_memcpy_h2d", _I32, [_VP, _VP, C.c_size_t]),
+    ("crgpu_dev_memcpy_d2h", _I32, [_VP, _VP, C.c_size_t]),
+    ("crgpu_dev_synchronize", _I32, []),
+    ("crgpu_dev_hash_cols", _I32, [C.POINTER(DCol), _I32, _I64, _U64, _I32, _U64, _VP]),
+    ("crgpu_dev_join_create", _I32, [C.POINTER(JoinSpec), C.POINTER(_VP)]),
+    ("crgpu_dev_join_build", _I32, [_VP, C.POINTER(DCol), _I64]),
+    ("crgpu_dev_join_probe", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult)]),
+    ("crgpu_dev_join_emit_right", _I32, [_VP, C.POINTER(DevResult)]),
+    ("crgpu_dev_join_reset", _I32, [_VP]),
+    ("crgpu_dev_join_destroy", None, [_VP]),
+    ("crgpu_dev_agg_create", _I32, [C.POINTER(AggSpec), C.POINTER(_VP)]),
+    ("crgpu_dev_agg_consume", _I32, [_VP, C.POINTER(DCol), _I64]),
+    ("crgpu_dev_agg_finish", _I32, [_VP, C.POINTER(DevResult)]),
+    ("crgpu_dev_agg_reset", _I32, [_VP]),
+    ("crgpu_dev_agg_destroy", None, [_VP]),
+    ("crgpu_dev_partitioner_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(_VP)]),
+    ("crgpu_dev_partition", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult), C.POINTER(_I64)]),
+    ("crgpu_dev_partitioner_destroy", None, [_VP]),
+    ("crgpu_hash_cols", _I32, [C.POINTER(Col), _I32, _I64, _VP, _U64, _I32, _U64, _VP]),
+    ("crgpu_hj_new", _I32, [C.POINTER(JoinSpec), C.POINTER(_VP)]),
+    ("crgpu_hj_build_append", _I32, [_VP, C.POINTER(Batch)]),
+    ("crgpu_hj_build_finish", _I32, [_VP]),
+    ("crgpu_hj_probe_append", _I32, [_VP, C.POINTER(Batch)]),
+    ("crgpu_hj_probe_finish", _I32, [_VP]),
+    ("crgpu_hj_next_output", _I32, [_VP, C.POINTER(OutBatch)]),
+    ("crgpu_hj_export_buffered", _I32, [_VP, C.POINTER(OutBatch)]),
+    ("crgpu_hj_reset", _I32, [_VP]),
+    ("crgpu_hj_free", None, [_VP]),
+    ("crgpu_agg_new", _I32, [C.POINTER(AggSpec), C.POINTER(_VP)]),
+    ("crgpu_agg_append", _I32, [_VP, C.POINTER(Batch)]),
+    ("crgpu_agg_finish", _I32, [_VP]),
+    ("crgpu_agg_next_output", _I32, [_VP, C.POINTER(OutBatch)]),
+    ("crgpu_agg_reset", _I32, [_VP]),
+    ("crgpu_agg_free", None, [_VP]),
+    ("crgpu_route_new", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _I32, C.POINTER(_VP)]),
+    ("crgpu_route_partition", _I32, [_VP, C.POINTER(Batch)]),
+    ("crgpu_route_finish", _I32, [_VP]),
+    ("crgpu_route_next_output", _I32, [_VP, _I32, C.POINTER(OutBatch)]),
+    ("crgpu_route_free", None, [_VP]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libcrgpu.so and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrgpuError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                         "(make -C cockroach_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        msg = load().crgpu_last_error()
+        raise CrgpuError(status, msg.decode() if msg else "")

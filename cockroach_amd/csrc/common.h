@@ -1,0 +1,132 @@
+// common.h -- internal declarations shared by the HIP translation units of libcrgpu.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 256 CUs in 8 XCDs, 160 KB LDS/CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "crgpu.h"
+
+namespace crgpu {
+
+// ------------------------------------------------------------------ errors
+void set_error(const std::string &msg);
+crgpu_status fail(crgpu_status code, const std::string &msg);
+crgpu_status hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define CRGPU_HIP(expr)                                                              \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) return ::crgpu::hip_fail(_e, #expr, __FILE__, __LINE__);   \
+  } while (0)
+#define CRGPU_TRY(expr)                          \
+  do {                                           \
+    crgpu_status _s = (expr);                    \
+    if (_s != CRGPU_OK) return _s;               \
+  } while (0)
+
+// ------------------------------------------------------------------ runtime
+hipStream_t stream();        // the library stream (created by crgpu_init)
+crgpu_status ensure_init();  // lazily crgpu_init(current device)
+int num_cus();
+
+// Grow-only device buffer; every byte is accounted in crgpu_mem_usage().
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  // Ensures capacity >= bytes.  Contents are NOT preserved on growth unless keep=true.
+  crgpu_status ensure(size_t bytes, bool keep = false);
+  void release();
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// HIP-event timing per kernel family (crgpu_prof_*).
+struct ProfScope {
+  const char *name;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool on;
+  explicit ProfScope(const char *n);
+  ~ProfScope();
+};
+
+// ------------------------------------------------------------------ device-side column model
+static constexpr int kMaxKeyCols = 8;
+static constexpr int kMaxCols = 64;
+
+struct DCol {  // POD mirror of crgpu_dcol passed to kernels by value
+  int32_t type;
+  int32_t _pad;
+  const void *data;
+  const uint8_t *valid;
+  const uint32_t *offsets;
+};
+static inline DCol to_dcol(const crgpu_dcol &c) { return DCol{c.type, 0, c.data, c.valid, c.offsets}; }
+
+struct KeyCols {
+  int32_t n;
+  int32_t _pad;
+  DCol c[kMaxKeyCols];
+};
+
+static inline int type_width(int t) {
+  switch (t) {
+    case CRGPU_BOOL: return 1;
+    case CRGPU_INT16: return 2;
+    case CRGPU_INT32: return 4;
+    case CRGPU_INT64: return 8;
+    case CRGPU_FLOAT64: return 8;
+    default: return 0;
+  }
+}
+static inline bool is_int_type(int t) { return t == CRGPU_INT16 || t == CRGPU_INT32 || t == CRGPU_INT64; }
+static inline bool valid_type(int t) { return t >= CRGPU_BOOL && t <= CRGPU_BYTES; }
+
+// An output column owned by the library: data / validity-bytes / offsets buffers.
+struct OutCol {
+  int type = 0;
+  DevBuf data;     // fixed-width values or BYTES payload
+  DevBuf valid;    // validity bitmap (bit = 1 present); only meaningful if nullable
+  DevBuf offsets;  // BYTES: n+1 uint32
+  bool nullable = false;
+  crgpu_dcol view() const {
+    crgpu_dcol d;
+    d.type = type;
+    d._pad = 0;
+    d.data = data.p;
+    d.valid = nullable ? valid.as<uint8_t>() : nullptr;
+    d.offsets = type == CRGPU_BYTES ? offsets.as<uint32_t>() : nullptr;
+    return d;
+  }
+};
+
+// ------------------------------------------------------------------ shared launch helpers (gather.hip)
+// dst[i] = src[idx[i]] for fixed-width columns; idx < 0 (as int32) => NULL row (zero value).
+crgpu_status gather_fixed(const DCol &src, const int32_t *idx, int64_t n, void *dst);
+// Validity of gathered rows: out bitmap bit i = src valid at idx[i] (idx<0 => 0). Returns via *any_null_dev (uint32 flag) if non-null.
+crgpu_status gather_valid(const DCol &src, const int32_t *idx, int64_t n, uint8_t *dst_bitmap);
+// BYTES gather: computes lengths, scans into dst_offsets[n+1], ensures dst_data capacity, copies payloads.
+crgpu_status gather_bytes(const DCol &src, const int32_t *idx, int64_t n, DevBuf &dst_offsets, DevBuf &dst_data,
+                          DevBuf &scratch);
+// Materialise column `src` through row ids `idx` into `out` (all families, validity included when
+// `force_nullable` or the source has a validity bitmap).
+crgpu_status materialize(const DCol &src, const int32_t *idx, int64_t n, bool force_nullable, OutCol &out,
+                         DevBuf &scratch);
+// Exclusive prefix sum of uint32 counts into uint64 offsets[n+1] (offsets[n] = total); returns total on host.
+crgpu_status exclusive_scan_u32(const uint32_t *counts, int64_t n, uint64_t *offsets, DevBuf &scratch,
+                                uint64_t *total_host);
+// idx_out[k] = i for every i in [0,n) with flags[i] != 0 (stable order); *count_host = number selected.
+crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, DevBuf &scratch,
+                            int64_t *count_host);
+// bytes-per-row -> bitmap packing (dst bit i = src[i] != 0)
+crgpu_status pack_bitmap(const uint8_t *bytes, int64_t n, uint8_t *bitmap);
+// hash rows (hash.hip): out32/out64 device arrays
+crgpu_status launch_hash(const KeyCols &keys, int64_t n, uint64_t init, int width, uint64_t nbuckets, void *out);
+
+}  // namespace crgpu

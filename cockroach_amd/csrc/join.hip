@@ -1,0 +1,870 @@
+// join.hip -- device-resident hash join.
+//
+// Replaces colexecjoin.hashJoiner (pkg/sql/colexec/colexecjoin/hashjoiner.go:166-712,
+// hashjoiner_tmpl.go) and the colexechash.HashTable it drives (hashtable.go,
+// hashtable_tmpl.go).  Results are the same multisets; the internals are not
+// the reference's First/Next/Same/Visited arrays:
+//
+//  * PACKED table (single int / float / bool equality column, first match
+//    suffices): open addressing over 16-byte {key64, val64} slots, linear
+//    probing, 64-bit atomicCAS on the key word at build, one 16-byte load per
+//    probe step.  val = build row id, or -- when the build side is {key, one
+//    8-byte payload} ("covering") -- the payload itself, so a probe touches
+//    exactly one random 16-byte slot and nothing else of the build side.
+//    The probe kernel is fused with output materialisation: 1024 lanes x 8
+//    rows per workgroup tile, ballot-compacted, one returning atomicAdd per
+//    8192-row tile to claim output space.
+//  * CHAINED table (multi-column / BYTES keys, duplicate build keys, RIGHT
+//    SEMI/ANTI, INTERSECT/EXCEPT ALL): first[nb]/next[n] chains built with
+//    atomicExch head insertion; probing is count -> exclusive scan -> fill
+//    (deterministic output offsets, no per-row atomics), then columns are
+//    materialised through (probe row, build row) pairs.
+//
+// Roofline: HBM-bound (random 16-byte slot reads + streaming columns).
+#include <cstring>
+
+#include "device.h"
+
+namespace crgpu {
+
+static constexpr uint64_t kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+struct alignas(16) Slot {
+  unsigned long long key;
+  unsigned long long val;
+};
+struct Special {  // the one build key whose packed value equals kEmptyKey
+  unsigned int present;
+  unsigned int _pad;
+  unsigned long long val;
+};
+
+// Packed key: ints sign-extended to 64 bits (mixed widths compare equal,
+// hashtable_tmpl.go:275-281); floats by bits with NaN and -0 canonicalised so
+// that NaN == NaN and +0 == -0 (hashtable_full_default.eg.go:4073-4091).
+__device__ __forceinline__ uint64_t pack_key(const DCol &c, int64_t i) {
+  switch (c.type) {
+    case CRGPU_BOOL: return col_get_bool(c, i);
+    case CRGPU_FLOAT64: {
+      double f = col_get_f64(c, i);
+      if (f != f) return 0x7FF8000000000000ull;
+      if (f == 0) return 0;
+      return static_cast<uint64_t>(__double_as_longlong(f));
+    }
+    default: return static_cast<uint64_t>(col_get_int(c, i));
+  }
+}
+
+// ------------------------------------------------------------------ PACKED build
+__global__ __launch_bounds__(256) void packed_build_kernel(DCol key, int64_t n, Slot *__restrict__ slots,
+                                                           uint64_t mask, const uint64_t *__restrict__ payload,
+                                                           Special *__restrict__ special) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+    if (col_is_null(key, row)) continue;  // NULL never matches (allowNullEquality=false, hashjoiner.go:264)
+    const uint64_t k = pack_key(key, row);
+    const unsigned long long v = payload ? payload[row] : static_cast<unsigned long long>(row);
+    if (k == kEmptyKey) {
+      if (atomicCAS(&special->present, 0u, 1u) == 0u) special->val = v;
+      continue;
+    }
+    uint64_t idx = fmix64(k) & mask;
+    while (true) {
+      unsigned long long old = atomicCAS(&slots[idx].key, kEmptyKey, static_cast<unsigned long long>(k));
+      if (old == kEmptyKey) {
+        slots[idx].val = v;
+        break;
+      }
+      if (old == k) break;  // duplicate key: first writer wins (distinct build semantics)
+      idx = (idx + 1) & mask;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ PACKED probe, fused with materialisation
+static constexpr int kMaxFused = 16;
+enum CopySide : int32_t { SIDE_PROBE = 0, SIDE_BUILD = 1, SIDE_COVER = 2, SIDE_KEYCAST = 3 };
+struct CopyCol {
+  const uint8_t *src;
+  uint8_t *dst;
+  const uint8_t *src_valid;  // validity bitmap of the source (or null)
+  uint8_t *dst_valid;        // one byte per output row (or null when the output cannot hold NULLs)
+  int32_t width;
+  int32_t side;
+};
+struct ProbeArgs {
+  DCol key;
+  int64_t n;
+  const Slot *slots;
+  uint64_t mask;
+  const Special *special;
+  int32_t ncopy;
+  int32_t _pad;
+  CopyCol copy[kMaxFused];
+  int32_t *pair_p;  // optional (probe row, build row) pairs for columns not fused
+  int32_t *pair_b;
+  uint8_t *matched;  // optional build-row matched flags (RIGHT/FULL OUTER)
+  unsigned long long *out_count;
+};
+
+__device__ __forceinline__ void store_width(uint8_t *dst, int64_t pos, int width, uint64_t v) {
+  switch (width) {
+    case 1: dst[pos] = static_cast<uint8_t>(v); break;
+    case 2: reinterpret_cast<uint16_t *>(dst)[pos] = static_cast<uint16_t>(v); break;
+    case 4: reinterpret_cast<uint32_t *>(dst)[pos] = static_cast<uint32_t>(v); break;
+    default: reinterpret_cast<uint64_t *>(dst)[pos] = v; break;
+  }
+}
+__device__ __forceinline__ uint64_t load_width(const uint8_t *src, int64_t i, int width) {
+  switch (width) {
+    case 1: return src[i];
+    case 2: return reinterpret_cast<const uint16_t *>(src)[i];
+    case 4: return reinterpret_cast<const uint32_t *>(src)[i];
+    default: return reinterpret_cast<const uint64_t *>(src)[i];
+  }
+}
+
+template <int JT, int TB, int RPT>
+__global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
+  constexpr int kWaves = TB / 64;
+  constexpr int kTile = TB * RPT;
+  __shared__ uint32_t s_cnt[RPT * kWaves];
+  __shared__ uint32_t s_pre[RPT * kWaves];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int64_t ntiles = (a.n + kTile - 1) / kTile;
+
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tbase = tile * kTile;
+    uint64_t k[RPT];
+    unsigned long long val[RPT];
+    bool found[RPT], inb[RPT], emit[RPT];
+    uint64_t idx[RPT];
+    Slot s[RPT];
+    // issue every first-step slot load of the tile before resolving any (memory-level parallelism)
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int64_t row = tbase + static_cast<int64_t>(j) * TB + tid;
+      inb[j] = row < a.n;
+      found[j] = false;
+      val[j] = 0;
+      k[j] = kEmptyKey;
+      bool probe = inb[j] && !col_is_null(a.key, row);
+      if (probe) {
+        k[j] = pack_key(a.key, row);
+        if (k[j] == kEmptyKey) {
+          found[j] = a.special->present != 0;
+          val[j] = a.special->val;
+        }
+      }
+      idx[j] = fmix64(k[j]) & a.mask;
+      if (k[j] != kEmptyKey) {
+        const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&a.slots[idx[j]]);
+        s[j].key = raw.x;
+        s[j].val = raw.y;
+      } else {
+        s[j].key = kEmptyKey;
+        s[j].val = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      if (k[j] != kEmptyKey) {
+        while (true) {
+          if (s[j].key == k[j]) {
+            found[j] = true;
+            val[j] = s[j].val;
+            break;
+          }
+          if (s[j].key == kEmptyKey) break;
+          idx[j] = (idx[j] + 1) & a.mask;
+          const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&a.slots[idx[j]]);
+          s[j].key = raw.x;
+          s[j].val = raw.y;
+        }
+      }
+      if (JT == CRGPU_INNER || JT == CRGPU_LEFT_SEMI || JT == CRGPU_RIGHT_OUTER) emit[j] = found[j];
+      else if (JT == CRGPU_LEFT_ANTI) emit[j] = inb[j] && !found[j];
+      else emit[j] = inb[j];  // LEFT / FULL OUTER keep every probe row
+      if (a.matched != nullptr && found[j]) a.matched[val[j]] = 1;
+    }
+    // output positions: row order within the tile is preserved
+    uint32_t rank[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint64_t m = __ballot(emit[j]);
+      rank[j] = rank_in_mask(m);
+      if (lane_id() == 0) s_cnt[j * kWaves + wave] = popc64(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int kPer = (RPT * kWaves + 63) / 64;
+      uint32_t e[kPer], sum = 0;
+#pragma unroll
+      for (int t = 0; t < kPer; t++) {
+        int q = lane_id() * kPer + t;
+        e[t] = q < RPT * kWaves ? s_cnt[q] : 0;
+        sum += e[t];
+      }
+      uint32_t incl = wave_incl_scan_u32(sum);
+      uint32_t ex = incl - sum;
+#pragma unroll
+      for (int t = 0; t < kPer; t++) {
+        int q = lane_id() * kPer + t;
+        if (q < RPT * kWaves) s_pre[q] = ex;
+        ex += e[t];
+      }
+      if (lane_id() == 63) s_base = incl ? atomicAdd(a.out_count, static_cast<unsigned long long>(incl)) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    int64_t pos[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) pos[j] = static_cast<int64_t>(base + s_pre[j * kWaves + wave] + rank[j]);
+
+    for (int c = 0; c < a.ncopy; c++) {
+      const CopyCol cc = a.copy[c];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (!emit[j]) continue;
+        const int64_t row = tbase + static_cast<int64_t>(j) * TB + tid;
+        uint64_t v = 0;
+        uint32_t present = 1;
+        if (cc.side == SIDE_PROBE) {
+          v = load_width(cc.src, row, cc.width);
+          if (cc.src_valid) present = (cc.src_valid[row >> 3] >> (row & 7)) & 1;
+        } else if (!found[j]) {
+          present = 0;  // outer join: NULL on the build side (hashjoiner.go:671-682)
+        } else if (cc.side == SIDE_BUILD) {
+          v = load_width(cc.src, static_cast<int64_t>(val[j]), cc.width);
+          if (cc.src_valid) present = (cc.src_valid[val[j] >> 3] >> (val[j] & 7)) & 1;
+        } else if (cc.side == SIDE_COVER) {
+          v = val[j];
+        } else {  // SIDE_KEYCAST: the build key equals the probe key numerically
+          v = k[j];
+        }
+        store_width(cc.dst, pos[j], cc.width, v);
+        if (cc.dst_valid) cc.dst_valid[pos[j]] = static_cast<uint8_t>(present);
+      }
+    }
+    if (a.pair_p != nullptr) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (!emit[j]) continue;
+        a.pair_p[pos[j]] = static_cast<int32_t>(tbase + static_cast<int64_t>(j) * TB + tid);
+        a.pair_b[pos[j]] = found[j] ? static_cast<int32_t>(val[j]) : -1;
+      }
+    }
+    __syncthreads();  // s_cnt / s_pre / s_base are reused by the next tile
+  }
+}
+
+// ------------------------------------------------------------------ CHAINED build / probe
+__global__ __launch_bounds__(256) void chain_build_kernel(KeyCols keys, int64_t n, bool null_eq, uint32_t nb_mask,
+                                                          uint32_t *__restrict__ first, uint32_t *__restrict__ next) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+    if (!null_eq && any_key_null(keys, row)) {
+      next[row] = 0;
+      continue;
+    }
+    const uint32_t h = hash_row32(keys, row, 1u) & nb_mask;
+    next[row] = atomicExch(&first[h], static_cast<uint32_t>(row) + 1u);
+  }
+}
+
+struct ChainArgs {
+  KeyCols probe, build;
+  int64_t n;
+  const uint32_t *first;
+  const uint32_t *next;
+  uint32_t nb_mask;
+  int32_t null_eq;
+  uint8_t *matched;       // build-row matched flags (RIGHT/FULL OUTER, RIGHT SEMI/ANTI)
+  unsigned int *claimed;  // "deleted" marks for INTERSECT/EXCEPT ALL (HashTableDeletingProbeMode, hashtable.go:46-58)
+  uint32_t *counts;       // pass 1 output
+  const uint64_t *offsets;  // pass 2 input
+  int32_t *pair_p, *pair_b;
+};
+
+// pass 1: number of output rows each probe row produces (and all side effects:
+// matched marks, claims).
+template <int JT>
+__global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    uint32_t cnt = 0;
+    bool found = false;
+    if (a.null_eq || !any_key_null(a.probe, i)) {
+      uint32_t cand = a.first[hash_row32(a.probe, i, 1u) & a.nb_mask];
+      while (cand != 0) {
+        const int64_t r = static_cast<int64_t>(cand) - 1;
+        if (keys_equal(a.probe, i, a.build, r, a.null_eq != 0)) {
+          if (JT == CRGPU_INTERSECT_ALL || JT == CRGPU_EXCEPT_ALL) {
+            if (atomicCAS(&a.claimed[r], 0u, 1u) == 0u) {
+              found = true;
+              break;
+            }
+          } else {
+            found = true;
+            cnt++;
+            if (a.matched != nullptr) a.matched[r] = 1;
+            if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
+          }
+        }
+        cand = a.next[r];
+      }
+    }
+    uint32_t out;
+    switch (JT) {
+      case CRGPU_INNER:
+      case CRGPU_RIGHT_OUTER: out = cnt; break;
+      case CRGPU_LEFT_OUTER:
+      case CRGPU_FULL_OUTER: out = cnt ? cnt : 1; break;
+      case CRGPU_LEFT_SEMI:
+      case CRGPU_INTERSECT_ALL: out = found; break;
+      case CRGPU_LEFT_ANTI:
+      case CRGPU_EXCEPT_ALL: out = !found; break;
+      default: out = 0; break;  // RIGHT SEMI / RIGHT ANTI emit nothing while probing
+    }
+    a.counts[i] = out;
+  }
+}
+
+// pass 3: write the (probe row, build row) pairs at the scanned offsets.
+template <int JT>
+__global__ __launch_bounds__(256) void chain_fill_kernel(ChainArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const uint32_t cnt = a.counts[i];
+    if (cnt == 0) continue;
+    uint64_t o = a.offsets[i];
+    constexpr bool kPairs = JT == CRGPU_INNER || JT == CRGPU_LEFT_OUTER || JT == CRGPU_RIGHT_OUTER || JT == CRGPU_FULL_OUTER;
+    if (!kPairs) {
+      a.pair_p[o] = static_cast<int32_t>(i);
+      continue;
+    }
+    uint32_t written = 0;
+    if (a.null_eq || !any_key_null(a.probe, i)) {
+      uint32_t cand = a.first[hash_row32(a.probe, i, 1u) & a.nb_mask];
+      while (cand != 0 && written < cnt) {
+        const int64_t r = static_cast<int64_t>(cand) - 1;
+        if (keys_equal(a.probe, i, a.build, r, a.null_eq != 0)) {
+          a.pair_p[o + written] = static_cast<int32_t>(i);
+          a.pair_b[o + written] = static_cast<int32_t>(r);
+          written++;
+        }
+        cand = a.next[r];
+      }
+    }
+    if (written == 0) {  // unmatched row of a LEFT/FULL OUTER join
+      a.pair_p[o] = static_cast<int32_t>(i);
+      a.pair_b[o] = -1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flag_eq_kernel(const uint8_t *__restrict__ in, int64_t n, uint8_t want,
+                                                      uint8_t *__restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = in[i] == want;
+}
+
+static inline int grid_for(int64_t n, int block) {
+  int64_t want = (n + block - 1) / block;
+  int64_t cap = static_cast<int64_t>(num_cus()) * 8;
+  if (want < 1) want = 1;
+  return static_cast<int>(want < cap ? want : cap);
+}
+static inline uint64_t next_pow2(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+}  // namespace crgpu
+
+using namespace crgpu;
+
+// ====================================================================== handle
+struct crgpu_join {
+  int join_type = 0;
+  bool right_distinct = false;      // after the MakeHashJoinerSpec overrides
+  bool track_build_matches = false;
+  bool null_eq = false;             // INTERSECT/EXCEPT ALL treat NULLs as equal (hashjoiner.go:264-268)
+  std::vector<int> left_types, right_types, left_eq, right_eq;
+  bool packed = false;
+
+  std::vector<DCol> build_cols;
+  int64_t n_build = 0;
+  bool built = false;
+
+  // packed table
+  DevBuf slots, special;
+  uint64_t cap = 0;
+  bool covering = false;
+  int cover_col = -1;
+  // chained table
+  DevBuf first, next;
+  uint32_t nb = 0;
+  // marks
+  DevBuf matched, claimed;
+  // scratch + outputs
+  DevBuf scratch, counts, offsets, pair_p, pair_b, counter, flags, null_data;
+  std::vector<OutCol> out;
+  std::vector<DevBuf> valid_bytes;  // per output column: one byte per row, packed after the fused kernel
+  std::vector<crgpu_dcol> views;
+};
+
+static bool left_in_output(int jt) { return !(jt == CRGPU_RIGHT_SEMI || jt == CRGPU_RIGHT_ANTI); }
+static bool right_in_output(int jt) {
+  return !(jt == CRGPU_LEFT_SEMI || jt == CRGPU_LEFT_ANTI || jt == CRGPU_INTERSECT_ALL || jt == CRGPU_EXCEPT_ALL);
+}
+static bool left_or_full_outer(int jt) { return jt == CRGPU_LEFT_OUTER || jt == CRGPU_FULL_OUTER; }
+
+static int key_family(int t) {
+  if (is_int_type(t)) return 1;
+  return 10 + t;
+}
+
+extern "C" crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu_join **out) {
+  CRGPU_TRY(ensure_init());
+  if (spec == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_create: null argument");
+  if (spec->join_type < CRGPU_INNER || spec->join_type > CRGPU_RIGHT_ANTI)
+    return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_create: unknown join type");
+  if (spec->n_eq < 1 || spec->n_eq > kMaxKeyCols)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_create: between 1 and 8 equality columns are supported");
+  if (spec->n_left_cols < 0 || spec->n_right_cols < 1 || spec->n_left_cols > kMaxCols || spec->n_right_cols > kMaxCols)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_create: column count out of range");
+  auto j = new crgpu_join();
+  j->join_type = spec->join_type;
+  for (int i = 0; i < spec->n_left_cols; i++) j->left_types.push_back(spec->left_types[i]);
+  for (int i = 0; i < spec->n_right_cols; i++) j->right_types.push_back(spec->right_types[i]);
+  for (int i = 0; i < spec->n_eq; i++) {
+    j->left_eq.push_back(spec->left_eq[i]);
+    j->right_eq.push_back(spec->right_eq[i]);
+  }
+  for (int t : j->left_types)
+    if (!valid_type(t)) { delete j; return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_create: unsupported left column type"); }
+  for (int t : j->right_types)
+    if (!valid_type(t)) { delete j; return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_create: unsupported right column type"); }
+  for (int i = 0; i < spec->n_eq; i++) {
+    int l = j->left_eq[i], r = j->right_eq[i];
+    if (l < 0 || l >= spec->n_left_cols || r < 0 || r >= spec->n_right_cols) {
+      delete j;
+      return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_create: equality column ordinal out of range");
+    }
+    // same family, or integers of mixed widths (hashtable_tmpl.go:275-281)
+    if (key_family(j->left_types[l]) != key_family(j->right_types[r])) {
+      delete j;
+      return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_create: equality columns of different type families");
+    }
+  }
+  // MakeHashJoinerSpec (hashjoiner.go:827-883)
+  int jt = j->join_type;
+  bool rd = spec->right_eq_cols_are_key != 0;
+  if (jt == CRGPU_LEFT_SEMI) rd = true;
+  else if (jt == CRGPU_LEFT_ANTI || jt == CRGPU_RIGHT_ANTI || jt == CRGPU_RIGHT_SEMI || jt == CRGPU_INTERSECT_ALL ||
+           jt == CRGPU_EXCEPT_ALL)
+    rd = false;
+  j->right_distinct = rd;
+  j->track_build_matches = jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER || jt == CRGPU_RIGHT_SEMI || jt == CRGPU_RIGHT_ANTI;
+  j->null_eq = jt == CRGPU_INTERSECT_ALL || jt == CRGPU_EXCEPT_ALL;
+  // The packed table keeps one row per key: usable whenever the first match
+  // decides the result (distinct build side, or pure existence tests).
+  bool first_match = rd || jt == CRGPU_LEFT_ANTI;
+  bool jt_ok = jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER ||
+               jt == CRGPU_LEFT_SEMI || jt == CRGPU_LEFT_ANTI;
+  int kt = j->right_types[j->right_eq[0]];
+  j->packed = spec->n_eq == 1 && first_match && jt_ok && kt != CRGPU_BYTES;
+  *out = j;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_dev_join_destroy(crgpu_join *j) {
+  if (j == nullptr) return;
+  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
+  delete j;
+}
+
+extern "C" crgpu_status crgpu_dev_join_reset(crgpu_join *j) {
+  if (j == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_reset: null handle");
+  j->built = false;
+  j->n_build = 0;
+  j->build_cols.clear();
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
+  if (j == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null handle");
+  if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_build: build side limited to 2^31 rows per table");
+  if (n > 0 && right_cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null columns");
+  const int nr = static_cast<int>(j->right_types.size());
+  j->build_cols.clear();
+  for (int c = 0; c < nr; c++) {
+    DCol d{j->right_types[c], 0, nullptr, nullptr, nullptr};
+    if (n > 0) {
+      if (right_cols[c].type != j->right_types[c]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: column type differs from the spec");
+      if (right_cols[c].type == CRGPU_BYTES && right_cols[c].offsets == nullptr)
+        return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: BYTES column without offsets");
+      if (right_cols[c].type != CRGPU_BYTES && right_cols[c].data == nullptr)
+        return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null data pointer");
+      d = to_dcol(right_cols[c]);
+    }
+    j->build_cols.push_back(d);
+  }
+  j->n_build = n;
+  hipStream_t st = stream();
+
+  if (j->track_build_matches) {
+    CRGPU_TRY(j->matched.ensure(static_cast<size_t>(n > 0 ? n : 1)));
+    CRGPU_HIP(hipMemsetAsync(j->matched.p, 0, static_cast<size_t>(n > 0 ? n : 1), st));
+  }
+  if (j->null_eq) {  // set-operation joins
+    CRGPU_TRY(j->claimed.ensure(static_cast<size_t>(n > 0 ? n : 1) * 4));
+    CRGPU_HIP(hipMemsetAsync(j->claimed.p, 0, static_cast<size_t>(n > 0 ? n : 1) * 4, st));
+  }
+
+  if (j->packed) {
+    const int kc = j->right_eq[0];
+    j->cap = next_pow2(static_cast<uint64_t>(n) * 2 < 1024 ? 1024 : static_cast<uint64_t>(n) * 2);
+    CRGPU_TRY(j->slots.ensure(j->cap * sizeof(Slot)));
+    CRGPU_TRY(j->special.ensure(sizeof(Special)));
+    CRGPU_HIP(hipMemsetAsync(j->slots.p, 0xFF, j->cap * sizeof(Slot), st));
+    CRGPU_HIP(hipMemsetAsync(j->special.p, 0, sizeof(Special), st));
+    // covering: build side is {int/bool key} or {int/bool key, one 8-byte non-null payload}
+    j->covering = false;
+    j->cover_col = -1;
+    const int jt = j->join_type;
+    const bool key_castable = j->right_types[kc] != CRGPU_FLOAT64 && j->build_cols[kc].valid == nullptr;
+    if (!j->track_build_matches && key_castable && right_in_output(jt)) {
+      if (nr == 1) {
+        j->covering = true;
+      } else if (nr == 2) {
+        int pc = 1 - kc;
+        if (type_width(j->right_types[pc]) == 8 && j->build_cols[pc].valid == nullptr) {
+          j->covering = true;
+          j->cover_col = pc;
+        }
+      }
+    }
+    if (n > 0) {
+      const uint64_t *payload = (j->covering && j->cover_col >= 0)
+                                    ? static_cast<const uint64_t *>(j->build_cols[j->cover_col].data)
+                                    : nullptr;
+      ProfScope prof("join_build");
+      hipLaunchKernelGGL(packed_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, j->build_cols[kc], n,
+                         j->slots.as<Slot>(), j->cap - 1, payload, j->special.as<Special>());
+      CRGPU_HIP(hipGetLastError());
+    }
+  } else {
+    uint64_t nb = next_pow2(static_cast<uint64_t>(n) < 256 ? 256 : static_cast<uint64_t>(n));
+    if (nb > 0x80000000ull) nb = 0x80000000ull;
+    j->nb = static_cast<uint32_t>(nb);
+    CRGPU_TRY(j->first.ensure(static_cast<size_t>(nb) * 4));
+    CRGPU_TRY(j->next.ensure(static_cast<size_t>(n > 0 ? n : 1) * 4));
+    CRGPU_HIP(hipMemsetAsync(j->first.p, 0, static_cast<size_t>(nb) * 4, st));
+    if (n > 0) {
+      KeyCols keys;
+      keys.n = static_cast<int>(j->right_eq.size());
+      keys._pad = 0;
+      for (int k = 0; k < keys.n; k++) keys.c[k] = j->build_cols[j->right_eq[k]];
+      ProfScope prof("join_build");
+      hipLaunchKernelGGL(chain_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n, j->null_eq,
+                         j->nb - 1, j->first.as<uint32_t>(), j->next.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+    }
+  }
+  CRGPU_HIP(hipStreamSynchronize(st));
+  j->built = true;
+  return CRGPU_OK;
+}
+
+// Output column bookkeeping ------------------------------------------------
+static void join_setup_outputs(crgpu_join *j) {
+  const int jt = j->join_type;
+  size_t nout = (left_in_output(jt) ? j->left_types.size() : 0) + (right_in_output(jt) ? j->right_types.size() : 0);
+  if (j->out.size() != nout) {
+    j->out = std::vector<OutCol>(nout);
+    j->valid_bytes = std::vector<DevBuf>(nout);
+    j->views.resize(nout);
+  }
+}
+
+// All-NULL column of `n` rows (emitRight's probe side, hashjoiner.go:436-443).
+static crgpu_status make_null_col(int type, int64_t n, OutCol &o) {
+  o.type = type;
+  o.nullable = true;
+  size_t w = type == CRGPU_BYTES ? 1 : type_width(type);
+  CRGPU_TRY(o.data.ensure(static_cast<size_t>(n > 0 ? n : 1) * w));
+  CRGPU_HIP(hipMemsetAsync(o.data.p, 0, static_cast<size_t>(n > 0 ? n : 1) * w, stream()));
+  CRGPU_TRY(o.valid.ensure(static_cast<size_t>((n + 7) / 8 + 1)));
+  CRGPU_HIP(hipMemsetAsync(o.valid.p, 0, static_cast<size_t>((n + 7) / 8 + 1), stream()));
+  if (type == CRGPU_BYTES) {
+    CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(n + 1) * 4));
+    CRGPU_HIP(hipMemsetAsync(o.offsets.p, 0, static_cast<size_t>(n + 1) * 4, stream()));
+  }
+  return CRGPU_OK;
+}
+
+static crgpu_status finish_result(crgpu_join *j, int64_t n, crgpu_dev_result *res) {
+  for (size_t c = 0; c < j->out.size(); c++) j->views[c] = j->out[c].view();
+  res->n = n;
+  res->ncols = static_cast<int32_t>(j->out.size());
+  res->_pad = 0;
+  res->cols = j->views.data();
+  return CRGPU_OK;
+}
+
+template <int TB, int RPT>
+static crgpu_status launch_packed_probe(int jt, const ProbeArgs &a, int grid) {
+  hipStream_t st = stream();
+  switch (jt) {
+    case CRGPU_INNER: hipLaunchKernelGGL((packed_probe_kernel<CRGPU_INNER, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_LEFT_OUTER: hipLaunchKernelGGL((packed_probe_kernel<CRGPU_LEFT_OUTER, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_RIGHT_OUTER: hipLaunchKernelGGL((packed_probe_kernel<CRGPU_RIGHT_OUTER, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_FULL_OUTER: hipLaunchKernelGGL((packed_probe_kernel<CRGPU_FULL_OUTER, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_LEFT_SEMI: hipLaunchKernelGGL((packed_probe_kernel<CRGPU_LEFT_SEMI, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_LEFT_ANTI: hipLaunchKernelGGL((packed_probe_kernel<CRGPU_LEFT_ANTI, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    default: return fail(CRGPU_ERR_INVALID, "packed probe: join type not handled by the packed table");
+  }
+  CRGPU_HIP(hipGetLastError());
+  return CRGPU_OK;
+}
+
+static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, int64_t n, crgpu_dev_result *res) {
+  const int jt = j->join_type;
+  const int nl = static_cast<int>(left.size()), nr = static_cast<int>(j->right_types.size());
+  const bool outer_nulls = left_or_full_outer(jt);
+  hipStream_t st = stream();
+  const int64_t cap_rows = n > 0 ? n : 1;  // first-match joins emit at most one row per probe row
+
+  ProbeArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.key = left[j->left_eq[0]];
+  a.n = n;
+  a.slots = j->slots.as<Slot>();
+  a.mask = j->cap - 1;
+  a.special = j->special.as<Special>();
+  a.matched = j->track_build_matches ? j->matched.as<uint8_t>() : nullptr;
+  CRGPU_TRY(j->counter.ensure(8));
+  CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
+  a.out_count = j->counter.as<unsigned long long>();
+
+  // Decide per output column: fused into the probe kernel, or materialised afterwards through pairs.
+  struct Later { int out_idx; bool is_left; int src; };
+  std::vector<Later> later;
+  std::vector<int> fused_out;
+  int oc = 0;
+  auto add_fused = [&](const uint8_t *src, const uint8_t *src_valid, int type, int side, bool nullable) -> crgpu_status {
+    OutCol &o = j->out[oc];
+    o.type = type;
+    o.nullable = nullable;
+    CRGPU_TRY(o.data.ensure(static_cast<size_t>(cap_rows) * type_width(type)));
+    CopyCol &cc = a.copy[a.ncopy++];
+    fused_out.push_back(oc);
+    cc.src = src;
+    cc.dst = o.data.as<uint8_t>();
+    cc.src_valid = src_valid;
+    cc.width = type_width(type);
+    cc.side = side;
+    cc.dst_valid = nullptr;
+    if (nullable) {
+      CRGPU_TRY(j->valid_bytes[oc].ensure(static_cast<size_t>(cap_rows)));
+      CRGPU_TRY(o.valid.ensure(static_cast<size_t>((cap_rows + 7) / 8 + 1)));
+      cc.dst_valid = j->valid_bytes[oc].as<uint8_t>();
+    }
+    return CRGPU_OK;
+  };
+  for (int c = 0; c < nl; c++, oc++) {
+    if (left[c].type != CRGPU_BYTES && a.ncopy < kMaxFused)
+      CRGPU_TRY(add_fused(static_cast<const uint8_t *>(left[c].data), left[c].valid, left[c].type, SIDE_PROBE,
+                          left[c].valid != nullptr));
+    else
+      later.push_back(Later{oc, true, c});
+  }
+  if (right_in_output(jt)) {
+    for (int c = 0; c < nr; c++, oc++) {
+      const DCol &b = j->build_cols[c];
+      if (j->covering && c == j->right_eq[0] && a.ncopy < kMaxFused) {
+        CRGPU_TRY(add_fused(nullptr, nullptr, b.type, SIDE_KEYCAST, outer_nulls));
+      } else if (j->covering && c == j->cover_col && a.ncopy < kMaxFused) {
+        CRGPU_TRY(add_fused(nullptr, nullptr, b.type, SIDE_COVER, outer_nulls));
+      } else if (!j->covering && b.type != CRGPU_BYTES && a.ncopy < kMaxFused) {
+        CRGPU_TRY(add_fused(static_cast<const uint8_t *>(b.data), b.valid, b.type, SIDE_BUILD,
+                            outer_nulls || b.valid != nullptr));
+      } else {
+        later.push_back(Later{oc, false, c});
+      }
+    }
+  }
+  if (!later.empty()) {
+    CRGPU_TRY(j->pair_p.ensure(static_cast<size_t>(cap_rows) * 4));
+    CRGPU_TRY(j->pair_b.ensure(static_cast<size_t>(cap_rows) * 4));
+    a.pair_p = j->pair_p.as<int32_t>();
+    a.pair_b = j->pair_b.as<int32_t>();
+  }
+
+  uint64_t nout = 0;
+  if (n > 0) {
+    constexpr int TB = 1024, RPT = 8;
+    int64_t ntiles = (n + TB * RPT - 1) / (TB * RPT);
+    int64_t cap_grid = static_cast<int64_t>(num_cus()) * 2;
+    int grid = static_cast<int>(ntiles < cap_grid ? ntiles : cap_grid);
+    {
+      ProfScope prof("join_probe");
+      CRGPU_TRY((launch_packed_probe<TB, RPT>(jt, a, grid)));
+    }
+    CRGPU_HIP(hipMemcpyAsync(&nout, j->counter.p, 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+  }
+  for (int c = 0; c < a.ncopy; c++)  // pack the validity bytes of fused nullable columns into bitmaps
+    if (a.copy[c].dst_valid != nullptr)
+      CRGPU_TRY(pack_bitmap(a.copy[c].dst_valid, static_cast<int64_t>(nout), j->out[fused_out[c]].valid.as<uint8_t>()));
+  for (const Later &l : later) {
+    if (l.is_left)
+      CRGPU_TRY(materialize(left[l.src], j->pair_p.as<int32_t>(), static_cast<int64_t>(nout), false, j->out[l.out_idx], j->scratch));
+    else
+      CRGPU_TRY(materialize(j->build_cols[l.src], j->pair_b.as<int32_t>(), static_cast<int64_t>(nout), outer_nulls,
+                            j->out[l.out_idx], j->scratch));
+  }
+  CRGPU_HIP(hipStreamSynchronize(st));
+  return finish_result(j, static_cast<int64_t>(nout), res);
+}
+
+template <int JT>
+static void launch_chain(const ChainArgs &a, bool fill) {
+  int grid = grid_for(a.n, 256);
+  if (fill) hipLaunchKernelGGL(chain_fill_kernel<JT>, dim3(grid), dim3(256), 0, stream(), a);
+  else hipLaunchKernelGGL(chain_count_kernel<JT>, dim3(grid), dim3(256), 0, stream(), a);
+}
+static crgpu_status launch_chain_jt(int jt, const ChainArgs &a, bool fill) {
+  switch (jt) {
+    case CRGPU_INNER: launch_chain<CRGPU_INNER>(a, fill); break;
+    case CRGPU_LEFT_OUTER: launch_chain<CRGPU_LEFT_OUTER>(a, fill); break;
+    case CRGPU_RIGHT_OUTER: launch_chain<CRGPU_RIGHT_OUTER>(a, fill); break;
+    case CRGPU_FULL_OUTER: launch_chain<CRGPU_FULL_OUTER>(a, fill); break;
+    case CRGPU_LEFT_SEMI: launch_chain<CRGPU_LEFT_SEMI>(a, fill); break;
+    case CRGPU_LEFT_ANTI: launch_chain<CRGPU_LEFT_ANTI>(a, fill); break;
+    case CRGPU_INTERSECT_ALL: launch_chain<CRGPU_INTERSECT_ALL>(a, fill); break;
+    case CRGPU_EXCEPT_ALL: launch_chain<CRGPU_EXCEPT_ALL>(a, fill); break;
+    case CRGPU_RIGHT_SEMI: launch_chain<CRGPU_RIGHT_SEMI>(a, fill); break;
+    case CRGPU_RIGHT_ANTI: launch_chain<CRGPU_RIGHT_ANTI>(a, fill); break;
+    default: return fail(CRGPU_ERR_INVALID, "chained probe: unknown join type");
+  }
+  CRGPU_HIP(hipGetLastError());
+  return CRGPU_OK;
+}
+
+static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, int64_t n, crgpu_dev_result *res) {
+  const int jt = j->join_type;
+  const int nl = static_cast<int>(left.size()), nr = static_cast<int>(j->right_types.size());
+  hipStream_t st = stream();
+  uint64_t total = 0;
+  if (n > 0) {
+    ChainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.probe.n = a.build.n = static_cast<int>(j->left_eq.size());
+    for (int k = 0; k < a.probe.n; k++) {
+      a.probe.c[k] = left[j->left_eq[k]];
+      a.build.c[k] = j->build_cols[j->right_eq[k]];
+    }
+    a.n = n;
+    a.first = j->first.as<uint32_t>();
+    a.next = j->next.as<uint32_t>();
+    a.nb_mask = j->nb - 1;
+    a.null_eq = j->null_eq;
+    a.matched = j->track_build_matches ? j->matched.as<uint8_t>() : nullptr;
+    a.claimed = j->null_eq ? j->claimed.as<unsigned int>() : nullptr;
+    CRGPU_TRY(j->counts.ensure(static_cast<size_t>(n) * 4));
+    CRGPU_TRY(j->offsets.ensure(static_cast<size_t>(n + 1) * 8));
+    a.counts = j->counts.as<uint32_t>();
+    a.offsets = j->offsets.as<uint64_t>();
+    {
+      ProfScope prof("join_probe");
+      CRGPU_TRY(launch_chain_jt(jt, a, false));
+    }
+    if (left_in_output(jt)) {
+      CRGPU_TRY(exclusive_scan_u32(a.counts, n, j->offsets.as<uint64_t>(), j->scratch, &total));
+      if (total > 0x7FFFFFF0ull)
+        return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_probe: more than 2^31 output rows for one probe chunk; probe in smaller chunks");
+      CRGPU_TRY(j->pair_p.ensure(static_cast<size_t>(total ? total : 1) * 4));
+      CRGPU_TRY(j->pair_b.ensure(static_cast<size_t>(total ? total : 1) * 4));
+      a.pair_p = j->pair_p.as<int32_t>();
+      a.pair_b = j->pair_b.as<int32_t>();
+      if (total > 0) {
+        ProfScope prof("join_probe");
+        CRGPU_TRY(launch_chain_jt(jt, a, true));
+      }
+    }
+  }
+  int oc = 0;
+  if (left_in_output(jt)) {
+    for (int c = 0; c < nl; c++, oc++)
+      CRGPU_TRY(materialize(left[c], j->pair_p.as<int32_t>(), static_cast<int64_t>(total), false, j->out[oc], j->scratch));
+    if (right_in_output(jt))
+      for (int c = 0; c < nr; c++, oc++)
+        CRGPU_TRY(materialize(j->build_cols[c], j->pair_b.as<int32_t>(), static_cast<int64_t>(total),
+                              left_or_full_outer(jt), j->out[oc], j->scratch));
+  } else {
+    // RIGHT SEMI / RIGHT ANTI: nothing while probing; keep well-formed empty columns
+    for (int c = 0; c < nr; c++, oc++) CRGPU_TRY(make_null_col(j->right_types[c], 0, j->out[oc]));
+    total = 0;
+  }
+  CRGPU_HIP(hipStreamSynchronize(st));
+  return finish_result(j, static_cast<int64_t>(total), res);
+}
+
+extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
+                                             crgpu_dev_result *res) {
+  if (j == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: null argument");
+  if (!j->built) return fail(CRGPU_ERR_STATE, "crgpu_dev_join_probe: build side not built");
+  if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_probe: at most 2^31 rows per probe chunk");
+  if (n > 0 && left_cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: null columns");
+  const int nl = static_cast<int>(j->left_types.size());
+  std::vector<DCol> left;
+  for (int c = 0; c < nl; c++) {
+    DCol d{j->left_types[c], 0, nullptr, nullptr, nullptr};
+    if (n > 0) {
+      if (left_cols[c].type != j->left_types[c]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: column type differs from the spec");
+      if (left_cols[c].type == CRGPU_BYTES && left_cols[c].offsets == nullptr)
+        return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: BYTES column without offsets");
+      if (left_cols[c].type != CRGPU_BYTES && left_cols[c].data == nullptr)
+        return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: null data pointer");
+      d = to_dcol(left_cols[c]);
+    }
+    left.push_back(d);
+  }
+  join_setup_outputs(j);
+  // Empty build side short-circuits (hashjoiner.go:300-306, join_type.go:79-88): the
+  // kernels below already produce the right answer on an empty table, so no special case.
+  if (j->packed) return probe_packed(j, left, n, res);
+  return probe_chained(j, left, n, res);
+}
+
+extern "C" crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_result *res) {
+  if (j == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_emit_right: null argument");
+  if (!j->built) return fail(CRGPU_ERR_STATE, "crgpu_dev_join_emit_right: build side not built");
+  join_setup_outputs(j);
+  const int jt = j->join_type;
+  const int nl = static_cast<int>(j->left_types.size()), nr = static_cast<int>(j->right_types.size());
+  int64_t count = 0;
+  if (j->track_build_matches && j->n_build > 0) {
+    const int64_t n = j->n_build;
+    CRGPU_TRY(j->flags.ensure(static_cast<size_t>(n)));
+    CRGPU_TRY(j->pair_b.ensure(static_cast<size_t>(n) * 4));
+    const uint8_t want = jt == CRGPU_RIGHT_SEMI ? 1 : 0;  // emitRight(matched) hashjoiner.go:327,405
+    hipLaunchKernelGGL(flag_eq_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream(), j->matched.as<uint8_t>(), n, want,
+                       j->flags.as<uint8_t>());
+    CRGPU_HIP(hipGetLastError());
+    CRGPU_TRY(select_flagged(j->flags.as<uint8_t>(), n, j->pair_b.as<int32_t>(), j->scratch, &count));
+  }
+  int oc = 0;
+  if (left_in_output(jt))
+    for (int c = 0; c < nl; c++, oc++) CRGPU_TRY(make_null_col(j->left_types[c], count, j->out[oc]));
+  if (right_in_output(jt) || !left_in_output(jt))
+    for (int c = 0; c < nr; c++, oc++)
+      CRGPU_TRY(materialize(j->build_cols[c], j->pair_b.as<int32_t>(), count, false, j->out[oc], j->scratch));
+  CRGPU_HIP(hipStreamSynchronize(stream()));
+  return finish_result(j, count, res);
+}

@@ -1,0 +1,250 @@
+"""Thin Python face of the bulk device API (include/crgpu.h, layer 1).
+
+Used by bench.py and the GPU parity tests.  It only moves pointers around:
+every operation is a call into libcrgpu.so through ctypes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import coldata as cd
+
+
+class DeviceBuffer:
+    """Raw HBM allocation owned by Python (crgpu_dev_malloc / crgpu_dev_free)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_malloc(C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+
+    @staticmethod
+    def from_numpy(arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        b = DeviceBuffer(arr.nbytes)
+        if arr.nbytes:
+            _lib.check(_lib.load().crgpu_dev_memcpy_h2d(b.ptr, arr.ctypes.data, arr.nbytes))
+        return b
+
+    def to_numpy(self, dtype, count) -> np.ndarray:
+        return download(self.ptr, dtype, count)
+
+    def free(self):
+        if self.ptr:
+            _lib.load().crgpu_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def download(ptr, dtype, count) -> np.ndarray:
+    out = np.empty(int(count), dtype=dtype)
+    if out.nbytes:
+        _lib.check(_lib.load().crgpu_dev_memcpy_d2h(out.ctypes.data, ptr, out.nbytes))
+    return out
+
+
+class DeviceColumn:
+    """One device-resident column (crgpu_dcol) plus whatever keeps its memory alive."""
+
+    def __init__(self, typ, n, data_ptr, valid_ptr=None, offsets_ptr=None, keep=None):
+        self.type, self.n = typ, int(n)
+        self.data_ptr, self.valid_ptr, self.offsets_ptr = data_ptr, valid_ptr, offsets_ptr
+        self.keep = keep
+
+    def dcol(self) -> _lib.DCol:
+        return _lib.DCol(self.type, 0, self.data_ptr, self.valid_ptr, self.offsets_ptr)
+
+
+def upload(vec: cd.Vec) -> DeviceColumn:
+    keep = []
+    data = DeviceBuffer.from_numpy(vec.data)
+    keep.append(data)
+    valid = offs = None
+    if vec.valid is not None:
+        valid = DeviceBuffer.from_numpy(vec.valid)
+        keep.append(valid)
+    if vec.type == cd.BYTES:
+        offs = DeviceBuffer.from_numpy(vec.offsets)
+        keep.append(offs)
+    return DeviceColumn(vec.type, len(vec), data.ptr, valid.ptr if valid else None, offs.ptr if offs else None, keep)
+
+
+def from_torch(typ, tensor, valid=None, offsets=None) -> DeviceColumn:
+    """Wrap torch CUDA tensors (no copy)."""
+    n = (offsets.numel() - 1) if typ == cd.BYTES else tensor.numel()
+    return DeviceColumn(typ, n, tensor.data_ptr(), None if valid is None else valid.data_ptr(),
+                        None if offsets is None else offsets.data_ptr(), keep=(tensor, valid, offsets))
+
+
+def dcol_array(cols):
+    arr = (_lib.DCol * max(len(cols), 1))()
+    for i, c in enumerate(cols):
+        arr[i] = c.dcol()
+    return arr
+
+
+def result_to_vecs(res: _lib.DevResult):
+    """Copy a library-owned device result back to host Vecs."""
+    n, out = int(res.n), []
+    for i in range(res.ncols):
+        c = res.cols[i]
+        valid = download(c.valid, np.uint8, (n + 7) // 8) if c.valid else None
+        if c.type == cd.BYTES:
+            offs = download(c.offsets, np.uint32, n + 1)
+            total = int(offs[-1]) if n else 0
+            data = download(c.data, np.uint8, total)
+            out.append(cd.Vec(cd.BYTES, data, valid, offs))
+        else:
+            out.append(cd.Vec(c.type, download(c.data, cd.NP_DTYPE[c.type], n), valid))
+    return out
+
+
+def result_columns(res: _lib.DevResult):
+    """Device-resident views of a result (valid until the next call on the handle)."""
+    return [DeviceColumn(res.cols[i].type, res.n, res.cols[i].data, res.cols[i].valid, res.cols[i].offsets)
+            for i in range(res.ncols)]
+
+
+def _i32arr(xs):
+    xs = list(xs)
+    return (C.c_int32 * max(len(xs), 1))(*xs)
+
+
+def hash_cols(cols, n=None, init=1, width=64, nbuckets=0) -> np.ndarray:
+    """colexechash.rehash over device columns; returns the hashes on the host."""
+    n = cols[0].n if n is None else n
+    dt = np.uint32 if width == 32 else np.uint64
+    out = DeviceBuffer(max(n, 1) * np.dtype(dt).itemsize)
+    _lib.check(_lib.load().crgpu_dev_hash_cols(dcol_array(cols), len(cols), n, init, width, nbuckets, out.ptr))
+    return out.to_numpy(dt, n)
+
+
+class Join:
+    """crgpu_join handle: build once, probe chunk by chunk, then emit_right."""
+
+    def __init__(self, join_type, left_types, right_types, left_eq, right_eq, right_eq_cols_are_key=False):
+        self._keep = (_i32arr(left_types), _i32arr(right_types), _i32arr(left_eq), _i32arr(right_eq))
+        spec = _lib.JoinSpec(join_type, int(bool(right_eq_cols_are_key)), len(left_types), len(right_types),
+                             self._keep[0], self._keep[1], len(left_eq), 0, self._keep[2], self._keep[3])
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_join_create(C.byref(spec), C.byref(self.h)))
+        self._build_cols = None
+
+    def build(self, cols, n=None):
+        self._build_cols = cols  # borrowed by the library until reset/destroy
+        n = (cols[0].n if cols else 0) if n is None else n
+        _lib.check(_lib.load().crgpu_dev_join_build(self.h, dcol_array(cols), n))
+
+    def probe(self, cols, n=None) -> _lib.DevResult:
+        n = (cols[0].n if cols else 0) if n is None else n
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_join_probe(self.h, dcol_array(cols), n, C.byref(res)))
+        return res
+
+    def emit_right(self) -> _lib.DevResult:
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_join_emit_right(self.h, C.byref(res)))
+        return res
+
+    def reset(self):
+        _lib.check(_lib.load().crgpu_dev_join_reset(self.h))
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_join_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Agg:
+    """crgpu_agg handle (online hash aggregation)."""
+
+    def __init__(self, types, group_cols, aggs):
+        """aggs: list of (func, col or -1, filter_col or -1[, distinct])."""
+        self._types, self._groups = _i32arr(types), _i32arr(group_cols)
+        self._aggs = (_lib.AggDesc * max(len(aggs), 1))()
+        for i, a in enumerate(aggs):
+            self._aggs[i] = _lib.AggDesc(a[0], a[1], a[2] if len(a) > 2 else -1, int(a[3]) if len(a) > 3 else 0)
+        spec = _lib.AggSpec(len(types), len(group_cols), self._types, self._groups, len(aggs), 0, self._aggs)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_agg_create(C.byref(spec), C.byref(self.h)))
+
+    def consume(self, cols, n=None):
+        n = (cols[0].n if cols else 0) if n is None else n
+        _lib.check(_lib.load().crgpu_dev_agg_consume(self.h, dcol_array(cols), n))
+
+    def finish(self) -> _lib.DevResult:
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_agg_finish(self.h, C.byref(res)))
+        return res
+
+    def reset(self):
+        _lib.check(_lib.load().crgpu_dev_agg_reset(self.h))
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_agg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Partitioner:
+    """crgpu_partitioner handle: hash-repartition rows into num_outputs contiguous regions."""
+
+    def __init__(self, types, hash_cols, num_outputs, init=1):
+        self._types, self._hc = _i32arr(types), _i32arr(hash_cols)
+        self.num_outputs = num_outputs
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_partitioner_create(self._types, len(types), self._hc, len(hash_cols), init,
+                                                            num_outputs, C.byref(self.h)))
+
+    def partition(self, cols, n=None):
+        n = (cols[0].n if cols else 0) if n is None else n
+        res = _lib.DevResult()
+        counts = (C.c_int64 * self.num_outputs)()
+        _lib.check(_lib.load().crgpu_dev_partition(self.h, dcol_array(cols), n, C.byref(res), counts))
+        return res, np.array(list(counts), dtype=np.int64)
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_partitioner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prof_enable(on=True):
+    _lib.load().crgpu_prof_enable(int(on))
+
+
+def prof_reset():
+    _lib.load().crgpu_prof_reset()
+
+
+def prof_get(name):
+    ms, n = C.c_double(0), C.c_int64(0)
+    _lib.check(_lib.load().crgpu_prof_get(name.encode(), C.byref(ms), C.byref(n)))
+    return ms.value, n.value

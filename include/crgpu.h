@@ -1,0 +1,290 @@
+/*
+ * crgpu.h -- C ABI of the MI355X-native hash path for CockroachDB's vectorized
+ * engine (hashing -> hash table build/probe -> hash aggregation -> hash
+ * repartition).  This is the drop-in boundary: exactly what a cgo shim in the
+ * reference would bind (INTEGRATION.md shows the Go side).  Plain pointers and
+ * sizes only; no C++/torch types; no exceptions cross it.
+ *
+ * Two layers are exported:
+ *
+ *  (1) crgpu_dev_*  -- the bulk, device-resident hot path.  Columns live in HBM
+ *      in an Arrow-like layout (crgpu_dcol).  One call processes arbitrarily
+ *      many rows.  This is what bench.py measures.
+ *  (2) crgpu_hj_* / crgpu_agg_* / crgpu_route_* / crgpu_hash_cols -- the operator
+ *      layer that takes coldata.Batch-shaped HOST memory exactly as Go lays it
+ *      out (crgpu_col / crgpu_batch), stages it to the device, drives layer (1)
+ *      and hands results back in <= coldata.BatchSize() output batches, i.e. the
+ *      colexecop.Operator Next() contract (pkg/sql/colexecop/operator.go:22-58).
+ *
+ * Error style follows the in-tree cgo precedent pkg/geo/geos/geos.h:13-61:
+ * every call returns a status; crgpu_last_error() gives the message for the
+ * calling thread.  Handles are NOT thread-safe (Init/Next are single-goroutine,
+ * operator.go:36,54) except crgpu_route_* (internally locked; routers.go:486-488).
+ *
+ * Reference paths below are relative to /root/reference/pkg.
+ */
+#ifndef CRGPU_H
+#define CRGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- status */
+typedef int32_t crgpu_status;
+#define CRGPU_OK 0
+#define CRGPU_ERR_INVALID 1          /* bad argument / spec -> colexecerror.InternalError */
+#define CRGPU_ERR_UNSUPPORTED 2      /* type / aggregate / spec outside the GPU path: plan the reference operator instead
+                                        (pattern: supportedNatively, sql/colexec/colbuilder/execplan.go:149) */
+#define CRGPU_ERR_OOM 3              /* HBM exhausted -> memory-budget error so the disk spiller engages
+                                        (sql/colexec/colexecdisk/disk_spiller.go:81) */
+#define CRGPU_ERR_INT_OUT_OF_RANGE 4 /* tree.ErrIntOutOfRange via colexecerror.ExpectedError
+                                        (sql/colexec/colexecagg/hash_sum_int_agg.eg.go:295-298) */
+#define CRGPU_ERR_HIP 5              /* HIP runtime failure */
+#define CRGPU_ERR_NO_DEVICE 6        /* no gfx950 device visible */
+#define CRGPU_ERR_STATE 7            /* call made in the wrong operator state */
+
+/* canonical type families: col/typeconv/typeconv.go:30 */
+typedef enum {
+  CRGPU_BOOL = 0, CRGPU_INT16 = 1, CRGPU_INT32 = 2, CRGPU_INT64 = 3, CRGPU_FLOAT64 = 4, CRGPU_BYTES = 5
+} crgpu_type;
+
+/* descpb.JoinType: sql/catalog/descpb/join_type.proto:13-83 */
+typedef enum {
+  CRGPU_INNER = 0, CRGPU_LEFT_OUTER = 1, CRGPU_RIGHT_OUTER = 2, CRGPU_FULL_OUTER = 3, CRGPU_LEFT_SEMI = 4,
+  CRGPU_LEFT_ANTI = 5, CRGPU_INTERSECT_ALL = 6, CRGPU_EXCEPT_ALL = 7, CRGPU_RIGHT_SEMI = 8, CRGPU_RIGHT_ANTI = 9
+} crgpu_join_type;
+
+/* execinfrapb.AggregatorSpec_Func: sql/execinfrapb/processors_sql.proto:778-791 */
+typedef enum {
+  CRGPU_ANY_NOT_NULL = 0, CRGPU_AVG = 1, CRGPU_BOOL_AND = 2, CRGPU_BOOL_OR = 3, CRGPU_COUNT = 5, CRGPU_MAX = 7,
+  CRGPU_MIN = 8, CRGPU_SUM = 10, CRGPU_SUM_INT = 11, CRGPU_COUNT_ROWS = 14
+} crgpu_agg_func;
+
+/* ------------------------------------------------------------ lifecycle */
+/* Selects HIP device `device` for the calling process (one process per GPU)
+ * and creates the library stream.  Idempotent. */
+crgpu_status crgpu_init(int32_t device);
+void crgpu_shutdown(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char *crgpu_last_error(void);
+/* Device bytes currently held by the library; the Go shell reports the delta
+ * through colmem.Allocator.AdjustMemoryUsage (sql/colmem/allocator.go:526). */
+int64_t crgpu_mem_usage(void);
+
+/* Kernel timing with HIP events on the library stream (for bench.py's roofline
+ * object; batchInfoCollector-style stats, sql/colflow/stats.go:41-137).
+ * `name` is a kernel family: "hash", "join_build", "join_probe", "agg",
+ * "partition", "decode". */
+void crgpu_prof_enable(int32_t on);
+void crgpu_prof_reset(void);
+crgpu_status crgpu_prof_get(const char *name, double *total_ms, int64_t *launches);
+
+/* Raw device memory helpers for callers that do not bring their own allocator
+ * (the Go shell stages coldata batches through these; torch callers pass
+ * tensor.data_ptr() instead).  Copies are synchronous. */
+crgpu_status crgpu_dev_malloc(void **out, size_t bytes);
+void crgpu_dev_free(void *p);
+crgpu_status crgpu_dev_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+crgpu_status crgpu_dev_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+crgpu_status crgpu_dev_synchronize(void);
+
+/* ============================================================ layer (1) */
+/* Device-resident column.  Fixed-width families: dense array in `data`.
+ * BYTES: `offsets[n+1]` (uint32) into the flat `data` buffer.
+ * `valid`: validity bitmap with coldata.Nulls bit convention (LSB first,
+ * bit = 1 => present; col/coldata/nulls.go:184-201); NULL => no NULLs. */
+typedef struct crgpu_dcol {
+  int32_t type; /* crgpu_type */
+  int32_t _pad;
+  const void *data;
+  const uint8_t *valid;
+  const uint32_t *offsets;
+} crgpu_dcol;
+
+/* Library-owned result batch (device memory), valid until the next call on
+ * the same handle. */
+typedef struct crgpu_dev_result {
+  int64_t n;
+  int32_t ncols;
+  int32_t _pad;
+  const crgpu_dcol *cols; /* host array of `ncols` descriptors */
+} crgpu_dev_result;
+
+/* Replaces colexechash.rehash + initHash + finalizeHash
+ * (sql/colexec/colexechash/hash_utils.eg.go:39, hash_utils.go:65,83,104) over
+ * `n` rows: out[i] = finalize(fold over cols of hash(col[i], seed)).
+ * width 32: out is uint32[n], running hash truncated after every column
+ * (hash tables); width 64: uint64[n] (routing).  nbuckets 0 = no finalize. */
+crgpu_status crgpu_dev_hash_cols(const crgpu_dcol *cols, int32_t ncols, int64_t n, uint64_t init, int32_t width,
+                                 uint64_t nbuckets, void *out_dev);
+
+/* ---- hash join: replaces colexecjoin.hashJoiner build()/exec()/emitRight()
+ * (sql/colexec/colexecjoin/hashjoiner.go:339,504,405) and colexechash.HashTable
+ * FullBuild/Check/DistinctCheck (hashtable.go:477, hashtable_tmpl.go:732). */
+typedef struct crgpu_join_spec {
+  int32_t join_type;             /* crgpu_join_type */
+  int32_t right_eq_cols_are_key; /* HashJoinerSpec.RightEqColumnsAreKey; MakeHashJoinerSpec overrides applied inside
+                                    (hashjoiner.go:827-883) */
+  int32_t n_left_cols, n_right_cols;
+  const int32_t *left_types, *right_types; /* crgpu_type per column */
+  int32_t n_eq;
+  int32_t _pad;
+  const int32_t *left_eq, *right_eq; /* equality column ordinals */
+} crgpu_join_spec;
+
+typedef struct crgpu_join crgpu_join;
+crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu_join **out);
+/* Build side (right input), all rows at once.  The columns are BORROWED and
+ * must stay valid and unchanged until reset/destroy (ht.Vals, hashtable.go:252). */
+crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n);
+/* Probe one chunk of the left input; `out` = joined rows for this chunk (left
+ * columns then right columns, JoinType.MakeOutputTypes join_type.go:101).
+ * RIGHT SEMI / RIGHT ANTI produce no probe-time output (n = 0). */
+crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n, crgpu_dev_result *out);
+/* After the last probe chunk: hjEmittingRight (hashjoiner.go:322-328) --
+ * unmatched build rows (RIGHT/FULL OUTER, RIGHT ANTI) or matched ones (RIGHT SEMI). */
+crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_result *out);
+crgpu_status crgpu_dev_join_reset(crgpu_join *j); /* colexecop.Resetter */
+void crgpu_dev_join_destroy(crgpu_join *j);
+
+/* ---- hash aggregation: replaces colexec.hashAggregator onlineAgg + the
+ * colexecagg *HashAgg accumulators (sql/colexec/hash_aggregator.go:354,
+ * sql/colexec/colexecagg/hash_*_agg.eg.go). */
+typedef struct crgpu_agg_desc {
+  int32_t func;       /* crgpu_agg_func */
+  int32_t col;        /* AggregatorSpec_Aggregation.ColIdx[0]; -1 for COUNT_ROWS */
+  int32_t filter_col; /* FilterColIdx (BOOL column) or -1 */
+  int32_t distinct;   /* must be 0: DISTINCT aggregation => CRGPU_ERR_UNSUPPORTED */
+} crgpu_agg_desc;
+
+typedef struct crgpu_agg_spec {
+  int32_t n_cols;
+  int32_t n_group;
+  const int32_t *types;      /* crgpu_type per input column */
+  const int32_t *group_cols; /* AggregatorSpec.GroupCols */
+  int32_t n_aggs;
+  int32_t _pad;
+  const crgpu_agg_desc *aggs;
+} crgpu_agg_spec;
+
+typedef struct crgpu_agg crgpu_agg;
+crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_agg **out);
+/* Online: may be called any number of times (hashAggregatorAggregating state). */
+crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n);
+/* One row per group, one column per aggregation (hashAggregatorOutputting,
+ * hash_aggregator_tmpl.go:331-387); arbitrary row order. */
+crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *out);
+crgpu_status crgpu_dev_agg_reset(crgpu_agg *a);
+void crgpu_dev_agg_destroy(crgpu_agg *a);
+
+/* ---- hash repartition: replaces colexechash.TupleHashDistributor.Distribute
+ * (hash_utils.go:163) + the per-output row copies of HashRouter
+ * (sql/colflow/routers.go:683-715).  Rows of `cols` are regrouped by
+ * destination = rehash64(init, hash_cols) % num_outputs into one contiguous
+ * region per destination; counts_host[p] = rows for output p (host array).
+ * The exchange itself (RCCL all-to-all over xGMI) is driven by the host side
+ * on the returned device buffers. */
+typedef struct crgpu_partitioner crgpu_partitioner;
+crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32_t n_cols, const int32_t *hash_cols,
+                                          int32_t n_hash, uint64_t init, int32_t num_outputs,
+                                          crgpu_partitioner **out);
+crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *out,
+                                 int64_t *counts_host);
+void crgpu_dev_partitioner_destroy(crgpu_partitioner *p);
+
+/* ============================================================ layer (2) */
+/* One coldata.Vec as Go lays it out (col/coldata/vec.go:44, native_types.go:15-37,
+ * bytes.go:45-74,156-165): fixed-width families -> the slice's backing array;
+ * BYTES -> &Bytes.elements[0] (32-byte elements, <= 30 bytes inline) and
+ * &Bytes.buffer[0].  All memory is BORROWED for the duration of the call only
+ * (cgo rule: no Go pointer is retained). */
+typedef struct crgpu_col {
+  int32_t type;            /* crgpu_type */
+  int32_t maybe_has_nulls; /* Nulls.MaybeHasNulls() */
+  const void *data;        /* values, or Bytes.elements */
+  const uint8_t *nulls;    /* Nulls.NullBitmap(), bit = 1 => present; may be NULL if !maybe_has_nulls */
+  const uint8_t *bytes_buf; /* Bytes.buffer */
+  int64_t bytes_buf_len;
+} crgpu_col;
+
+/* One coldata.Batch (col/coldata/batch.go:24): Length(), Selection(), ColVecs(). */
+typedef struct crgpu_batch {
+  int64_t length;
+  const int64_t *sel; /* Go []int; NULL => rows 0..length-1 */
+  int32_t ncols;
+  int32_t _pad;
+  const crgpu_col *cols;
+} crgpu_batch;
+
+/* Caller-owned output batch (allocator.ResetMaybeReallocate on the Go side).
+ * Fixed-width: `data` has room for `capacity` values.  BYTES: `data` is the
+ * elements array (capacity * 32 bytes), `bytes_buf` the spill buffer of
+ * `bytes_buf_cap` bytes; if a batch needs more, the call returns CRGPU_OK with
+ * length = 0 and bytes_buf_len = required size so the caller can grow and retry. */
+typedef struct crgpu_out_col {
+  int32_t type;
+  int32_t has_nulls; /* out */
+  void *data;
+  uint8_t *nulls; /* (capacity+7)/8 bytes */
+  uint8_t *bytes_buf;
+  int64_t bytes_buf_cap;
+  int64_t bytes_buf_len; /* out */
+} crgpu_out_col;
+
+typedef struct crgpu_out_batch {
+  int64_t capacity; /* <= coldata.BatchSize() typically */
+  int64_t length;   /* out; 0 = no more output (EOF of this phase) */
+  int32_t ncols;
+  int32_t _pad;
+  crgpu_out_col *cols;
+} crgpu_out_batch;
+
+/* colexechash.rehash over host vectors with a selection vector
+ * (hash_utils.eg.go:39; used by the Go router / partitioner shells). */
+crgpu_status crgpu_hash_cols(const crgpu_col *cols, int32_t ncols, int64_t n, const int64_t *sel, uint64_t init,
+                             int32_t width, uint64_t nbuckets, void *out_host);
+
+/* colexecjoin.NewHashJoiner + hashJoiner.Next() (hashjoiner.go:886-910,291). */
+typedef struct crgpu_hj crgpu_hj;
+crgpu_status crgpu_hj_new(const crgpu_join_spec *spec, crgpu_hj **out);
+crgpu_status crgpu_hj_build_append(crgpu_hj *h, const crgpu_batch *right); /* InputTwo.Next() batches */
+crgpu_status crgpu_hj_build_finish(crgpu_hj *h);                           /* right input exhausted */
+crgpu_status crgpu_hj_probe_append(crgpu_hj *h, const crgpu_batch *left);  /* InputOne.Next() batches */
+crgpu_status crgpu_hj_probe_finish(crgpu_hj *h);                           /* left input exhausted */
+/* Next(): fills `out` with up to out->capacity joined rows; length 0 once
+ * everything appended so far has been emitted. */
+crgpu_status crgpu_hj_next_output(crgpu_hj *h, crgpu_out_batch *out);
+/* BufferingInMemoryOperator.ExportBuffered (colexecop/operator.go:167-196):
+ * hands the buffered build rows back so the CPU disk-backed joiner can take over. */
+crgpu_status crgpu_hj_export_buffered(crgpu_hj *h, crgpu_out_batch *out);
+crgpu_status crgpu_hj_reset(crgpu_hj *h);
+void crgpu_hj_free(crgpu_hj *h);
+
+/* colexec.NewHashAggregator + hashAggregator.Next() (hash_aggregator.go:194,
+ * hash_aggregator_tmpl.go:400). */
+typedef struct crgpu_ha crgpu_ha;
+crgpu_status crgpu_agg_new(const crgpu_agg_spec *spec, crgpu_ha **out);
+crgpu_status crgpu_agg_append(crgpu_ha *h, const crgpu_batch *in);
+crgpu_status crgpu_agg_finish(crgpu_ha *h); /* input exhausted */
+crgpu_status crgpu_agg_next_output(crgpu_ha *h, crgpu_out_batch *out);
+crgpu_status crgpu_agg_reset(crgpu_ha *h);
+void crgpu_agg_free(crgpu_ha *h);
+
+/* colflow.NewHashRouter + processNextBatch + routerOutputOp.Next
+ * (sql/colflow/routers.go:490,683,238). */
+typedef struct crgpu_router crgpu_router;
+crgpu_status crgpu_route_new(const int32_t *types, int32_t n_cols, const int32_t *hash_cols, int32_t n_hash,
+                             int32_t num_outputs, crgpu_router **out);
+crgpu_status crgpu_route_partition(crgpu_router *r, const crgpu_batch *in); /* processNextBatch */
+crgpu_status crgpu_route_finish(crgpu_router *r);                          /* zero-length batch = EOF to all */
+crgpu_status crgpu_route_next_output(crgpu_router *r, int32_t output, crgpu_out_batch *out);
+void crgpu_route_free(crgpu_router *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRGPU_H */
