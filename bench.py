@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json configs[1]: "Synthetic hash join microbench: int64
+keys, 2^27 build x 2^29 probe rows, 1 MI355X" (SURVEY.md 8(d) config J).
+
+One step = one full hash join of the batch: build the table on (k, v)
+(2^27 rows, k a permutation) + probe it with (k, w) (2^29 rows, 100 % hit) +
+materialise (w, v) (2^29 rows).  Inputs are resident in HBM before the timed
+region.  N > 1 (one process per GPU, RCCL): every rank holds its own 2^27 x
+2^29 shard (weak scaling), hash-repartitions both inputs by key with the
+reference's router hash (crgpu_dev_partition), exchanges the regions with one
+all-to-all per column and joins locally -- BASELINE.json configs[3] shape.
+
+Prints ONE JSON line (see the repo contract); `roofline` is for the dominant
+kernel (packed_probe_kernel), `cpu_baseline` times the oracle port on a bounded
+sample at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2-build", type=int, default=27)
+    ap.add_argument("--log2-probe", type=int, default=29)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2-build", type=int, default=24)
+    ap.add_argument("--cpu-log2-probe", type=int, default=26)
+    return ap.parse_args()
+
+
+def cpu_baseline(lb, lp):
+    """The oracle port (oracle/crdb_oracle.c: reference algorithm, single thread,
+    1024-tuple batches) on a bounded sample of the same workload."""
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    from cockroach_amd import coldata as cd
+    rng = np.random.default_rng(42)
+    nb, npr = 1 << lb, 1 << lp
+    bk = rng.permutation(nb).astype(np.int64)
+    bv = bk * 3 + 1
+    pk = rng.integers(0, nb, size=npr, dtype=np.int64)
+    pw = np.arange(npr, dtype=np.int64)
+    L = [cd.Vec.from_numpy(cd.INT64, pk), cd.Vec.from_numpy(cd.INT64, pw)]
+    R = [cd.Vec.from_numpy(cd.INT64, bk), cd.Vec.from_numpy(cd.INT64, bv)]
+    cl, _k1 = O.make_cols(L)
+    cr, _k2 = O.make_cols(R)
+    eq = np.array([0], dtype=np.int32)
+    t0 = time.perf_counter()
+    res = O.lib().ora_hash_join(0, cl, 2, npr, cr, 2, nb, eq.ctypes.data, eq.ctypes.data, 1, 1, 1024, 256)
+    dt = time.perf_counter() - t0
+    nout = O.lib().ora_result_nrows(res)
+    O.lib().ora_result_free(res)
+    assert nout == npr
+    return {"value": (nb + npr) / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"same workload at 2^{lb} build x 2^{lp} probe rows (oracle/crdb_oracle.c, 1 thread, "
+                      f"1024-tuple batches), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from cockroach_amd import coldata as cd
+    from cockroach_amd import device as dev
+    from cockroach_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _lib.check(_lib.load().crgpu_init(local_rank))
+
+    nb, npr = 1 << args.log2_build, 1 << args.log2_probe
+    g = torch.Generator(device=device)
+    g.manual_seed(42 + rank)
+    # build (k, v): k = a permutation of the GLOBAL key domain shard-by-shard (unique keys), v = 3k+1
+    bk = torch.randperm(nb, generator=g, device=device, dtype=torch.int64)
+    if world > 1:
+        bk = bk * world + rank  # globally unique keys, spread over all destinations
+    bv = bk * 3 + 1
+    g.manual_seed(43 + rank)
+    pk = torch.randint(0, nb * world, (npr,), generator=g, device=device, dtype=torch.int64)  # 100 % hit
+    pw = torch.arange(npr, device=device, dtype=torch.int64) + rank * npr
+    torch.cuda.synchronize()
+
+    I64 = cd.INT64
+    join = dev.Join(0, [I64, I64], [I64, I64], [0], [0], True, out_cols=[1, 3])  # INNER, output (w, v)
+    part_b = part_p = None
+    if world > 1:
+        part_b = dev.Partitioner([I64, I64], [0], world)
+        part_p = dev.Partitioner([I64, I64], [0], world)
+
+    def exchange(part, cols_t, n):
+        """hash-repartition + all-to-all; returns received torch tensors (k, x)."""
+        res, counts = part.partition([dev.from_torch(I64, t) for t in cols_t], n)
+        send_counts = torch.tensor(counts.tolist(), device=device, dtype=torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts)
+        rc = recv_counts.tolist()
+        total = int(sum(rc))
+        outs = []
+        for c in range(res.ncols):
+            src = _wrap(torch, res.cols[c].data, n, device)
+            dst = torch.empty(total, device=device, dtype=torch.int64)
+            dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=counts.tolist())
+            outs.append(dst)
+        return outs, total
+
+    def step():
+        if world == 1:
+            b_cols, nbl = [bk, bv], nb
+            p_cols, npl = [pk, pw], npr
+        else:
+            b_cols, nbl = exchange(part_b, [bk, bv], nb)
+            p_cols, npl = exchange(part_p, [pk, pw], npr)
+            torch.cuda.synchronize()
+        join.build([dev.from_torch(I64, t) for t in b_cols], nbl)
+        res = join.probe([dev.from_torch(I64, t) for t in p_cols], npl)
+        return res, b_cols, p_cols
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res, _b, _p = step()
+    dev.prof_enable(True)
+    dev.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    out_rows = 0
+    for _ in range(args.steps):
+        res, _b, _p = step()
+        out_rows = int(res.n)
+    barrier()
+    dt = time.perf_counter() - t0
+    dev.prof_enable(False)
+
+    # result check outside the timed region (size-independent property: sum(v) == sum(3k+1) over probe keys)
+    w_out = _wrap(torch, res.cols[0].data, out_rows, device)
+    v_out = _wrap(torch, res.cols[1].data, out_rows, device)
+    ok = True
+    if world == 1:
+        ok = out_rows == npr and int(v_out.sum().item()) == int((pk * 3 + 1).sum().item()) \
+            and int(w_out.sum().item()) == int(pw.sum().item())
+    if world > 1:
+        t = torch.tensor([dt, float(out_rows), float(ok)], device=device, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0].item())
+        total_out = int(tsum[1].item())
+        ok = total_out == npr * world
+    probe_ms, probe_n = dev.prof_get("join_probe")
+    build_ms, build_n = dev.prof_get("join_build")
+    part_ms, part_n = dev.prof_get("partition")
+
+    if rank == 0:
+        rows_per_step = (nb + npr) * world
+        value = rows_per_step * args.steps / dt
+        # algorithmic bytes of one probe launch: 16 B/row read (k, w) + 16 B/row written (w, v)  [SURVEY.md 8(d)]
+        probe_alg = 32.0 * npr
+        avg_probe_s = (probe_ms / max(probe_n, 1)) / 1e3
+        achieved = probe_alg / avg_probe_s / 1e9 if avg_probe_s > 0 else 0.0
+        line = {
+            "metric": "rows/s hash join (build+probe rows per second)", "value": value, "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": f"hash join microbench: int64 keys, 2^{args.log2_build} build x "
+                                   f"2^{args.log2_probe} probe rows per GPU, INNER, unique build keys, 100% hit, "
+                                   "output (w, v)",
+                       "parallelism": "single GPU" if world == 1 else f"hash repartition all-to-all over {world} GPUs",
+                       "result_check": "ok" if ok else "MISMATCH"},
+            "roofline": {"bound": "hbm", "kernel": "packed_probe_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_probe_s * 1e3, "launches": probe_n,
+                         "algorithmic_bytes_per_launch": probe_alg},
+            "kernels_ms_per_step": {"join_build": build_ms / max(args.steps, 1), "join_probe": probe_ms / max(args.steps, 1),
+                                    "partition": part_ms / max(args.steps, 1)},
+            "whole_join_hbm_frac": (16.0 * nb + 32.0 * npr) * world / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_log2_build, args.cpu_log2_probe)
+        print(json.dumps(line), flush=True)
+    join.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+def _wrap(torch, ptr, n, device):
+    """torch view (no copy) of a library-owned int64 device buffer."""
+    import ctypes as C
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 3}
+    return torch.as_tensor(h, device=device)
+
+
+if __name__ == "__main__":
+    main()

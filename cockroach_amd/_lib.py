@@ -33,8 +33,9 @@ class DevResult(C.Structure):  # crgpu_dev_result
 class JoinSpec(C.Structure):  # crgpu_join_spec
     _fields_ = [("join_type", C.c_int32), ("right_eq_cols_are_key", C.c_int32), ("n_left_cols", C.c_int32),
                 ("n_right_cols", C.c_int32), ("left_types", C.POINTER(C.c_int32)),
-                ("right_types", C.POINTER(C.c_int32)), ("n_eq", C.c_int32), ("_pad", C.c_int32),
-                ("left_eq", C.POINTER(C.c_int32)), ("right_eq", C.POINTER(C.c_int32))]
+                ("right_types", C.POINTER(C.c_int32)), ("n_eq", C.c_int32), ("n_out_cols", C.c_int32),
+                ("left_eq", C.POINTER(C.c_int32)), ("right_eq", C.POINTER(C.c_int32)),
+                ("out_cols", C.POINTER(C.c_int32))]
 
 
 class AggDesc(C.Structure):  # crgpu_agg_desc

@@ -394,6 +394,12 @@ struct crgpu_join {
   bool null_eq = false;             // INTERSECT/EXCEPT ALL treat NULLs as equal (hashjoiner.go:264-268)
   std::vector<int> left_types, right_types, left_eq, right_eq;
   bool packed = false;
+  // Output schema after the pushed-down projection: one entry per emitted column.
+  struct OutSrc {
+    bool is_left;
+    int src;  // ordinal within its side
+  };
+  std::vector<OutSrc> out_src;
 
   std::vector<DCol> build_cols;
   int64_t n_build = 0;
@@ -470,6 +476,25 @@ extern "C" crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu
   j->right_distinct = rd;
   j->track_build_matches = jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER || jt == CRGPU_RIGHT_SEMI || jt == CRGPU_RIGHT_ANTI;
   j->null_eq = jt == CRGPU_INTERSECT_ALL || jt == CRGPU_EXCEPT_ALL;
+  {  // emitted columns: JoinType.MakeOutputTypes (join_type.go:101-140), then the optional projection
+    std::vector<crgpu_join::OutSrc> all;
+    if (left_in_output(jt))
+      for (int c = 0; c < spec->n_left_cols; c++) all.push_back({true, c});
+    if (right_in_output(jt))
+      for (int c = 0; c < spec->n_right_cols; c++) all.push_back({false, c});
+    if (spec->n_out_cols < 0) {
+      j->out_src = all;
+    } else {
+      for (int k = 0; k < spec->n_out_cols; k++) {
+        int q = spec->out_cols[k];
+        if (q < 0 || q >= static_cast<int>(all.size())) {
+          delete j;
+          return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_create: projected column ordinal out of range");
+        }
+        j->out_src.push_back(all[q]);
+      }
+    }
+  }
   // The packed table keeps one row per key: usable whenever the first match
   // decides the result (distinct build side, or pure existence tests).
   bool first_match = rd || jt == CRGPU_LEFT_ANTI;
@@ -532,20 +557,28 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
     CRGPU_TRY(j->special.ensure(sizeof(Special)));
     CRGPU_HIP(hipMemsetAsync(j->slots.p, 0xFF, j->cap * sizeof(Slot), st));
     CRGPU_HIP(hipMemsetAsync(j->special.p, 0, sizeof(Special), st));
-    // covering: build side is {int/bool key} or {int/bool key, one 8-byte non-null payload}
+    // covering: every emitted build column is the int/bool key itself or ONE 8-byte non-null payload
+    // column, which then rides in the slot's val word (no row-id indirection at probe time).
     j->covering = false;
     j->cover_col = -1;
-    const int jt = j->join_type;
     const bool key_castable = j->right_types[kc] != CRGPU_FLOAT64 && j->build_cols[kc].valid == nullptr;
-    if (!j->track_build_matches && key_castable && right_in_output(jt)) {
-      if (nr == 1) {
-        j->covering = true;
-      } else if (nr == 2) {
-        int pc = 1 - kc;
-        if (type_width(j->right_types[pc]) == 8 && j->build_cols[pc].valid == nullptr) {
-          j->covering = true;
-          j->cover_col = pc;
+    if (!j->track_build_matches && j->out_src.size() <= static_cast<size_t>(kMaxFused)) {
+      bool ok = true;
+      int pc = -1;
+      for (const auto &o : j->out_src) {
+        if (o.is_left) continue;
+        if (o.src == kc) {
+          ok = ok && key_castable;
+        } else if (pc == -1 || pc == o.src) {
+          pc = o.src;
+          ok = ok && type_width(j->right_types[pc]) == 8 && j->build_cols[pc].valid == nullptr;
+        } else {
+          ok = false;
         }
+      }
+      if (ok) {
+        j->covering = true;
+        j->cover_col = pc;
       }
     }
     if (n > 0) {
@@ -582,8 +615,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
 
 // Output column bookkeeping ------------------------------------------------
 static void join_setup_outputs(crgpu_join *j) {
-  const int jt = j->join_type;
-  size_t nout = (left_in_output(jt) ? j->left_types.size() : 0) + (right_in_output(jt) ? j->right_types.size() : 0);
+  size_t nout = j->out_src.size();
   if (j->out.size() != nout) {
     j->out = std::vector<OutCol>(nout);
     j->valid_bytes = std::vector<DevBuf>(nout);
@@ -634,7 +666,6 @@ static crgpu_status launch_packed_probe(int jt, const ProbeArgs &a, int grid) {
 
 static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, int64_t n, crgpu_dev_result *res) {
   const int jt = j->join_type;
-  const int nl = static_cast<int>(left.size()), nr = static_cast<int>(j->right_types.size());
   const bool outer_nulls = left_or_full_outer(jt);
   hipStream_t st = stream();
   const int64_t cap_rows = n > 0 ? n : 1;  // first-match joins emit at most one row per probe row
@@ -676,20 +707,18 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
     }
     return CRGPU_OK;
   };
-  for (int c = 0; c < nl; c++, oc++) {
-    if (left[c].type != CRGPU_BYTES && a.ncopy < kMaxFused)
-      CRGPU_TRY(add_fused(static_cast<const uint8_t *>(left[c].data), left[c].valid, left[c].type, SIDE_PROBE,
-                          left[c].valid != nullptr));
-    else
-      later.push_back(Later{oc, true, c});
-  }
-  if (right_in_output(jt)) {
-    for (int c = 0; c < nr; c++, oc++) {
+  for (const auto &os : j->out_src) {
+    const int c = os.src;
+    if (os.is_left) {
+      if (left[c].type != CRGPU_BYTES && a.ncopy < kMaxFused)
+        CRGPU_TRY(add_fused(static_cast<const uint8_t *>(left[c].data), left[c].valid, left[c].type, SIDE_PROBE,
+                            left[c].valid != nullptr));
+      else
+        later.push_back(Later{oc, true, c});
+    } else {
       const DCol &b = j->build_cols[c];
-      if (j->covering && c == j->right_eq[0] && a.ncopy < kMaxFused) {
-        CRGPU_TRY(add_fused(nullptr, nullptr, b.type, SIDE_KEYCAST, outer_nulls));
-      } else if (j->covering && c == j->cover_col && a.ncopy < kMaxFused) {
-        CRGPU_TRY(add_fused(nullptr, nullptr, b.type, SIDE_COVER, outer_nulls));
+      if (j->covering && a.ncopy < kMaxFused) {  // covering => c is the key column or the cover column
+        CRGPU_TRY(add_fused(nullptr, nullptr, b.type, c == j->cover_col ? SIDE_COVER : SIDE_KEYCAST, outer_nulls));
       } else if (!j->covering && b.type != CRGPU_BYTES && a.ncopy < kMaxFused) {
         CRGPU_TRY(add_fused(static_cast<const uint8_t *>(b.data), b.valid, b.type, SIDE_BUILD,
                             outer_nulls || b.valid != nullptr));
@@ -697,6 +726,7 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
         later.push_back(Later{oc, false, c});
       }
     }
+    oc++;
   }
   if (!later.empty()) {
     CRGPU_TRY(j->pair_p.ensure(static_cast<size_t>(cap_rows) * 4));
@@ -758,7 +788,6 @@ static crgpu_status launch_chain_jt(int jt, const ChainArgs &a, bool fill) {
 
 static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, int64_t n, crgpu_dev_result *res) {
   const int jt = j->join_type;
-  const int nl = static_cast<int>(left.size()), nr = static_cast<int>(j->right_types.size());
   hipStream_t st = stream();
   uint64_t total = 0;
   if (n > 0) {
@@ -799,17 +828,17 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     }
   }
   int oc = 0;
-  if (left_in_output(jt)) {
-    for (int c = 0; c < nl; c++, oc++)
-      CRGPU_TRY(materialize(left[c], j->pair_p.as<int32_t>(), static_cast<int64_t>(total), false, j->out[oc], j->scratch));
-    if (right_in_output(jt))
-      for (int c = 0; c < nr; c++, oc++)
-        CRGPU_TRY(materialize(j->build_cols[c], j->pair_b.as<int32_t>(), static_cast<int64_t>(total),
-                              left_or_full_outer(jt), j->out[oc], j->scratch));
-  } else {
-    // RIGHT SEMI / RIGHT ANTI: nothing while probing; keep well-formed empty columns
-    for (int c = 0; c < nr; c++, oc++) CRGPU_TRY(make_null_col(j->right_types[c], 0, j->out[oc]));
-    total = 0;
+  if (!left_in_output(jt)) total = 0;  // RIGHT SEMI / RIGHT ANTI: nothing while probing
+  for (const auto &os : j->out_src) {
+    if (!left_in_output(jt))
+      CRGPU_TRY(make_null_col(j->right_types[os.src], 0, j->out[oc]));  // well-formed empty column
+    else if (os.is_left)
+      CRGPU_TRY(materialize(left[os.src], j->pair_p.as<int32_t>(), static_cast<int64_t>(total), false, j->out[oc],
+                            j->scratch));
+    else
+      CRGPU_TRY(materialize(j->build_cols[os.src], j->pair_b.as<int32_t>(), static_cast<int64_t>(total),
+                            left_or_full_outer(jt), j->out[oc], j->scratch));
+    oc++;
   }
   CRGPU_HIP(hipStreamSynchronize(st));
   return finish_result(j, static_cast<int64_t>(total), res);
@@ -847,7 +876,6 @@ extern "C" crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_resul
   if (!j->built) return fail(CRGPU_ERR_STATE, "crgpu_dev_join_emit_right: build side not built");
   join_setup_outputs(j);
   const int jt = j->join_type;
-  const int nl = static_cast<int>(j->left_types.size()), nr = static_cast<int>(j->right_types.size());
   int64_t count = 0;
   if (j->track_build_matches && j->n_build > 0) {
     const int64_t n = j->n_build;
@@ -860,11 +888,13 @@ extern "C" crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_resul
     CRGPU_TRY(select_flagged(j->flags.as<uint8_t>(), n, j->pair_b.as<int32_t>(), j->scratch, &count));
   }
   int oc = 0;
-  if (left_in_output(jt))
-    for (int c = 0; c < nl; c++, oc++) CRGPU_TRY(make_null_col(j->left_types[c], count, j->out[oc]));
-  if (right_in_output(jt) || !left_in_output(jt))
-    for (int c = 0; c < nr; c++, oc++)
-      CRGPU_TRY(materialize(j->build_cols[c], j->pair_b.as<int32_t>(), count, false, j->out[oc], j->scratch));
+  for (const auto &os : j->out_src) {
+    if (os.is_left)
+      CRGPU_TRY(make_null_col(j->left_types[os.src], count, j->out[oc]));
+    else
+      CRGPU_TRY(materialize(j->build_cols[os.src], j->pair_b.as<int32_t>(), count, false, j->out[oc], j->scratch));
+    oc++;
+  }
   CRGPU_HIP(hipStreamSynchronize(stream()));
   return finish_result(j, count, res);
 }

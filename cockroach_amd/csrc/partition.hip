@@ -1,0 +1,271 @@
+// partition.hip -- hash repartition: the device half of the HashRouter replacement.
+//
+// Replaces colexechash.TupleHashDistributor.Distribute
+// (pkg/sql/colexec/colexechash/hash_utils.go:163-208: initHash64 -> rehash per
+// hash column -> finalizeHash(% numOutputs) -> one selection vector per output)
+// and the per-output row copies HashRouter.processNextBatch makes
+// (pkg/sql/colflow/routers.go:683-715).  Instead of P selection vectors over
+// 1024-row batches, the whole input is regrouped in two streaming passes into
+// P contiguous regions (the send buffers of the all-to-all):
+//   pass 1: dest = hash64 % P per row (cached as uint16) + per-tile histograms in LDS;
+//   scan  : exclusive scan of the P x ntiles histogram (partition-major);
+//   pass 2: each 4096-row tile scatters its rows to base[p][tile] + rank.
+// Same hash as the reference, so a mixed CPU/GPU cluster co-locates equal keys.
+//
+// Roofline: HBM streaming; algorithmic bytes/row = row width read + row width written.
+#include <cstring>
+
+#include "device.h"
+
+namespace crgpu {
+
+static constexpr int kPartBlock = 256;
+static constexpr int kPartItems = 16;
+static constexpr int kPartTile = kPartBlock * kPartItems;
+static constexpr int kMaxOutputs = 1024;
+static constexpr int kMaxScatter = 16;
+
+__global__ __launch_bounds__(kPartBlock) void part_hist_kernel(KeyCols keys, int64_t n, uint64_t init, uint32_t P,
+                                                               int64_t ntiles, uint16_t *__restrict__ dest,
+                                                               uint32_t *__restrict__ tile_hist) {
+  extern __shared__ uint32_t s_hist[];
+  for (uint32_t p = threadIdx.x; p < P; p += kPartBlock) s_hist[p] = 0;
+  __syncthreads();
+  const int64_t tile = blockIdx.x;
+  const int64_t base = tile * kPartTile;
+  const bool pow2 = (P & (P - 1)) == 0;
+#pragma unroll 4
+  for (int k = 0; k < kPartItems; k++) {
+    const int64_t i = base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x;
+    if (i < n) {
+      const uint64_t h = hash_row64(keys, i, init);
+      const uint32_t d = pow2 ? static_cast<uint32_t>(h & (P - 1)) : static_cast<uint32_t>(h % P);  // finalizeHash
+      dest[i] = static_cast<uint16_t>(d);
+      atomicAdd(&s_hist[d], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < P; p += kPartBlock) tile_hist[static_cast<int64_t>(p) * ntiles + tile] = s_hist[p];
+}
+
+struct ScatterCol {
+  const uint8_t *src;
+  uint8_t *dst;
+  const uint8_t *src_valid;
+  uint8_t *dst_valid;  // byte per row, packed afterwards
+  int32_t width;
+  int32_t _pad;
+};
+struct ScatterArgs {
+  int64_t n, ntiles;
+  uint32_t P;
+  int32_t ncols;
+  const uint16_t *dest;
+  const uint64_t *bases;  // [P * ntiles + 1]
+  int32_t *src_of_pos;    // optional: inverse map for columns not scattered here
+  ScatterCol cols[kMaxScatter];
+};
+
+__global__ __launch_bounds__(kPartBlock) void part_scatter_kernel(ScatterArgs a) {
+  extern __shared__ uint32_t s_cursor[];  // next free rank per partition within this tile
+  for (uint32_t p = threadIdx.x; p < a.P; p += kPartBlock) s_cursor[p] = 0;
+  __syncthreads();
+  const int64_t tile = blockIdx.x;
+  const int64_t base = tile * kPartTile;
+  int64_t pos[kPartItems];
+#pragma unroll
+  for (int k = 0; k < kPartItems; k++) {
+    const int64_t i = base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x;
+    pos[k] = -1;
+    if (i < a.n) {
+      const uint32_t d = a.dest[i];
+      const uint32_t r = atomicAdd(&s_cursor[d], 1u);
+      pos[k] = static_cast<int64_t>(a.bases[static_cast<int64_t>(d) * a.ntiles + tile] + r);
+    }
+  }
+  for (int c = 0; c < a.ncols; c++) {
+    const ScatterCol sc = a.cols[c];
+#pragma unroll
+    for (int k = 0; k < kPartItems; k++) {
+      if (pos[k] < 0) continue;
+      const int64_t i = base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x;
+      switch (sc.width) {
+        case 1: sc.dst[pos[k]] = sc.src[i]; break;
+        case 2: reinterpret_cast<uint16_t *>(sc.dst)[pos[k]] = reinterpret_cast<const uint16_t *>(sc.src)[i]; break;
+        case 4: reinterpret_cast<uint32_t *>(sc.dst)[pos[k]] = reinterpret_cast<const uint32_t *>(sc.src)[i]; break;
+        default: reinterpret_cast<uint64_t *>(sc.dst)[pos[k]] = reinterpret_cast<const uint64_t *>(sc.src)[i]; break;
+      }
+      if (sc.dst_valid) sc.dst_valid[pos[k]] = (sc.src_valid[i >> 3] >> (i & 7)) & 1;
+    }
+  }
+  if (a.src_of_pos != nullptr) {
+#pragma unroll
+    for (int k = 0; k < kPartItems; k++)
+      if (pos[k] >= 0) a.src_of_pos[pos[k]] = static_cast<int32_t>(base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x);
+  }
+}
+
+__global__ void part_counts_kernel(const uint64_t *__restrict__ bases, int64_t ntiles, uint32_t P,
+                                   uint64_t *__restrict__ counts) {
+  for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
+    counts[p] = bases[static_cast<int64_t>(p + 1) * ntiles] - bases[static_cast<int64_t>(p) * ntiles];
+}
+
+}  // namespace crgpu
+
+using namespace crgpu;
+
+struct crgpu_partitioner {
+  std::vector<int> types, hash_cols;
+  uint64_t init = 1;
+  int P = 1;
+  DevBuf dest, tile_hist, bases, src_of_pos, counts_dev, scratch;
+  std::vector<OutCol> out;
+  std::vector<DevBuf> valid_bytes;
+  std::vector<crgpu_dcol> views;
+};
+
+extern "C" crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32_t n_cols, const int32_t *hash_cols,
+                                                     int32_t n_hash, uint64_t init, int32_t num_outputs,
+                                                     crgpu_partitioner **out) {
+  CRGPU_TRY(ensure_init());
+  if (types == nullptr || out == nullptr || (n_hash > 0 && hash_cols == nullptr))
+    return fail(CRGPU_ERR_INVALID, "crgpu_dev_partitioner_create: null argument");
+  if (n_cols < 1 || n_cols > kMaxCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partitioner_create: column count out of range");
+  if (n_hash < 0 || n_hash > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partitioner_create: at most 8 hash columns");
+  if (num_outputs < 1 || num_outputs > kMaxOutputs)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partitioner_create: between 1 and 1024 outputs");
+  if (init == 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partitioner_create: init hash value must be non-zero (hash_utils.go:64)");
+  auto p = new crgpu_partitioner();
+  for (int i = 0; i < n_cols; i++) {
+    if (!valid_type(types[i])) { delete p; return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partitioner_create: unsupported column type"); }
+    p->types.push_back(types[i]);
+  }
+  for (int i = 0; i < n_hash; i++) {
+    if (hash_cols[i] < 0 || hash_cols[i] >= n_cols) { delete p; return fail(CRGPU_ERR_INVALID, "crgpu_dev_partitioner_create: hash column ordinal out of range"); }
+    p->hash_cols.push_back(hash_cols[i]);
+  }
+  p->init = init;
+  p->P = num_outputs;
+  p->out = std::vector<OutCol>(n_cols);
+  p->valid_bytes = std::vector<DevBuf>(n_cols);
+  p->views.resize(n_cols);
+  *out = p;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_dev_partitioner_destroy(crgpu_partitioner *p) {
+  if (p == nullptr) return;
+  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
+  delete p;
+}
+
+extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n,
+                                            crgpu_dev_result *res, int64_t *counts_host) {
+  if (p == nullptr || res == nullptr || counts_host == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: null argument");
+  if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition: at most 2^31 rows per call");
+  if (n > 0 && cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: null columns");
+  const int nc = static_cast<int>(p->types.size());
+  hipStream_t st = stream();
+  std::vector<DCol> in;
+  for (int c = 0; c < nc; c++) {
+    DCol d{p->types[c], 0, nullptr, nullptr, nullptr};
+    if (n > 0) {
+      if (cols[c].type != p->types[c]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: column type differs from the spec");
+      if (cols[c].type == CRGPU_BYTES && cols[c].offsets == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: BYTES column without offsets");
+      if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: null data pointer");
+      d = to_dcol(cols[c]);
+    }
+    in.push_back(d);
+  }
+  for (int q = 0; q < p->P; q++) counts_host[q] = 0;
+  if (n == 0) {
+    for (int c = 0; c < nc; c++) {
+      OutCol &o = p->out[c];
+      o.type = p->types[c];
+      o.nullable = false;
+      CRGPU_TRY(o.data.ensure(16));
+      if (o.type == CRGPU_BYTES) {
+        CRGPU_TRY(o.offsets.ensure(4));
+        CRGPU_HIP(hipMemsetAsync(o.offsets.p, 0, 4, st));
+      }
+      p->views[c] = o.view();
+    }
+    CRGPU_HIP(hipStreamSynchronize(st));
+    res->n = 0; res->ncols = nc; res->_pad = 0; res->cols = p->views.data();
+    return CRGPU_OK;
+  }
+
+  const int64_t ntiles = (n + kPartTile - 1) / kPartTile;
+  const uint32_t P = static_cast<uint32_t>(p->P);
+  KeyCols keys;
+  keys.n = static_cast<int>(p->hash_cols.size());
+  keys._pad = 0;
+  for (int k = 0; k < keys.n; k++) keys.c[k] = in[p->hash_cols[k]];
+  CRGPU_TRY(p->dest.ensure(static_cast<size_t>(n) * 2));
+  CRGPU_TRY(p->tile_hist.ensure(static_cast<size_t>(ntiles) * P * 4));
+  CRGPU_TRY(p->bases.ensure((static_cast<size_t>(ntiles) * P + 1) * 8));
+  CRGPU_TRY(p->counts_dev.ensure(static_cast<size_t>(P) * 8));
+
+  ScatterArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n = n;
+  a.ntiles = ntiles;
+  a.P = P;
+  a.dest = p->dest.as<uint16_t>();
+  a.bases = p->bases.as<uint64_t>();
+  std::vector<int> later;
+  std::vector<int> scattered;
+  for (int c = 0; c < nc; c++) {
+    OutCol &o = p->out[c];
+    o.type = in[c].type;
+    o.nullable = in[c].valid != nullptr;
+    if (in[c].type != CRGPU_BYTES && a.ncols < kMaxScatter) {
+      CRGPU_TRY(o.data.ensure(static_cast<size_t>(n) * type_width(in[c].type)));
+      ScatterCol &sc = a.cols[a.ncols++];
+      scattered.push_back(c);
+      sc.src = static_cast<const uint8_t *>(in[c].data);
+      sc.dst = o.data.as<uint8_t>();
+      sc.width = type_width(in[c].type);
+      sc.src_valid = in[c].valid;
+      sc.dst_valid = nullptr;
+      if (o.nullable) {
+        CRGPU_TRY(p->valid_bytes[c].ensure(static_cast<size_t>(n)));
+        CRGPU_TRY(o.valid.ensure(static_cast<size_t>((n + 7) / 8 + 1)));
+        sc.dst_valid = p->valid_bytes[c].as<uint8_t>();
+      }
+    } else {
+      later.push_back(c);
+    }
+  }
+  if (!later.empty()) {
+    CRGPU_TRY(p->src_of_pos.ensure(static_cast<size_t>(n) * 4));
+    a.src_of_pos = p->src_of_pos.as<int32_t>();
+  }
+  {
+    ProfScope prof("partition");
+    hipLaunchKernelGGL(part_hist_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, keys, n, p->init, P, ntiles,
+                       p->dest.as<uint16_t>(), p->tile_hist.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+    CRGPU_TRY(exclusive_scan_u32(p->tile_hist.as<uint32_t>(), ntiles * P, p->bases.as<uint64_t>(), p->scratch, nullptr));
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, a);
+    CRGPU_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(part_counts_kernel, dim3(1), dim3(256), 0, st, p->bases.as<uint64_t>(), ntiles, P,
+                     p->counts_dev.as<uint64_t>());
+  CRGPU_HIP(hipGetLastError());
+  for (size_t s = 0; s < scattered.size(); s++)
+    if (a.cols[s].dst_valid != nullptr)
+      CRGPU_TRY(pack_bitmap(a.cols[s].dst_valid, n, p->out[scattered[s]].valid.as<uint8_t>()));
+  for (int c : later) CRGPU_TRY(materialize(in[c], p->src_of_pos.as<int32_t>(), n, false, p->out[c], p->scratch));
+  std::vector<uint64_t> cnt(P);
+  CRGPU_HIP(hipMemcpyAsync(cnt.data(), p->counts_dev.p, static_cast<size_t>(P) * 8, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  for (uint32_t q = 0; q < P; q++) counts_host[q] = static_cast<int64_t>(cnt[q]);
+  for (int c = 0; c < nc; c++) p->views[c] = p->out[c].view();
+  res->n = n;
+  res->ncols = nc;
+  res->_pad = 0;
+  res->cols = p->views.data();
+  return CRGPU_OK;
+}

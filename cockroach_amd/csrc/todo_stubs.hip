@@ -3,14 +3,6 @@
 using namespace crgpu;
 #define NOTYET(name) return fail(CRGPU_ERR_UNSUPPORTED, name ": not implemented yet")
 extern "C" {
-crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *, crgpu_agg **) { NOTYET("crgpu_dev_agg_create"); }
-crgpu_status crgpu_dev_agg_consume(crgpu_agg *, const crgpu_dcol *, int64_t) { NOTYET("crgpu_dev_agg_consume"); }
-crgpu_status crgpu_dev_agg_finish(crgpu_agg *, crgpu_dev_result *) { NOTYET("crgpu_dev_agg_finish"); }
-crgpu_status crgpu_dev_agg_reset(crgpu_agg *) { NOTYET("crgpu_dev_agg_reset"); }
-void crgpu_dev_agg_destroy(crgpu_agg *) {}
-crgpu_status crgpu_dev_partitioner_create(const int32_t *, int32_t, const int32_t *, int32_t, uint64_t, int32_t, crgpu_partitioner **) { NOTYET("crgpu_dev_partitioner_create"); }
-crgpu_status crgpu_dev_partition(crgpu_partitioner *, const crgpu_dcol *, int64_t, crgpu_dev_result *, int64_t *) { NOTYET("crgpu_dev_partition"); }
-void crgpu_dev_partitioner_destroy(crgpu_partitioner *) {}
 crgpu_status crgpu_hash_cols(const crgpu_col *, int32_t, int64_t, const int64_t *, uint64_t, int32_t, uint64_t, void *) { NOTYET("crgpu_hash_cols"); }
 crgpu_status crgpu_hj_new(const crgpu_join_spec *, crgpu_hj **) { NOTYET("crgpu_hj_new"); }
 crgpu_status crgpu_hj_build_append(crgpu_hj *, const crgpu_batch *) { NOTYET("crgpu_hj_build_append"); }

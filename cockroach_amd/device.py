@@ -131,10 +131,13 @@ def hash_cols(cols, n=None, init=1, width=64, nbuckets=0) -> np.ndarray:
 class Join:
     """crgpu_join handle: build once, probe chunk by chunk, then emit_right."""
 
-    def __init__(self, join_type, left_types, right_types, left_eq, right_eq, right_eq_cols_are_key=False):
-        self._keep = (_i32arr(left_types), _i32arr(right_types), _i32arr(left_eq), _i32arr(right_eq))
+    def __init__(self, join_type, left_types, right_types, left_eq, right_eq, right_eq_cols_are_key=False,
+                 out_cols=None):
+        self._keep = (_i32arr(left_types), _i32arr(right_types), _i32arr(left_eq), _i32arr(right_eq),
+                      _i32arr(out_cols or []))
         spec = _lib.JoinSpec(join_type, int(bool(right_eq_cols_are_key)), len(left_types), len(right_types),
-                             self._keep[0], self._keep[1], len(left_eq), 0, self._keep[2], self._keep[3])
+                             self._keep[0], self._keep[1], len(left_eq), -1 if out_cols is None else len(out_cols),
+                             self._keep[2], self._keep[3], self._keep[4])
         self.h = C.c_void_p()
         _lib.check(_lib.load().crgpu_dev_join_create(C.byref(spec), C.byref(self.h)))
         self._build_cols = None

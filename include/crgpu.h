@@ -132,8 +132,11 @@ typedef struct crgpu_join_spec {
   int32_t n_left_cols, n_right_cols;
   const int32_t *left_types, *right_types; /* crgpu_type per column */
   int32_t n_eq;
-  int32_t _pad;
+  int32_t n_out_cols; /* -1: emit every column of JoinType.MakeOutputTypes; else the PostProcessSpec
+                         projection (execinfrapb.PostProcessSpec.OutputColumns, hashjoiner_test.go:939-968)
+                         pushed into the joiner so that unused columns are never materialised */
   const int32_t *left_eq, *right_eq; /* equality column ordinals */
+  const int32_t *out_cols;           /* n_out_cols ordinals into (left columns ++ right columns) as emitted */
 } crgpu_join_spec;
 
 typedef struct crgpu_join crgpu_join;
