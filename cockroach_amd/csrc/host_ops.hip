@@ -1,0 +1,622 @@
+// host_ops.hip -- layer (2) of include/crgpu.h: the operator boundary a cgo shell binds.
+//
+// Takes coldata.Batch-shaped HOST memory exactly as Go lays it out (pkg/col/coldata:
+// dense value slices, 32-byte Bytes elements + buffer, validity bitmaps, []int
+// selection vectors), stages it (deselect + Bytes -> offsets/data), moves it to HBM
+// in large pieces, drives the bulk device API and hands results back in caller-owned
+// output batches -- the colexecop.Operator Next() contract
+// (pkg/sql/colexecop/operator.go:22-58).  Nothing borrowed is retained across calls.
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+
+#include "common.h"
+
+namespace crgpu {
+
+static constexpr int64_t kFlushRows = int64_t(1) << 20;  // staged probe / agg / router rows before a device round trip
+static constexpr int kElemSize = 32;                     // coldata.ElementSize (bytes.go:76-78)
+static constexpr int kMaxInline = 30;                    // coldata.BytesMaxInlineLength (bytes.go:80-82)
+
+// ------------------------------------------------------------------ host-side staging
+struct HostCol {
+  int type = 0;
+  std::vector<uint8_t> data;      // fixed-width values or BYTES payload
+  std::vector<uint32_t> offsets;  // BYTES: n+1
+  std::vector<uint8_t> present;   // one byte per row
+  bool any_null = false;
+  int64_t n = 0;
+  void init(int t) {
+    type = t;
+    clear();
+  }
+  void clear() {
+    data.clear();
+    offsets.clear();
+    present.clear();
+    if (type == CRGPU_BYTES) offsets.push_back(0);
+    any_null = false;
+    n = 0;
+  }
+};
+
+static inline bool host_is_null(const crgpu_col &c, int64_t i) {
+  return c.maybe_has_nulls && c.nulls != nullptr && !((c.nulls[i >> 3] >> (i & 7)) & 1);
+}
+
+// element.get (bytes.go:93-103)
+static inline const uint8_t *elem_get(const crgpu_col &c, int64_t i, uint32_t *len) {
+  const uint8_t *e = static_cast<const uint8_t *>(c.data) + i * kElemSize;
+  if (e[31]) {  // inlined
+    *len = e[30];
+    return e;
+  }
+  int64_t off, l;
+  std::memcpy(&off, e, 8);
+  std::memcpy(&l, e + 8, 8);
+  *len = static_cast<uint32_t>(l);
+  return c.bytes_buf + off;
+}
+
+// AppendTuples with deselection (colexecutils/utils.go:204)
+static crgpu_status stage_batch(std::vector<HostCol> &cols, const crgpu_batch *b) {
+  if (b == nullptr) return fail(CRGPU_ERR_INVALID, "null batch");
+  if (b->length < 0) return fail(CRGPU_ERR_INVALID, "negative batch length");
+  if (b->ncols != static_cast<int>(cols.size())) return fail(CRGPU_ERR_INVALID, "batch column count differs from the spec");
+  if (b->length == 0) return CRGPU_OK;
+  if (b->cols == nullptr) return fail(CRGPU_ERR_INVALID, "batch without columns");
+  const int64_t n = b->length;
+  for (size_t ci = 0; ci < cols.size(); ci++) {
+    const crgpu_col &c = b->cols[ci];
+    HostCol &h = cols[ci];
+    if (c.type != h.type) return fail(CRGPU_ERR_INVALID, "batch column type differs from the spec");
+    if (c.data == nullptr) return fail(CRGPU_ERR_INVALID, "batch column without data");
+    const size_t old = h.present.size();
+    h.present.resize(old + n);
+    if (h.type == CRGPU_BYTES) {
+      for (int64_t r = 0; r < n; r++) {
+        const int64_t i = b->sel ? b->sel[r] : r;
+        const bool isnull = host_is_null(c, i);
+        h.present[old + r] = !isnull;
+        if (isnull) {
+          h.any_null = true;
+        } else {
+          uint32_t len;
+          const uint8_t *p = elem_get(c, i, &len);
+          if (h.data.size() + len > 0xFFFFFFF0ull) return fail(CRGPU_ERR_UNSUPPORTED, "a staged BYTES column exceeds 4 GiB");
+          h.data.insert(h.data.end(), p, p + len);
+        }
+        h.offsets.push_back(static_cast<uint32_t>(h.data.size()));
+      }
+    } else {
+      const int w = type_width(h.type);
+      const size_t oldb = h.data.size();
+      h.data.resize(oldb + static_cast<size_t>(n) * w);
+      const uint8_t *src = static_cast<const uint8_t *>(c.data);
+      if (b->sel == nullptr) {
+        std::memcpy(h.data.data() + oldb, src, static_cast<size_t>(n) * w);
+      } else {
+        for (int64_t r = 0; r < n; r++) std::memcpy(h.data.data() + oldb + r * w, src + b->sel[r] * w, w);
+      }
+      for (int64_t r = 0; r < n; r++) {
+        const bool isnull = host_is_null(c, b->sel ? b->sel[r] : r);
+        h.present[old + r] = !isnull;
+        if (isnull) h.any_null = true;
+      }
+    }
+    h.n += n;
+  }
+  return CRGPU_OK;
+}
+
+// ------------------------------------------------------------------ device copies of staged tables
+struct DevTable {
+  std::vector<DevBuf> data, valid, offsets;
+  std::vector<crgpu_dcol> cols;
+  int64_t n = 0;
+};
+
+static crgpu_status upload_table(const std::vector<HostCol> &h, DevTable &t) {
+  const size_t nc = h.size();
+  if (t.data.size() != nc) {
+    t.data = std::vector<DevBuf>(nc);
+    t.valid = std::vector<DevBuf>(nc);
+    t.offsets = std::vector<DevBuf>(nc);
+    t.cols.resize(nc);
+  }
+  t.n = nc ? h[0].n : 0;
+  std::vector<uint8_t> bitmap;
+  for (size_t c = 0; c < nc; c++) {
+    const HostCol &hc = h[c];
+    crgpu_dcol &d = t.cols[c];
+    d.type = hc.type;
+    d._pad = 0;
+    CRGPU_TRY(t.data[c].ensure(hc.data.size() ? hc.data.size() : 16));
+    if (!hc.data.empty()) CRGPU_HIP(hipMemcpy(t.data[c].p, hc.data.data(), hc.data.size(), hipMemcpyHostToDevice));
+    d.data = t.data[c].p;
+    d.offsets = nullptr;
+    if (hc.type == CRGPU_BYTES) {
+      CRGPU_TRY(t.offsets[c].ensure(hc.offsets.size() * 4));
+      CRGPU_HIP(hipMemcpy(t.offsets[c].p, hc.offsets.data(), hc.offsets.size() * 4, hipMemcpyHostToDevice));
+      d.offsets = t.offsets[c].as<uint32_t>();
+    }
+    d.valid = nullptr;
+    if (hc.any_null) {
+      bitmap.assign(static_cast<size_t>((hc.n + 7) / 8), 0xFF);
+      for (int64_t i = 0; i < hc.n; i++)
+        if (!hc.present[i]) bitmap[i >> 3] &= static_cast<uint8_t>(~(1u << (i & 7)));
+      CRGPU_TRY(t.valid[c].ensure(bitmap.size() ? bitmap.size() : 1));
+      CRGPU_HIP(hipMemcpy(t.valid[c].p, bitmap.data(), bitmap.size(), hipMemcpyHostToDevice));
+      d.valid = t.valid[c].as<uint8_t>();
+    }
+  }
+  return CRGPU_OK;
+}
+
+// result of a bulk call copied back to the host, served in output batches
+struct HostResult {
+  std::vector<HostCol> cols;
+  int64_t n = 0, cursor = 0;
+};
+
+static crgpu_status download_result(const crgpu_dev_result &r, HostResult &out) {
+  out.n = r.n;
+  out.cursor = 0;
+  out.cols.resize(r.ncols);
+  CRGPU_HIP(hipStreamSynchronize(stream()));
+  std::vector<uint8_t> bitmap;
+  for (int c = 0; c < r.ncols; c++) {
+    const crgpu_dcol &d = r.cols[c];
+    HostCol &h = out.cols[c];
+    h.init(d.type);
+    h.n = r.n;
+    h.present.assign(static_cast<size_t>(r.n), 1);
+    if (d.valid != nullptr && r.n > 0) {
+      bitmap.resize(static_cast<size_t>((r.n + 7) / 8));
+      CRGPU_HIP(hipMemcpy(bitmap.data(), d.valid, bitmap.size(), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < r.n; i++) {
+        h.present[i] = (bitmap[i >> 3] >> (i & 7)) & 1;
+        if (!h.present[i]) h.any_null = true;
+      }
+    }
+    if (d.type == CRGPU_BYTES) {
+      h.offsets.assign(static_cast<size_t>(r.n + 1), 0);
+      if (r.n > 0) CRGPU_HIP(hipMemcpy(h.offsets.data(), d.offsets, static_cast<size_t>(r.n + 1) * 4, hipMemcpyDeviceToHost));
+      h.data.resize(h.offsets[r.n]);
+      if (!h.data.empty()) CRGPU_HIP(hipMemcpy(h.data.data(), d.data, h.data.size(), hipMemcpyDeviceToHost));
+    } else {
+      h.data.resize(static_cast<size_t>(r.n) * type_width(d.type));
+      if (!h.data.empty()) CRGPU_HIP(hipMemcpy(h.data.data(), d.data, h.data.size(), hipMemcpyDeviceToHost));
+    }
+  }
+  return CRGPU_OK;
+}
+
+// Copy rows [cursor, cursor+k) of `src` into the caller's output batch (coldata layout).
+// Returns false (and fills bytes_buf_len with the required sizes) if a BYTES spill buffer is too small.
+static crgpu_status emit_rows(HostResult &src, crgpu_out_batch *out, bool *emitted) {
+  *emitted = false;
+  out->length = 0;
+  if (out->ncols != static_cast<int>(src.cols.size())) return fail(CRGPU_ERR_INVALID, "output batch column count differs from the operator's output schema");
+  if (out->capacity <= 0) return fail(CRGPU_ERR_INVALID, "output batch without capacity");
+  const int64_t k = std::min<int64_t>(out->capacity, src.n - src.cursor);
+  if (k <= 0) return CRGPU_OK;
+  // pass 1: BYTES spill requirements
+  bool fits = true;
+  for (size_t c = 0; c < src.cols.size(); c++) {
+    crgpu_out_col &o = out->cols[c];
+    const HostCol &h = src.cols[c];
+    if (o.type != h.type) return fail(CRGPU_ERR_INVALID, "output batch column type differs from the operator's output schema");
+    o.bytes_buf_len = 0;
+    if (h.type != CRGPU_BYTES) continue;
+    int64_t need = 0;
+    for (int64_t r = 0; r < k; r++) {
+      const uint32_t len = h.offsets[src.cursor + r + 1] - h.offsets[src.cursor + r];
+      if (len > static_cast<uint32_t>(kMaxInline)) need += len;
+    }
+    o.bytes_buf_len = need;
+    if (need > o.bytes_buf_cap) fits = false;
+  }
+  if (!fits) return CRGPU_OK;  // length stays 0, bytes_buf_len tells the caller how much to allocate
+  for (size_t c = 0; c < src.cols.size(); c++) {
+    crgpu_out_col &o = out->cols[c];
+    const HostCol &h = src.cols[c];
+    if (o.data == nullptr) return fail(CRGPU_ERR_INVALID, "output column without data buffer");
+    o.has_nulls = 0;
+    if (o.nulls != nullptr) std::memset(o.nulls, 0xFF, static_cast<size_t>((out->capacity + 7) / 8));
+    for (int64_t r = 0; r < k; r++) {
+      if (!h.present[src.cursor + r]) {
+        if (o.nulls == nullptr) return fail(CRGPU_ERR_INVALID, "output column needs a null bitmap");
+        o.nulls[r >> 3] &= static_cast<uint8_t>(~(1u << (r & 7)));
+        o.has_nulls = 1;
+      }
+    }
+    if (h.type == CRGPU_BYTES) {
+      uint8_t *elems = static_cast<uint8_t *>(o.data);
+      int64_t spill = 0;
+      for (int64_t r = 0; r < k; r++) {
+        const uint32_t a = h.offsets[src.cursor + r], len = h.offsets[src.cursor + r + 1] - a;
+        uint8_t *e = elems + r * kElemSize;
+        std::memset(e, 0, kElemSize);
+        if (len <= static_cast<uint32_t>(kMaxInline)) {  // element.set (bytes.go:105-112)
+          if (len) std::memcpy(e, h.data.data() + a, len);
+          e[30] = static_cast<uint8_t>(len);
+          e[31] = 1;
+        } else {
+          const int64_t l64 = len;
+          std::memcpy(e, &spill, 8);
+          std::memcpy(e + 8, &l64, 8);
+          std::memcpy(e + 16, &l64, 8);
+          std::memcpy(o.bytes_buf + spill, h.data.data() + a, len);
+          spill += len;
+        }
+      }
+    } else {
+      const int w = type_width(h.type);
+      std::memcpy(o.data, h.data.data() + static_cast<size_t>(src.cursor) * w, static_cast<size_t>(k) * w);
+    }
+  }
+  src.cursor += k;
+  out->length = k;
+  *emitted = true;
+  return CRGPU_OK;
+}
+
+static crgpu_status emit_from_queue(std::deque<std::unique_ptr<HostResult>> &q, crgpu_out_batch *out) {
+  out->length = 0;
+  while (!q.empty() && q.front()->cursor >= q.front()->n) q.pop_front();
+  if (q.empty()) return CRGPU_OK;
+  bool emitted;
+  return emit_rows(*q.front(), out, &emitted);
+}
+
+static void init_cols(std::vector<HostCol> &cols, const std::vector<int> &types) {
+  cols.resize(types.size());
+  for (size_t i = 0; i < types.size(); i++) cols[i].init(types[i]);
+}
+static void clear_cols(std::vector<HostCol> &cols) {
+  for (auto &c : cols) c.clear();
+}
+
+}  // namespace crgpu
+
+using namespace crgpu;
+
+// ====================================================================== crgpu_hash_cols
+extern "C" crgpu_status crgpu_hash_cols(const crgpu_col *cols, int32_t ncols, int64_t n, const int64_t *sel,
+                                        uint64_t init, int32_t width, uint64_t nbuckets, void *out_host) {
+  CRGPU_TRY(ensure_init());
+  if (n < 0 || ncols < 0 || ncols > kMaxKeyCols) return fail(CRGPU_ERR_INVALID, "crgpu_hash_cols: bad n / ncols");
+  if (width != 32 && width != 64) return fail(CRGPU_ERR_INVALID, "crgpu_hash_cols: width must be 32 or 64");
+  if (n == 0) return CRGPU_OK;
+  if (cols == nullptr || out_host == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hash_cols: null argument");
+  std::vector<int> types;
+  for (int c = 0; c < ncols; c++) {
+    if (!valid_type(cols[c].type)) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_hash_cols: unsupported column type");
+    types.push_back(cols[c].type);
+  }
+  std::vector<HostCol> staged;
+  init_cols(staged, types);
+  crgpu_batch b{n, sel, ncols, 0, cols};
+  CRGPU_TRY(stage_batch(staged, &b));
+  DevTable t;
+  CRGPU_TRY(upload_table(staged, t));
+  DevBuf out;
+  CRGPU_TRY(out.ensure(static_cast<size_t>(n) * (width / 8)));
+  CRGPU_TRY(crgpu_dev_hash_cols(t.cols.data(), ncols, n, init, width, nbuckets, out.p));
+  CRGPU_HIP(hipMemcpy(out_host, out.p, static_cast<size_t>(n) * (width / 8), hipMemcpyDeviceToHost));
+  return CRGPU_OK;
+}
+
+// ====================================================================== hash joiner shell
+struct crgpu_hj {
+  crgpu_join *dev = nullptr;
+  std::vector<int> left_types, right_types;
+  std::vector<HostCol> build_stage, probe_stage;
+  DevTable build_dev, probe_dev;
+  enum State { BUILDING, PROBING, DRAINING } state = BUILDING;
+  std::deque<std::unique_ptr<HostResult>> outq;
+  int64_t export_cursor = 0;
+  bool build_on_host = true;
+  std::unique_ptr<HostResult> export_copy;
+};
+
+extern "C" crgpu_status crgpu_hj_new(const crgpu_join_spec *spec, crgpu_hj **out) {
+  if (spec == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_new: null argument");
+  crgpu_join *dev = nullptr;
+  CRGPU_TRY(crgpu_dev_join_create(spec, &dev));
+  auto h = new crgpu_hj();
+  h->dev = dev;
+  for (int i = 0; i < spec->n_left_cols; i++) h->left_types.push_back(spec->left_types[i]);
+  for (int i = 0; i < spec->n_right_cols; i++) h->right_types.push_back(spec->right_types[i]);
+  init_cols(h->build_stage, h->right_types);
+  init_cols(h->probe_stage, h->left_types);
+  *out = h;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_hj_free(crgpu_hj *h) {
+  if (h == nullptr) return;
+  crgpu_dev_join_destroy(h->dev);
+  delete h;
+}
+
+extern "C" crgpu_status crgpu_hj_reset(crgpu_hj *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_reset: null handle");
+  CRGPU_TRY(crgpu_dev_join_reset(h->dev));
+  clear_cols(h->build_stage);
+  clear_cols(h->probe_stage);
+  h->outq.clear();
+  h->state = crgpu_hj::BUILDING;
+  h->export_cursor = 0;
+  h->build_on_host = true;
+  h->export_copy.reset();
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_hj_build_append(crgpu_hj *h, const crgpu_batch *right) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_build_append: null handle");
+  if (h->state != crgpu_hj::BUILDING) return fail(CRGPU_ERR_STATE, "crgpu_hj_build_append: the build side is already finished");
+  return stage_batch(h->build_stage, right);
+}
+
+extern "C" crgpu_status crgpu_hj_build_finish(crgpu_hj *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_build_finish: null handle");
+  if (h->state != crgpu_hj::BUILDING) return fail(CRGPU_ERR_STATE, "crgpu_hj_build_finish: called twice");
+  CRGPU_TRY(upload_table(h->build_stage, h->build_dev));
+  CRGPU_TRY(crgpu_dev_join_build(h->dev, h->build_dev.cols.data(), h->build_dev.n));
+  h->state = crgpu_hj::PROBING;
+  return CRGPU_OK;
+}
+
+static crgpu_status hj_flush_probe(crgpu_hj *h) {
+  if (h->probe_stage.empty() || h->probe_stage[0].n == 0) return CRGPU_OK;
+  if (h->build_on_host) {  // the host copy of the build side is only needed for ExportBuffered before probing starts
+    clear_cols(h->build_stage);
+    for (auto &c : h->build_stage) { c.data.shrink_to_fit(); c.present.shrink_to_fit(); c.offsets.shrink_to_fit(); }
+    h->build_on_host = false;
+  }
+  CRGPU_TRY(upload_table(h->probe_stage, h->probe_dev));
+  crgpu_dev_result r;
+  CRGPU_TRY(crgpu_dev_join_probe(h->dev, h->probe_dev.cols.data(), h->probe_dev.n, &r));
+  clear_cols(h->probe_stage);
+  if (r.n > 0) {
+    std::unique_ptr<HostResult> hr(new HostResult());
+    CRGPU_TRY(download_result(r, *hr));
+    h->outq.push_back(std::move(hr));
+  }
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_hj_probe_append(crgpu_hj *h, const crgpu_batch *left) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_probe_append: null handle");
+  if (h->state != crgpu_hj::PROBING) return fail(CRGPU_ERR_STATE, "crgpu_hj_probe_append: build side not finished or probe side already finished");
+  CRGPU_TRY(stage_batch(h->probe_stage, left));
+  if (!h->probe_stage.empty() && h->probe_stage[0].n >= kFlushRows) CRGPU_TRY(hj_flush_probe(h));
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_hj_probe_finish(crgpu_hj *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_probe_finish: null handle");
+  if (h->state != crgpu_hj::PROBING) return fail(CRGPU_ERR_STATE, "crgpu_hj_probe_finish: not probing");
+  CRGPU_TRY(hj_flush_probe(h));
+  crgpu_dev_result r;
+  CRGPU_TRY(crgpu_dev_join_emit_right(h->dev, &r));  // hjEmittingRight (hashjoiner.go:322-328)
+  if (r.n > 0) {
+    std::unique_ptr<HostResult> hr(new HostResult());
+    CRGPU_TRY(download_result(r, *hr));
+    h->outq.push_back(std::move(hr));
+  }
+  h->state = crgpu_hj::DRAINING;
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_hj_next_output(crgpu_hj *h, crgpu_out_batch *out) {
+  if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_next_output: null argument");
+  out->length = 0;
+  while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
+  if (h->outq.empty() && h->state == crgpu_hj::PROBING) CRGPU_TRY(hj_flush_probe(h));
+  return emit_from_queue(h->outq, out);
+}
+
+extern "C" crgpu_status crgpu_hj_export_buffered(crgpu_hj *h, crgpu_out_batch *out) {
+  if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_export_buffered: null argument");
+  out->length = 0;
+  if (!h->export_copy) {
+    h->export_copy.reset(new HostResult());
+    if (h->build_on_host) {
+      h->export_copy->cols = h->build_stage;  // copy of the staged build rows
+      h->export_copy->n = h->build_stage.empty() ? 0 : h->build_stage[0].n;
+    } else {
+      crgpu_dev_result r;
+      r.n = h->build_dev.n;
+      r.ncols = static_cast<int32_t>(h->build_dev.cols.size());
+      r._pad = 0;
+      r.cols = h->build_dev.cols.data();
+      CRGPU_TRY(download_result(r, *h->export_copy));
+    }
+    h->export_copy->cursor = 0;
+  }
+  if (h->export_copy->cursor >= h->export_copy->n) return CRGPU_OK;
+  bool emitted;
+  return emit_rows(*h->export_copy, out, &emitted);
+}
+
+// ====================================================================== hash aggregator shell
+struct crgpu_ha {
+  crgpu_agg *dev = nullptr;
+  std::vector<int> types;
+  std::vector<HostCol> stage;
+  DevTable staged_dev;
+  bool finished = false;
+  std::deque<std::unique_ptr<HostResult>> outq;
+};
+
+extern "C" crgpu_status crgpu_agg_new(const crgpu_agg_spec *spec, crgpu_ha **out) {
+  if (spec == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_new: null argument");
+  crgpu_agg *dev = nullptr;
+  CRGPU_TRY(crgpu_dev_agg_create(spec, &dev));
+  auto h = new crgpu_ha();
+  h->dev = dev;
+  for (int i = 0; i < spec->n_cols; i++) h->types.push_back(spec->types[i]);
+  init_cols(h->stage, h->types);
+  *out = h;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_agg_free(crgpu_ha *h) {
+  if (h == nullptr) return;
+  crgpu_dev_agg_destroy(h->dev);
+  delete h;
+}
+
+extern "C" crgpu_status crgpu_agg_reset(crgpu_ha *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_reset: null handle");
+  CRGPU_TRY(crgpu_dev_agg_reset(h->dev));
+  clear_cols(h->stage);
+  h->outq.clear();
+  h->finished = false;
+  return CRGPU_OK;
+}
+
+static crgpu_status ha_flush(crgpu_ha *h) {
+  const int64_t n = h->stage.empty() ? 0 : h->stage[0].n;
+  if (n == 0) return CRGPU_OK;
+  CRGPU_TRY(upload_table(h->stage, h->staged_dev));
+  CRGPU_TRY(crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n));
+  clear_cols(h->stage);
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_agg_append(crgpu_ha *h, const crgpu_batch *in) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_append: null handle");
+  if (h->finished) return fail(CRGPU_ERR_STATE, "crgpu_agg_append: input already finished");
+  if (h->types.empty()) {
+    // no input columns at all (COUNT_ROWS only): nothing to stage but the row count matters
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_agg_append: aggregation without input columns");
+  }
+  CRGPU_TRY(stage_batch(h->stage, in));
+  if (h->stage[0].n >= kFlushRows) CRGPU_TRY(ha_flush(h));
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_agg_finish(crgpu_ha *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_finish: null handle");
+  if (h->finished) return fail(CRGPU_ERR_STATE, "crgpu_agg_finish: called twice");
+  CRGPU_TRY(ha_flush(h));
+  crgpu_dev_result r;
+  CRGPU_TRY(crgpu_dev_agg_finish(h->dev, &r));
+  if (r.n > 0) {
+    std::unique_ptr<HostResult> hr(new HostResult());
+    CRGPU_TRY(download_result(r, *hr));
+    h->outq.push_back(std::move(hr));
+  }
+  h->finished = true;
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_agg_next_output(crgpu_ha *h, crgpu_out_batch *out) {
+  if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_next_output: null argument");
+  out->length = 0;
+  if (!h->finished) return CRGPU_OK;  // the hash aggregator emits only after its input is exhausted
+  return emit_from_queue(h->outq, out);
+}
+
+// ====================================================================== hash router shell
+struct crgpu_router {
+  crgpu_partitioner *dev = nullptr;
+  std::vector<int> types;
+  int num_outputs = 0;
+  std::vector<HostCol> stage;
+  DevTable staged_dev;
+  std::vector<std::deque<std::unique_ptr<HostResult>>> outq;
+  std::mutex mu;  // Run() and every output's Next() live on different goroutines (routers.go:486-488)
+};
+
+extern "C" crgpu_status crgpu_route_new(const int32_t *types, int32_t n_cols, const int32_t *hash_cols, int32_t n_hash,
+                                        int32_t num_outputs, crgpu_router **out) {
+  if (out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_new: null argument");
+  crgpu_partitioner *dev = nullptr;
+  // HashRouter uses the default init hash value 1 (routers.go:557)
+  CRGPU_TRY(crgpu_dev_partitioner_create(types, n_cols, hash_cols, n_hash, 1, num_outputs, &dev));
+  auto r = new crgpu_router();
+  r->dev = dev;
+  r->num_outputs = num_outputs;
+  for (int i = 0; i < n_cols; i++) r->types.push_back(types[i]);
+  init_cols(r->stage, r->types);
+  r->outq.resize(num_outputs);
+  *out = r;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_route_free(crgpu_router *r) {
+  if (r == nullptr) return;
+  crgpu_dev_partitioner_destroy(r->dev);
+  delete r;
+}
+
+static crgpu_status route_flush(crgpu_router *r) {
+  const int64_t n = r->stage.empty() ? 0 : r->stage[0].n;
+  if (n == 0) return CRGPU_OK;
+  CRGPU_TRY(upload_table(r->stage, r->staged_dev));
+  crgpu_dev_result res;
+  std::vector<int64_t> counts(r->num_outputs, 0);
+  CRGPU_TRY(crgpu_dev_partition(r->dev, r->staged_dev.cols.data(), n, &res, counts.data()));
+  clear_cols(r->stage);
+  HostResult all;
+  CRGPU_TRY(download_result(res, all));
+  int64_t start = 0;
+  for (int p = 0; p < r->num_outputs; p++) {
+    const int64_t k = counts[p];
+    if (k > 0) {
+      std::unique_ptr<HostResult> hr(new HostResult());
+      hr->n = k;
+      hr->cols.resize(all.cols.size());
+      for (size_t c = 0; c < all.cols.size(); c++) {
+        const HostCol &s = all.cols[c];
+        HostCol &d = hr->cols[c];
+        d.init(s.type);
+        d.n = k;
+        d.present.assign(s.present.begin() + start, s.present.begin() + start + k);
+        if (s.type == CRGPU_BYTES) {
+          const uint32_t a = s.offsets[start], b = s.offsets[start + k];
+          d.data.assign(s.data.begin() + a, s.data.begin() + b);
+          d.offsets.resize(static_cast<size_t>(k + 1));
+          for (int64_t i = 0; i <= k; i++) d.offsets[i] = s.offsets[start + i] - a;
+        } else {
+          const int w = type_width(s.type);
+          d.data.assign(s.data.begin() + start * w, s.data.begin() + (start + k) * w);
+        }
+      }
+      r->outq[p].push_back(std::move(hr));
+    }
+    start += k;
+  }
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_route_partition(crgpu_router *r, const crgpu_batch *in) {
+  if (r == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_partition: null handle");
+  std::lock_guard<std::mutex> lk(r->mu);
+  CRGPU_TRY(stage_batch(r->stage, in));
+  if (!r->stage.empty() && r->stage[0].n >= kFlushRows) CRGPU_TRY(route_flush(r));
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_route_finish(crgpu_router *r) {
+  if (r == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_finish: null handle");
+  std::lock_guard<std::mutex> lk(r->mu);
+  return route_flush(r);
+}
+
+extern "C" crgpu_status crgpu_route_next_output(crgpu_router *r, int32_t output, crgpu_out_batch *out) {
+  if (r == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_next_output: null argument");
+  if (output < 0 || output >= r->num_outputs) return fail(CRGPU_ERR_INVALID, "crgpu_route_next_output: output index out of range");
+  std::lock_guard<std::mutex> lk(r->mu);
+  out->length = 0;
+  auto &q = r->outq[output];
+  while (!q.empty() && q.front()->cursor >= q.front()->n) q.pop_front();
+  if (q.empty()) CRGPU_TRY(route_flush(r));  // nothing buffered for this output: push what is staged through the device
+  return emit_from_queue(q, out);
+}
