@@ -77,6 +77,7 @@ def main():
     from cockroach_amd import coldata as cd
     from cockroach_amd import device as dev
     from cockroach_amd import _lib
+    from cockroach_amd.exchange import all_to_all_regions
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -112,18 +113,10 @@ def main():
     def exchange(part, cols_t, n):
         """hash-repartition + all-to-all; returns received torch tensors (k, x)."""
         res, counts = part.partition([dev.from_torch(I64, t) for t in cols_t], n)
-        send_counts = torch.tensor(counts.tolist(), device=device, dtype=torch.int64)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts)
-        rc = recv_counts.tolist()
-        total = int(sum(rc))
-        outs = []
-        for c in range(res.ncols):
-            src = _wrap(torch, res.cols[c].data, n, device)
-            dst = torch.empty(total, device=device, dtype=torch.int64)
-            dist.all_to_all_single(dst, src, output_split_sizes=rc, input_split_sizes=counts.tolist())
-            outs.append(dst)
-        return outs, total
+        torch.cuda.synchronize()  # the regions were written on the library stream
+        srcs = [_wrap(torch, res.cols[c].data, n, device) for c in range(res.ncols)]
+        outs, rc = all_to_all_regions(srcs, counts.tolist())
+        return outs, int(sum(rc))
 
     def step():
         if world == 1:
