@@ -208,4 +208,20 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
   return k;
 }
 
+// Packed key: ints sign-extended to 64 bits (mixed widths compare equal,
+// hashtable_tmpl.go:275-281); floats by bits with NaN and -0 canonicalised so
+// that NaN == NaN and +0 == -0 (hashtable_full_default.eg.go:4073-4091).
+__device__ __forceinline__ uint64_t pack_key(const DCol &c, int64_t i) {
+  switch (c.type) {
+    case CRGPU_BOOL: return col_get_bool(c, i);
+    case CRGPU_FLOAT64: {
+      double f = col_get_f64(c, i);
+      if (f != f) return 0x7FF8000000000000ull;
+      if (f == 0) return 0;
+      return static_cast<uint64_t>(__double_as_longlong(f));
+    }
+    default: return static_cast<uint64_t>(col_get_int(c, i));
+  }
+}
+
 }  // namespace crgpu

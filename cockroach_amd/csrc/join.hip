@@ -23,7 +23,10 @@
 // Roofline: HBM-bound (random 16-byte slot reads + streaming columns).
 #include <cstring>
 
+#include <cstdlib>
+
 #include "device.h"
+#include "radix.h"
 
 namespace crgpu {
 
@@ -37,22 +40,6 @@ struct Special {  // the one build key whose packed value equals kEmptyKey
   unsigned int _pad;
   unsigned long long val;
 };
-
-// Packed key: ints sign-extended to 64 bits (mixed widths compare equal,
-// hashtable_tmpl.go:275-281); floats by bits with NaN and -0 canonicalised so
-// that NaN == NaN and +0 == -0 (hashtable_full_default.eg.go:4073-4091).
-__device__ __forceinline__ uint64_t pack_key(const DCol &c, int64_t i) {
-  switch (c.type) {
-    case CRGPU_BOOL: return col_get_bool(c, i);
-    case CRGPU_FLOAT64: {
-      double f = col_get_f64(c, i);
-      if (f != f) return 0x7FF8000000000000ull;
-      if (f == 0) return 0;
-      return static_cast<uint64_t>(__double_as_longlong(f));
-    }
-    default: return static_cast<uint64_t>(col_get_int(c, i));
-  }
-}
 
 // ------------------------------------------------------------------ PACKED build
 __global__ __launch_bounds__(256) void packed_build_kernel(DCol key, int64_t n, Slot *__restrict__ slots,
@@ -410,6 +397,9 @@ struct crgpu_join {
   uint64_t cap = 0;
   bool covering = false;
   int cover_col = -1;
+  // radix-partitioned table (large unique-key build sides, radix.h)
+  RadixTable radix;
+  bool use_radix = false;
   // chained table
   DevBuf first, next;
   uint32_t nb = 0;
@@ -520,6 +510,30 @@ extern "C" crgpu_status crgpu_dev_join_reset(crgpu_join *j) {
   return CRGPU_OK;
 }
 
+
+// ---- radix path (radix.h): eligibility and row sources
+static int64_t env_i64(const char *name, int64_t def) {
+  const char *v = std::getenv(name);
+  return (v != nullptr && *v != 0) ? std::atoll(v) : def;
+}
+static bool radix_eligible(const crgpu_join *j, int64_t n) {
+  const int jt = j->join_type;
+  if (!(jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_SEMI || jt == CRGPU_LEFT_ANTI)) return false;
+  if (j->track_build_matches || j->out_src.size() > static_cast<size_t>(kRadixMaxFused)) return false;
+  return n > 0 && n >= env_i64("CRGPU_RADIX_MIN_BUILD", int64_t(1) << 22);
+}
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static RadixSrc radix_src(const DCol &key, const DCol *pay) {
+  RadixSrc s;
+  std::memset(&s, 0, sizeof(s));
+  s.key = key;
+  s.pay = pay ? static_cast<const uint8_t *>(pay->data) : nullptr;
+  s.pay_width = pay ? type_width(pay->type) : 0;
+  s.fast = key.type == CRGPU_INT64 && key.valid == nullptr && pay != nullptr && s.pay_width == 8 &&
+           aligned16(key.data) && aligned16(pay->data);
+  return s;
+}
+
 extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
   if (j == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null handle");
   if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_build: build side limited to 2^31 rows per table");
@@ -553,10 +567,6 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
   if (j->packed) {
     const int kc = j->right_eq[0];
     j->cap = next_pow2(static_cast<uint64_t>(n) * 2 < 1024 ? 1024 : static_cast<uint64_t>(n) * 2);
-    CRGPU_TRY(j->slots.ensure(j->cap * sizeof(Slot)));
-    CRGPU_TRY(j->special.ensure(sizeof(Special)));
-    CRGPU_HIP(hipMemsetAsync(j->slots.p, 0xFF, j->cap * sizeof(Slot), st));
-    CRGPU_HIP(hipMemsetAsync(j->special.p, 0, sizeof(Special), st));
     // covering: every emitted build column is the int/bool key itself or ONE 8-byte non-null payload
     // column, which then rides in the slot's val word (no row-id indirection at probe time).
     j->covering = false;
@@ -581,7 +591,21 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
         j->cover_col = pc;
       }
     }
-    if (n > 0) {
+    j->use_radix = false;
+    if (radix_eligible(j, n)) {
+      RadixSrc src = radix_src(j->build_cols[kc],
+                               (j->covering && j->cover_col >= 0) ? &j->build_cols[j->cover_col] : nullptr);
+      bool ok = false;
+      CRGPU_TRY(radix_build(j->radix, src, n, &ok));
+      j->use_radix = ok;
+    }
+    if (!j->use_radix) {
+      CRGPU_TRY(j->slots.ensure(j->cap * sizeof(Slot)));
+      CRGPU_TRY(j->special.ensure(sizeof(Special)));
+      CRGPU_HIP(hipMemsetAsync(j->slots.p, 0xFF, j->cap * sizeof(Slot), st));
+      CRGPU_HIP(hipMemsetAsync(j->special.p, 0, sizeof(Special), st));
+    }
+    if (n > 0 && !j->use_radix) {
       const uint64_t *payload = (j->covering && j->cover_col >= 0)
                                     ? static_cast<const uint64_t *>(j->build_cols[j->cover_col].data)
                                     : nullptr;
@@ -762,6 +786,107 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
   return finish_result(j, static_cast<int64_t>(nout), res);
 }
 
+
+// Probe through the radix-partitioned table.  Probe-side columns ride along as the row's
+// 64-bit payload when one fixed-width non-null column (plus, optionally, the key itself)
+// is all that is emitted; otherwise the payload is the probe row id and the columns are
+// gathered afterwards, like the build columns of a non-covering table.
+static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, int64_t n, crgpu_dev_result *res) {
+  const int jt = j->join_type;
+  const bool outer_nulls = left_or_full_outer(jt);
+  const bool keeps_unmatched = jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_ANTI;
+  hipStream_t st = stream();
+  const int64_t cap_rows = n > 0 ? n : 1;
+  const int lkc = j->left_eq[0], rkc = j->right_eq[0];
+  const DCol &lkey = left[lkc];
+  const bool key_castable = lkey.type != CRGPU_FLOAT64;
+
+  int pay_col = -1;
+  bool need_pairs_p = false;
+  for (const auto &os : j->out_src) {
+    if (!os.is_left) continue;
+    if (os.src == lkc && key_castable) continue;
+    const DCol &c = left[os.src];
+    if (c.type == CRGPU_BYTES || c.valid != nullptr || (pay_col != -1 && pay_col != os.src)) need_pairs_p = true;
+    else pay_col = os.src;
+  }
+  if (need_pairs_p) pay_col = -1;
+  RadixSrc src = radix_src(lkey, pay_col >= 0 ? &left[pay_col] : nullptr);
+
+  RadixEmit e;
+  std::memset(&e, 0, sizeof(e));
+  CRGPU_TRY(j->counter.ensure(8));
+  CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
+  e.out_count = j->counter.as<unsigned long long>();
+  struct Later { int out_idx; bool is_left; int src; };
+  std::vector<Later> later;
+  std::vector<int> fused_out;
+  int oc = 0;
+  auto add_fused = [&](int type, int side, bool nullable) -> crgpu_status {
+    OutCol &o = j->out[oc];
+    o.type = type;
+    o.nullable = nullable;
+    CRGPU_TRY(o.data.ensure(static_cast<size_t>(cap_rows) * type_width(type)));
+    RadixCopy &cc = e.copy[e.ncopy++];
+    fused_out.push_back(oc);
+    cc.dst = o.data.as<uint8_t>();
+    cc.width = type_width(type);
+    cc.side = side;
+    cc.dst_valid = nullptr;
+    if (nullable) {
+      CRGPU_TRY(j->valid_bytes[oc].ensure(static_cast<size_t>(cap_rows)));
+      CRGPU_TRY(o.valid.ensure(static_cast<size_t>((cap_rows + 7) / 8 + 1)));
+      cc.dst_valid = j->valid_bytes[oc].as<uint8_t>();
+    }
+    return CRGPU_OK;
+  };
+  bool need_pairs_b = false;
+  for (const auto &os : j->out_src) {
+    const int c = os.src;
+    if (os.is_left) {
+      if (c == lkc && key_castable) CRGPU_TRY(add_fused(lkey.type, R_KEY, keeps_unmatched && lkey.valid != nullptr));
+      else if (c == pay_col) CRGPU_TRY(add_fused(left[c].type, R_PROBE_PAY, false));
+      else later.push_back(Later{oc, true, c});
+    } else if (j->covering) {  // c is the key column or the cover column
+      CRGPU_TRY(add_fused(j->build_cols[c].type, c == j->cover_col ? R_BUILD_VAL : R_BUILD_KEY, outer_nulls));
+    } else {
+      later.push_back(Later{oc, false, c});
+      need_pairs_b = true;
+    }
+    oc++;
+  }
+  (void)rkc;
+  if (need_pairs_p) {
+    CRGPU_TRY(j->pair_p.ensure(static_cast<size_t>(cap_rows) * 4));
+    e.pair_p = j->pair_p.as<int32_t>();
+  }
+  if (need_pairs_b) {
+    CRGPU_TRY(j->pair_b.ensure(static_cast<size_t>(cap_rows) * 4));
+    e.pair_b = j->pair_b.as<int32_t>();
+  }
+  uint64_t nout = 0;
+  if (n > 0) {
+    int64_t min_probe = j->n_build >> 3;
+    if (min_probe < (int64_t(1) << 20)) min_probe = int64_t(1) << 20;
+    const bool partitioned = n >= env_i64("CRGPU_RADIX_MIN_PROBE", min_probe);
+    CRGPU_TRY(radix_probe(j->radix, jt, src, n, e, partitioned));
+    CRGPU_HIP(hipMemcpyAsync(&nout, j->counter.p, 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+  }
+  for (int c = 0; c < e.ncopy; c++)
+    if (e.copy[c].dst_valid != nullptr)
+      CRGPU_TRY(pack_bitmap(e.copy[c].dst_valid, static_cast<int64_t>(nout), j->out[fused_out[c]].valid.as<uint8_t>()));
+  for (const Later &l : later) {
+    if (l.is_left)
+      CRGPU_TRY(materialize(left[l.src], j->pair_p.as<int32_t>(), static_cast<int64_t>(nout), false, j->out[l.out_idx], j->scratch));
+    else
+      CRGPU_TRY(materialize(j->build_cols[l.src], j->pair_b.as<int32_t>(), static_cast<int64_t>(nout), outer_nulls,
+                            j->out[l.out_idx], j->scratch));
+  }
+  CRGPU_HIP(hipStreamSynchronize(st));
+  return finish_result(j, static_cast<int64_t>(nout), res);
+}
+
 template <int JT>
 static void launch_chain(const ChainArgs &a, bool fill) {
   int grid = grid_for(a.n, 256);
@@ -867,6 +992,7 @@ extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *le
   join_setup_outputs(j);
   // Empty build side short-circuits (hashjoiner.go:300-306, join_type.go:79-88): the
   // kernels below already produce the right answer on an empty table, so no special case.
+  if (j->packed && j->use_radix) return probe_radix(j, left, n, res);
   if (j->packed) return probe_packed(j, left, n, res);
   return probe_chained(j, left, n, res);
 }

@@ -1,0 +1,77 @@
+// radix.h -- radix-partitioned hash join for large build sides (internal).
+//
+// A probe of an N_b-row table that does not fit the caches costs one random HBM
+// sector per row (~26 G accesses/s on MI355X, measured) no matter how the table is
+// laid out.  For big joins both inputs are therefore partitioned ONCE by the top
+// bits of fmix64(key) into 1024 partitions (one pass, every HBM write a full
+// 128-byte line), the build side is refined into sub-partitions of <= 3072 rows that
+// each get a 3072-slot open-addressing table built in LDS, and the probe kernel runs
+// partition by partition with all workgroups of an XCD on the same partition so that
+// partition's tables (<= 3 MiB) stay in that XCD's L2.
+#pragma once
+
+#include "common.h"
+
+namespace crgpu {
+
+static constexpr int kRadixP1 = 1024;        // level-1 partitions: hash bits 54..63
+static constexpr int kRadixMaxSubBits = 6;   // level-2 sub-partitions per partition: hash bits 48..53
+static constexpr int kRadixSlots = 3072;     // slots of one sub-partition's table (48 KiB, built in LDS)
+static constexpr int kRadixSubCap = 2560;    // rows one sub-partition may hold (load factor <= 0.83; ~0.67 typical)
+static constexpr unsigned long long kRadixEmpty = 0xFFFFFFFFFFFFFFFFull;
+static constexpr int kRadixSubPad = 512;     // extra rows per partition for 8-row alignment of sub-partitions
+static constexpr int kRadixMaxFused = 16;
+
+enum RadixSide : int32_t { R_KEY = 0, R_PROBE_PAY = 1, R_BUILD_VAL = 2, R_BUILD_KEY = 3 };
+
+struct RadixCopy {
+  uint8_t *dst;
+  uint8_t *dst_valid;  // one byte per output row, or null when the column cannot be NULL
+  int32_t width;
+  int32_t side;
+};
+
+struct RadixEmit {
+  int32_t ncopy;
+  int32_t _pad;
+  RadixCopy copy[kRadixMaxFused];
+  int32_t *pair_p;  // optional: probe row ids (payload is the row id)
+  int32_t *pair_b;  // optional: build row ids (value is the row id), -1 when unmatched
+  unsigned long long *out_count;
+};
+
+// One side of the join as {packed key, 64-bit payload} rows.
+struct RadixSrc {
+  DCol key;
+  const uint8_t *pay;  // payload column, or null => the payload is the row id
+  int32_t pay_width;
+  int32_t fast;  // int64 key without NULLs + 8-byte payload, both 16-byte aligned: vector loads
+};
+
+struct RadixSpecial {  // the one build key whose packed value equals kRadixEmpty
+  unsigned int present;
+  unsigned int _pad;
+  unsigned long long val;
+};
+
+struct RadixTable {
+  bool ready = false;
+  int sub_bits = 0;
+  int64_t n = 0;
+  DevBuf rows_a, rows_b;  // level-1 output; level-2 output (rows grouped by sub-partition)
+  DevBuf table, special;  // kRadixSlots slots per sub-partition
+  DevBuf hist, totals, starts, sub_start, sub_count, flag;
+  DevBuf p_rows, p_hist, p_totals, p_starts;  // probe-side partition buffers
+};
+
+// Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows
+// kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
+crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok);
+// Probes n rows.  partitioned: radix-partition the probe rows first (large probes);
+// otherwise look every row up directly (three dependent random reads per row).
+// nulls_pass: additionally emit the probe rows whose key is NULL as unmatched
+// (LEFT OUTER / LEFT ANTI).
+crgpu_status radix_probe(RadixTable &t, int join_type, const RadixSrc &src, int64_t n, const RadixEmit &emit,
+                         bool partitioned);
+
+}  // namespace crgpu

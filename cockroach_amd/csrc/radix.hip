@@ -1,0 +1,700 @@
+// radix.hip -- radix-partitioned hash join (see radix.h for the design).
+//
+// Replaces, for large unique-key build sides, the same reference code as join.hip's
+// packed table: HashTable.FullBuild / DistinctCheck / distinctCollect*
+// (colexechash/hashtable.go:477,921; colexecjoin/hashjoiner_tmpl.go:16-337).
+//
+// Kernels and their bound (all HBM streaming; measured on MI355X, 2^29 rows of 16 B):
+//   radix_hist_kernel      reads the key column once                       ~5.5 TB/s
+//   radix_scatter_kernel   streams (key, payload) in, full 128-B lines out ~4.7 TB/s (copy: 5.0)
+//   radix_split_kernel     per partition: refine into <=64 sub-partitions
+//   radix_table_kernel     per sub-partition: open-addressing table built in LDS, written out coalesced
+//   radix_probe_kernel     partition-at-a-time probe out of the XCD's L2
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "device.h"
+#include "radix.h"
+
+namespace crgpu {
+
+typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t rpart(uint64_t h) { return static_cast<uint32_t>(h >> 54); }
+__device__ __forceinline__ uint32_t rsub(uint64_t h, uint32_t smask) { return static_cast<uint32_t>(h >> 48) & smask; }
+// The three candidate slots of a key inside its sub-partition's table (3-way cuckoo hashing):
+// 32-bit hash fields scaled to [0, kRadixSlots).
+__device__ __forceinline__ uint32_t rscale(uint32_t x) {
+  return static_cast<uint32_t>((static_cast<uint64_t>(x) * kRadixSlots) >> 32);
+}
+__device__ __forceinline__ void rslots(uint64_t h, uint32_t *s) {
+  const uint64_t g = fmix64(h + 0x9E3779B97F4A7C15ULL);
+  s[0] = rscale(static_cast<uint32_t>(h));
+  s[1] = rscale(static_cast<uint32_t>(g));
+  s[2] = rscale(static_cast<uint32_t>(g >> 32));
+}
+
+__device__ __forceinline__ uint64_t rload(const uint8_t *src, int64_t i, int width) {
+  switch (width) {
+    case 1: return src[i];
+    case 2: return reinterpret_cast<const uint16_t *>(src)[i];
+    case 4: return reinterpret_cast<const uint32_t *>(src)[i];
+    default: return reinterpret_cast<const uint64_t *>(src)[i];
+  }
+}
+// output columns are written once and never re-read by the kernel: non-temporal, so that
+// they do not displace the partition's table from L2
+__device__ __forceinline__ void rstore(uint8_t *dst, int64_t pos, int width, uint64_t v) {
+  switch (width) {
+    case 1: __builtin_nontemporal_store(static_cast<uint8_t>(v), dst + pos); break;
+    case 2: __builtin_nontemporal_store(static_cast<uint16_t>(v), reinterpret_cast<uint16_t *>(dst) + pos); break;
+    case 4: __builtin_nontemporal_store(static_cast<uint32_t>(v), reinterpret_cast<uint32_t *>(dst) + pos); break;
+    default: __builtin_nontemporal_store(v, reinterpret_cast<uint64_t *>(dst) + pos); break;
+  }
+}
+
+// rows r0, r0+1 (r0 even) of one join side as {packed key, payload}
+template <bool FAST>
+__device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64_t hi, uint64_t *k, uint64_t *v,
+                                            bool *ok) {
+  if (FAST && r0 + 1 < hi) {
+    const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(s.key.data)[r0 >> 1];
+    const ulonglong2 b = reinterpret_cast<const ulonglong2 *>(s.pay)[r0 >> 1];
+    k[0] = a.x, k[1] = a.y, v[0] = b.x, v[1] = b.y;
+    ok[0] = ok[1] = true;
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int64_t r = r0 + t;
+    ok[t] = r < hi && !col_is_null(s.key, r);
+    k[t] = 0, v[t] = 0;
+    if (ok[t]) {
+      k[t] = pack_key(s.key, r);
+      v[t] = s.pay ? rload(s.pay, r, s.pay_width) : static_cast<uint64_t>(r);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ level 1: histogram per chunk
+template <bool FAST>
+__global__ __launch_bounds__(1024) void radix_hist_kernel(RadixSrc src, int64_t n, int64_t chunk_rows,
+                                                          uint32_t *__restrict__ hist) {
+  __shared__ uint32_t h[kRadixP1];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t lo = blockIdx.x * chunk_rows;
+  int64_t hi = lo + chunk_rows;
+  if (hi > n) hi = n;
+  for (int64_t r0 = lo + 2 * static_cast<int64_t>(threadIdx.x); r0 < hi; r0 += 2048) {
+    if (FAST && r0 + 1 < hi) {
+      const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(src.key.data)[r0 >> 1];
+      atomicAdd(&h[rpart(fmix64(a.x))], 1u);
+      atomicAdd(&h[rpart(fmix64(a.y))], 1u);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int64_t r = r0 + t;
+        if (r < hi && !col_is_null(src.key, r)) atomicAdd(&h[rpart(fmix64(pack_key(src.key, r)))], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  hist[static_cast<int64_t>(blockIdx.x) * kRadixP1 + threadIdx.x] = h[threadIdx.x];
+}
+
+// ------------------------------------------------------------------ level 1: offsets
+// totals[p] = rows of partition p; starts[p] = first row of partition p (8-row aligned);
+// hist[c][p] becomes the first row chunk c writes for partition p.
+// One block of 1024 threads per 64 partitions: thread (g = tid / 64, px = tid % 64) owns chunk group g.
+__global__ __launch_bounds__(1024) void radix_colsum_kernel(const uint32_t *__restrict__ hist, int nchunks,
+                                                            uint32_t *__restrict__ totals) {
+  const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + px;
+  __shared__ uint32_t s[16][64];
+  const int per = (nchunks + 15) / 16;
+  uint32_t sum = 0;
+  for (int c = g * per; c < (g + 1) * per && c < nchunks; c++) sum += hist[static_cast<int64_t>(c) * kRadixP1 + p];
+  s[g][px] = sum;
+  __syncthreads();
+  if (g == 0) {
+    uint32_t t = 0;
+    for (int i = 0; i < 16; i++) t += s[i][px];
+    totals[p] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void radix_starts_kernel(const uint32_t *__restrict__ totals,
+                                                            uint32_t *__restrict__ starts) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t padded = (totals[threadIdx.x] + 7u) & ~7u;
+  const uint32_t incl = wave_incl_scan_u32(padded);
+  if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < static_cast<int>(threadIdx.x >> 6); w++) base += wsum[w];
+  starts[threadIdx.x] = base + incl - padded;
+}
+
+__global__ __launch_bounds__(1024) void radix_offs_kernel(uint32_t *__restrict__ hist, int nchunks,
+                                                          const uint32_t *__restrict__ starts) {
+  const int px = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + px;
+  __shared__ uint32_t s[16][64];
+  const int per = (nchunks + 15) / 16;
+  uint32_t sum = 0;
+  for (int c = g * per; c < (g + 1) * per && c < nchunks; c++) sum += hist[static_cast<int64_t>(c) * kRadixP1 + p];
+  s[g][px] = sum;
+  __syncthreads();
+  uint32_t base = starts[p];
+  for (int i = 0; i < g; i++) base += s[i][px];
+  for (int c = g * per; c < (g + 1) * per && c < nchunks; c++) {
+    const uint32_t v = hist[static_cast<int64_t>(c) * kRadixP1 + p];
+    hist[static_cast<int64_t>(c) * kRadixP1 + p] = base;
+    base += v;
+  }
+}
+
+// ------------------------------------------------------------------ level 1: scatter
+// Per-partition 128-byte line buffers in LDS (1024 x 128 B): rows are ranked with LDS
+// atomics; a partition's first pending line is completed in its buffer and written by 8
+// adjacent lanes, further complete lines of the same tile go out straight from registers,
+// the remainder waits in the buffer.  Every HBM write is therefore a whole line (random
+// 64-byte writes run at 3.4 TB/s, 16-byte ones at 2.0, whole lines at 4.7).
+template <bool FAST>
+__global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64_t n, int64_t chunk_rows,
+                                                             const uint32_t *__restrict__ offs,
+                                                             ulonglong2 *__restrict__ out) {
+  constexpr int P = kRadixP1, THREADS = 1024, ROWS = 4, TILE = THREADS * ROWS;
+  __shared__ ulonglong2 bins[P * 8];
+  __shared__ uint32_t cnt[P];    // rows pending in the buffer (incl. phantom slots before the first flush)
+  __shared__ uint32_t gbase[P];  // line-aligned absolute row position of buffer slot 0
+  __shared__ uint8_t first[P];   // first real slot: chunk-start misalignment, 0 after the first flush
+  {
+    const uint32_t g0 = offs[static_cast<int64_t>(blockIdx.x) * P + threadIdx.x];
+    const uint32_t a = g0 & 7u;
+    gbase[threadIdx.x] = g0 - a;
+    cnt[threadIdx.x] = a;
+    first[threadIdx.x] = static_cast<uint8_t>(a);
+  }
+  __syncthreads();
+  const int64_t lo = blockIdx.x * chunk_rows;
+  int64_t hi = lo + chunk_rows;
+  if (hi > n) hi = n;
+  uint64_t nk[ROWS], nv[ROWS];
+  bool nok[ROWS];
+#pragma unroll
+  for (int j = 0; j < ROWS / 2; j++)
+    radix_load2<FAST>(src, lo + static_cast<int64_t>(j * THREADS + threadIdx.x) * 2, hi, nk + 2 * j, nv + 2 * j, nok + 2 * j);
+  for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
+    uint64_t kk[ROWS], vv[ROWS];
+    uint32_t pp[ROWS], rk[ROWS], nfl[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      kk[j] = nk[j], vv[j] = nv[j];
+      pp[j] = nok[j] ? rpart(fmix64(kk[j])) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS / 2; j++)  // prefetch the next tile while this one is ranked and flushed
+      radix_load2<FAST>(src, t0 + TILE + static_cast<int64_t>(j * THREADS + threadIdx.x) * 2, hi, nk + 2 * j, nv + 2 * j,
+                        nok + 2 * j);
+    // A: rank among the partition's pending rows
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      if (pp[j] != 0xFFFFFFFFu) rk[j] = atomicAdd(&cnt[pp[j]], 1u);
+    __syncthreads();
+    // B: rows of the first line join the buffer; rows of further complete lines go straight to HBM
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      if (pp[j] != 0xFFFFFFFFu) {
+        nfl[j] = cnt[pp[j]] & ~7u;
+        if (rk[j] < 8u) bins[pp[j] * 8 + rk[j]] = make_ulonglong2(kk[j], vv[j]);
+        else if (rk[j] < nfl[j]) out[gbase[pp[j]] + rk[j]] = make_ulonglong2(kk[j], vv[j]);
+      }
+    }
+    __syncthreads();
+    // C: flush every complete first line, 8 lanes per line
+    for (int i = threadIdx.x; i < P * 8; i += THREADS) {
+      const int p = i >> 3, sl = i & 7;
+      if (cnt[p] >= 8u && sl >= static_cast<int>(first[p])) out[gbase[p] + sl] = bins[i];
+    }
+    __syncthreads();
+    // D: rows past the last complete line are the new buffer content
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      if (pp[j] != 0xFFFFFFFFu && rk[j] >= 8u && rk[j] >= nfl[j])
+        bins[pp[j] * 8 + (rk[j] - nfl[j])] = make_ulonglong2(kk[j], vv[j]);
+    {
+      const uint32_t t = cnt[threadIdx.x], f = t & ~7u;
+      if (f) {
+        gbase[threadIdx.x] += f;
+        cnt[threadIdx.x] = t - f;
+        first[threadIdx.x] = 0;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < P * 8; i += THREADS) {
+    const int p = i >> 3, sl = i & 7;
+    if (sl >= static_cast<int>(first[p]) && sl < static_cast<int>(cnt[p])) out[gbase[p] + sl] = bins[i];
+  }
+}
+
+// ------------------------------------------------------------------ level 2 (build side): refine one partition
+__global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__restrict__ in,
+                                                           const uint32_t *__restrict__ starts,
+                                                           const uint32_t *__restrict__ totals, uint32_t smask,
+                                                           ulonglong2 *__restrict__ out, uint32_t *__restrict__ sub_start,
+                                                           uint32_t *__restrict__ sub_count, uint32_t *__restrict__ overflow) {
+  const int p = blockIdx.x;
+  const uint32_t nsub = smask + 1;
+  __shared__ uint32_t hw[16][64];
+  __shared__ uint32_t cur[64];
+  hw[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+  __syncthreads();
+  const uint32_t s0 = starts[p], n = totals[p];
+  const int wave = threadIdx.x >> 6;
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&hw[wave][rsub(fmix64(in[s0 + i].x), smask)], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    uint32_t c = 0;
+    if (threadIdx.x < nsub)
+      for (int w = 0; w < 16; w++) c += hw[w][threadIdx.x];
+    const uint32_t padded = (c + 7u) & ~7u;
+    const uint32_t incl = wave_incl_scan_u32(padded);
+    if (threadIdx.x < nsub) {
+      const uint32_t base = s0 + static_cast<uint32_t>(kRadixSubPad) * p + incl - padded;
+      cur[threadIdx.x] = base;
+      sub_start[p * nsub + threadIdx.x] = base;
+      sub_count[p * nsub + threadIdx.x] = c;
+      if (c > static_cast<uint32_t>(kRadixSubCap)) atomicOr(overflow, 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+    const ulonglong2 row = in[s0 + i];
+    const uint32_t pos = atomicAdd(&cur[rsub(fmix64(row.x), smask)], 1u);
+    out[pos] = row;
+  }
+}
+
+// ------------------------------------------------------------------ level 3 (build side): one table per sub-partition
+// A divergent 16-byte load costs ~2 cycles per ACTIVE lane on a CU (measured: 270 G lane-loads/s
+// chip-wide, L1 or L2 hit alike), and a wave keeps looping until its slowest lane is done, so a
+// table is judged by loads per lookup and by the LENGTH OF THE TAIL.  Linear probing (mean 2,
+// tail 16+) and line-local buckets (mean 3.2) both measured 3-5x slower than this layout:
+// 3-way cuckoo hashing, one 16-byte slot per candidate, built in LDS by one workgroup per
+// sub-partition (<= 2560 rows into 3072 slots; load threshold of 3-way cuckoo is 0.91).
+// A lookup reads at most three slots (1.6 on average for a hit; an EMPTY slot ends a miss early
+// because occupied slots never become empty again).  The 48 KiB image is written out coalesced.
+__global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__restrict__ rows,
+                                                          const uint32_t *__restrict__ sub_start,
+                                                          const uint32_t *__restrict__ sub_count,
+                                                          ulonglong2 *__restrict__ table,
+                                                          RadixSpecial *__restrict__ special, uint32_t *__restrict__ failed) {
+  constexpr int THREADS = 512;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  __shared__ ulonglong2 srow[kRadixSubCap];
+  __shared__ uint32_t tab[kRadixSlots];
+  const int q = blockIdx.x;
+  const uint32_t base = sub_start[q];
+  uint32_t n = sub_count[q];
+  if (n > static_cast<uint32_t>(kRadixSubCap)) n = kRadixSubCap;  // overflow is reported by the split kernel
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) srow[i] = rows[base + i];
+  for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) tab[i] = kNone;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    if (srow[i].x == kRadixEmpty) {  // the one key equal to the empty marker lives beside the table
+      special->val = srow[i].y;
+      special->present = 1;
+      continue;
+    }
+    uint32_t cur = i, from = kNone, rnd = (i + 1u) * 2654435761u + static_cast<uint32_t>(q);
+    int iter = 0;
+    for (; iter < 4096; iter++) {
+      const unsigned long long kcur = srow[cur].x;
+      uint32_t s[3];
+      rslots(fmix64(kcur), s);
+      bool placed = false;
+#pragma unroll
+      for (int c = 0; c < 3 && !placed; c++) {
+        const uint32_t old = atomicCAS(&tab[s[c]], kNone, cur);
+        if (old == kNone || srow[old].x == kcur) placed = true;  // free slot, or a duplicate key: first writer wins
+      }
+      if (placed) break;
+      rnd = rnd * 1664525u + 1013904223u;
+      uint32_t c = (rnd >> 16) % 3u;  // evict one of the three occupants (random walk)
+      if (s[c] == from) c = (c + 1u) % 3u;
+      const uint32_t old = atomicExch(&tab[s[c]], cur);
+      if (old == kNone) break;
+      from = s[c];
+      cur = old;
+    }
+    if (iter == 4096) atomicOr(failed, 2u);
+  }
+  __syncthreads();
+  ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
+  for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) {
+    const uint32_t id = tab[i];
+    dst[i] = id == kNone ? make_ulonglong2(kRadixEmpty, 0) : srow[id];
+  }
+}
+
+// ------------------------------------------------------------------ probe
+struct RadixProbeArgs {
+  const ulonglong2 *prow;  // partitioned probe rows (MODE 0)
+  const uint32_t *pstart;
+  const uint32_t *pcount;
+  RadixSrc src;  // probe columns (MODE 1, 2)
+  int64_t n;
+  const ulonglong2 *table;
+  const RadixSpecial *special;
+  uint32_t smask;
+  int32_t sub_bits;
+  int32_t wg_per_part;
+  int32_t debug;
+  RadixEmit emit;
+};
+
+// MODE 0: partition-at-a-time (workgroups b, b+8, b+16, ... share an XCD, so the W
+//         workgroups of a partition are given consecutive ids on one XCD and its CSR is
+//         read from HBM once and then served by that XCD's L2);
+// MODE 1: direct lookups of unpartitioned probe rows (small probes);
+// MODE 2: only the rows whose key is NULL, as unmatched (LEFT OUTER / LEFT ANTI).
+template <int JT, int MODE, int TB, int RPT>
+__global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
+  constexpr int kWaves = TB / 64;
+  constexpr int kTile = TB * RPT;
+  __shared__ uint32_t s_cnt[RPT * kWaves];
+  __shared__ uint32_t s_pre[RPT * kWaves];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const uint32_t nsub = a.smask + 1;
+
+  int64_t lo, hi, step;
+  uint32_t part = 0;
+  if (MODE == 0) {
+    const uint32_t b = blockIdx.x, x = b & 7u, i = b >> 3;
+    part = (i / a.wg_per_part) * 8u + x;
+    const uint32_t slice = i % a.wg_per_part;
+    // the workgroup takes tiles slice, slice + W, ... of its partition: no undersized slices
+    const int64_t pbeg = a.pstart[part];
+    lo = pbeg + static_cast<int64_t>(slice) * kTile;
+    hi = pbeg + a.pcount[part];
+    step = static_cast<int64_t>(a.wg_per_part) * kTile;
+  } else {
+    lo = static_cast<int64_t>(blockIdx.x) * kTile;
+    hi = a.n;
+    step = static_cast<int64_t>(gridDim.x) * kTile;
+  }
+
+  for (int64_t tbase = lo; tbase < hi; tbase += step) {
+    uint64_t k[RPT], pay[RPT];
+    unsigned long long val[RPT];
+    bool look[RPT], inb[RPT], found[RPT], emit[RPT], knull[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int64_t r = tbase + static_cast<int64_t>(j) * TB + tid;
+      inb[j] = r < hi;
+      look[j] = false, knull[j] = false, found[j] = false;
+      k[j] = 0, pay[j] = 0, val[j] = 0;
+      if (MODE == 0) {
+        if (inb[j]) {
+          if (a.debug & 4) {
+            const ulonglong2 row = a.prow[r];
+            k[j] = row.x, pay[j] = row.y;
+          } else {
+            const ull2 row = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(a.prow) + r);
+            k[j] = row.x, pay[j] = row.y;
+          }
+          look[j] = true;
+        }
+      } else if (inb[j]) {
+        knull[j] = col_is_null(a.src.key, r);
+        if (MODE == 2) {
+          inb[j] = knull[j];  // this pass only sees the NULL-key rows
+        } else {
+          look[j] = !knull[j];
+          if (knull[j]) inb[j] = false;  // NULL-key rows are emitted by the MODE 2 pass
+        }
+        if (!knull[j]) k[j] = pack_key(a.src.key, r);
+        pay[j] = a.src.pay ? rload(a.src.pay, r, a.src.pay_width) : static_cast<uint64_t>(r);
+      }
+    }
+    if (MODE != 2) {
+      // At most three dependent slot reads per row (3-way cuckoo).  Each stage is issued for all
+      // rows of the lane before the next one resolves; only lanes that still need a slot take
+      // part in a load (the cost of a divergent load is ~2 cycles per ACTIVE lane).  Everything
+      // is unrolled: indexing k[]/val[] with a loop variable would put them in scratch memory.
+      const ulonglong2 *tb[RPT];
+      uint32_t s1[RPT], s2[RPT];
+      ulonglong2 rw[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (look[j] && k[j] == kRadixEmpty) {
+          found[j] = a.special->present != 0;
+          val[j] = a.special->val;
+          look[j] = false;
+        }
+        if (a.debug & 1) { found[j] = look[j]; val[j] = k[j]; look[j] = false; }
+        tb[j] = a.table;
+        s1[j] = s2[j] = 0;
+        if (look[j]) {
+          const uint64_t h = fmix64(k[j]);
+          const uint32_t p = MODE == 0 ? part : rpart(h);
+          tb[j] = a.table + static_cast<int64_t>(p * nsub + rsub(h, a.smask)) * kRadixSlots;
+          uint32_t s[3];
+          rslots(h, s);
+          s1[j] = s[1], s2[j] = s[2];
+          rw[j] = tb[j][s[0]];
+        }
+      }
+#pragma unroll
+      for (int c = 1; c <= 3; c++) {
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+          if (look[j]) {
+            if (rw[j].x == k[j]) {
+              found[j] = true;
+              val[j] = rw[j].y;
+              look[j] = false;
+            } else if (rw[j].x == kRadixEmpty || c == 3) {
+              look[j] = false;
+            } else {
+              rw[j] = tb[j][c == 1 ? s1[j] : s2[j]];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      if (JT == CRGPU_INNER || JT == CRGPU_LEFT_SEMI) emit[j] = found[j];
+      else if (JT == CRGPU_LEFT_ANTI) emit[j] = inb[j] && !found[j];
+      else emit[j] = inb[j];  // LEFT OUTER keeps every probe row
+    }
+    uint32_t rank[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint64_t m = __ballot(emit[j]);
+      rank[j] = rank_in_mask(m);
+      if (lane_id() == 0) s_cnt[j * kWaves + wave] = popc64(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      constexpr int kPer = (RPT * kWaves + 63) / 64;
+      uint32_t e[kPer], sum = 0;
+#pragma unroll
+      for (int t = 0; t < kPer; t++) {
+        const int q = lane_id() * kPer + t;
+        e[t] = q < RPT * kWaves ? s_cnt[q] : 0;
+        sum += e[t];
+      }
+      const uint32_t incl = wave_incl_scan_u32(sum);
+      uint32_t ex = incl - sum;
+#pragma unroll
+      for (int t = 0; t < kPer; t++) {
+        const int q = lane_id() * kPer + t;
+        if (q < RPT * kWaves) s_pre[q] = ex;
+        ex += e[t];
+      }
+      if (lane_id() == 63) s_base = (a.debug & 8) ? static_cast<unsigned long long>(tbase) : (incl ? atomicAdd(a.emit.out_count, static_cast<unsigned long long>(incl)) : 0ull);
+    }
+    __syncthreads();
+    const unsigned long long obase = s_base;
+    int64_t pos[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) pos[j] = static_cast<int64_t>(obase + s_pre[j * kWaves + wave] + rank[j]);
+    for (int c = 0; c < ((a.debug & 2) ? 0 : a.emit.ncopy); c++) {
+      const RadixCopy cc = a.emit.copy[c];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (!emit[j]) continue;
+        uint64_t v;
+        uint32_t present = 1;
+        if (cc.side == R_KEY) {
+          v = k[j];
+          present = !knull[j];
+        } else if (cc.side == R_PROBE_PAY) {
+          v = pay[j];
+        } else {  // build side: NULL when a LEFT OUTER row has no match (hashjoiner.go:671-682)
+          v = cc.side == R_BUILD_KEY ? k[j] : val[j];
+          present = found[j];
+        }
+        rstore(cc.dst, pos[j], cc.width, v);
+        if (cc.dst_valid) cc.dst_valid[pos[j]] = static_cast<uint8_t>(present);
+      }
+    }
+    if (a.emit.pair_p != nullptr) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++)
+        if (emit[j]) a.emit.pair_p[pos[j]] = static_cast<int32_t>(pay[j]);
+    }
+    if (a.emit.pair_b != nullptr) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++)
+        if (emit[j]) a.emit.pair_b[pos[j]] = found[j] ? static_cast<int32_t>(val[j]) : -1;
+    }
+    __syncthreads();  // s_cnt / s_pre / s_base are reused by the next tile
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static void chunking(int64_t n, int *nchunks, int64_t *chunk_rows) {
+  int64_t want = (n + 65535) / 65536;  // >= 64 rows per partition and chunk on average
+  if (want < 1) want = 1;
+  if (want > 512) want = 512;
+  int64_t rows = (n + want - 1) / want;
+  rows = (rows + 4095) / 4096 * 4096;
+  if (rows < 4096) rows = 4096;
+  *chunk_rows = rows;
+  *nchunks = static_cast<int>((n + rows - 1) / rows);
+  if (*nchunks < 1) *nchunks = 1;
+}
+
+// hist -> offsets -> scatter of one side into `rows` (AoS {key, payload}); totals/starts per partition.
+static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist, DevBuf &totals, DevBuf &starts,
+                                    DevBuf &rows, int64_t extra_rows, const char *prof_hist, const char *prof_scatter) {
+  hipStream_t st = stream();
+  int nchunks;
+  int64_t chunk_rows;
+  chunking(n, &nchunks, &chunk_rows);
+  CRGPU_TRY(hist.ensure(static_cast<size_t>(nchunks) * kRadixP1 * 4));
+  CRGPU_TRY(totals.ensure(kRadixP1 * 4));
+  CRGPU_TRY(starts.ensure(kRadixP1 * 4));
+  CRGPU_TRY(rows.ensure(static_cast<size_t>(n + 8 * kRadixP1 + extra_rows) * 16));
+  {
+    ProfScope prof(prof_hist);
+    if (src.fast)
+      hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(radix_hist_kernel<false>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_colsum_kernel, dim3(kRadixP1 / 64), dim3(1024), 0, st, hist.as<uint32_t>(), nchunks,
+                       totals.as<uint32_t>());
+    hipLaunchKernelGGL(radix_starts_kernel, dim3(1), dim3(1024), 0, st, totals.as<uint32_t>(), starts.as<uint32_t>());
+    hipLaunchKernelGGL(radix_offs_kernel, dim3(kRadixP1 / 64), dim3(1024), 0, st, hist.as<uint32_t>(), nchunks,
+                       starts.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  {
+    ProfScope prof(prof_scatter);
+    if (src.fast)
+      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+                         hist.as<uint32_t>(), rows.as<ulonglong2>());
+    else
+      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+                         hist.as<uint32_t>(), rows.as<ulonglong2>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  return CRGPU_OK;
+}
+
+crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok) {
+  hipStream_t st = stream();
+  *ok = false;
+  t.ready = false;
+  t.n = n;
+  int lg = 0;
+  while ((int64_t(1) << lg) < n) lg++;
+  int sb = lg - 21;  // ~2048 rows per sub-partition
+  if (sb < 0) sb = 0;
+  if (sb > kRadixMaxSubBits) sb = kRadixMaxSubBits;
+  t.sub_bits = sb;
+  const uint32_t nsub = 1u << sb;
+  const int64_t extra = static_cast<int64_t>(kRadixSubPad) * kRadixP1;
+  CRGPU_TRY(radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter"));
+  CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(n + 8 * kRadixP1 + extra) * 16));
+  CRGPU_TRY(t.sub_start.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
+  CRGPU_TRY(t.sub_count.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
+  CRGPU_TRY(t.table.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSlots * 16));
+  CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
+  CRGPU_TRY(t.flag.ensure(4));
+  CRGPU_HIP(hipMemsetAsync(t.flag.p, 0, 4, st));
+  CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
+  {
+    ProfScope prof("radix_build_split");
+    hipLaunchKernelGGL(radix_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
+                       t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
+                       t.sub_start.as<uint32_t>(), t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  uint32_t overflow = 0;
+  CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  if (overflow && std::getenv("CRGPU_DEBUG_RADIX")) fprintf(stderr, "radix build: split kernel flag %u\n", overflow);
+  if (overflow) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
+  {
+    ProfScope prof("radix_build_table");
+    hipLaunchKernelGGL(radix_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                       t.sub_start.as<uint32_t>(), t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(),
+                       t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  if (overflow && std::getenv("CRGPU_DEBUG_RADIX")) fprintf(stderr, "radix build: table kernel flag %u\n", overflow);
+  if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (>= 4 equal keys, or an unlucky hash): classic table
+  t.ready = true;
+  *ok = true;
+  return CRGPU_OK;
+}
+
+static constexpr int kProbeTB = 512, kProbeRPT = 4;
+template <int MODE>
+static crgpu_status launch_probe(int jt, const RadixProbeArgs &a, int grid) {
+  constexpr int TB = kProbeTB, RPT = kProbeRPT;
+  hipStream_t st = stream();
+  switch (jt) {
+    case CRGPU_INNER: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_INNER, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_LEFT_OUTER: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_LEFT_OUTER, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_LEFT_SEMI: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_LEFT_SEMI, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    case CRGPU_LEFT_ANTI: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_LEFT_ANTI, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
+    default: return fail(CRGPU_ERR_INVALID, "radix probe: join type not handled");
+  }
+  CRGPU_HIP(hipGetLastError());
+  return CRGPU_OK;
+}
+
+crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, const RadixEmit &emit, bool partitioned) {
+  if (!t.ready) return fail(CRGPU_ERR_STATE, "radix probe: table not built");
+  if (n <= 0) return CRGPU_OK;
+  constexpr int kTile = kProbeTB * kProbeRPT;
+  RadixProbeArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.src = src;
+  a.n = n;
+  a.table = t.table.as<ulonglong2>();
+  a.special = t.special.as<RadixSpecial>();
+  a.smask = (1u << t.sub_bits) - 1;
+  a.sub_bits = t.sub_bits;
+  a.emit = emit;
+  { const char *d = std::getenv("CRGPU_DEBUG_PROBE"); a.debug = d ? std::atoi(d) : 0; }
+  const bool keeps_unmatched = jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_ANTI;
+  if (partitioned) {
+    CRGPU_TRY(radix_partition(src, n, t.p_hist, t.p_totals, t.p_starts, t.p_rows, 0, "radix_probe_hist", "radix_probe_scatter"));
+    a.prow = t.p_rows.as<ulonglong2>();
+    a.pstart = t.p_starts.as<uint32_t>();
+    a.pcount = t.p_totals.as<uint32_t>();
+    int64_t w = (n / kRadixP1 + kTile - 1) / kTile;
+    if (w < 1) w = 1;
+    if (w > 64) w = 64;  // all workgroups resident on an XCD (32 CUs x 2) share one partition
+    a.wg_per_part = static_cast<int32_t>(w);
+    ProfScope prof("join_probe");
+    CRGPU_TRY(launch_probe<0>(jt, a, kRadixP1 * static_cast<int>(w)));
+  } else {
+    int64_t tiles = (n + kTile - 1) / kTile;
+    int64_t cap = static_cast<int64_t>(num_cus()) * 4;
+    ProfScope prof("join_probe");
+    CRGPU_TRY(launch_probe<1>(jt, a, static_cast<int>(tiles < cap ? tiles : cap)));
+  }
+  if (keeps_unmatched && src.key.valid != nullptr) {  // NULL keys never match but LEFT OUTER / ANTI keep the row
+    int64_t tiles = (n + kTile - 1) / kTile;
+    int64_t cap = static_cast<int64_t>(num_cus()) * 4;
+    CRGPU_TRY(launch_probe<2>(jt, a, static_cast<int>(tiles < cap ? tiles : cap)));
+  }
+  return CRGPU_OK;
+}
+
+}  // namespace crgpu

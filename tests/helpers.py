@@ -76,7 +76,8 @@ def _sort_key(row):
         elif isinstance(v, bool):
             key.append((2, int(v)))
         else:
-            key.append((2, round(float(v), 5) if isinstance(v, float) else v))
+            # floats: tolerance-friendly primary key, exact value as the tie-break
+            key.append((2, round(float(v), 5), v) if isinstance(v, float) else (2, v))
     return key
 
 
