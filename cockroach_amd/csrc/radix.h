@@ -19,7 +19,6 @@ static constexpr int kRadixMaxSubBits = 6;   // level-2 sub-partitions per parti
 static constexpr int kRadixSlots = 3072;     // slots of one sub-partition's table (48 KiB, built in LDS)
 static constexpr int kRadixSubCap = 2560;    // rows one sub-partition may hold (load factor <= 0.83; ~0.67 typical)
 static constexpr unsigned long long kRadixEmpty = 0xFFFFFFFFFFFFFFFFull;
-static constexpr int kRadixSubPad = 512;     // extra rows per partition for 8-row alignment of sub-partitions
 static constexpr int kRadixMaxFused = 16;
 
 enum RadixSide : int32_t { R_KEY = 0, R_PROBE_PAY = 1, R_BUILD_VAL = 2, R_BUILD_KEY = 3 };
@@ -58,9 +57,9 @@ struct RadixTable {
   bool ready = false;
   int sub_bits = 0;
   int64_t n = 0;
-  DevBuf rows_a, rows_b;  // level-1 output; level-2 output (rows grouped by sub-partition)
+  DevBuf rows_a, rows_b;  // level-1 output; level-2 output (kRadixSubCap rows reserved per sub-partition)
   DevBuf table, special;  // kRadixSlots slots per sub-partition
-  DevBuf hist, totals, starts, sub_start, sub_count, flag;
+  DevBuf hist, totals, starts, sub_count, flag;
   DevBuf p_rows, p_hist, p_totals, p_starts;  // probe-side partition buffers
 };
 

@@ -242,40 +242,66 @@ __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64
 }
 
 // ------------------------------------------------------------------ level 2 (build side): refine one partition
+// One workgroup per level-1 partition, ONE pass: sub-partition (p, s) owns a fixed region of
+// kRadixSubCap rows, so no counting pass is needed; each 4096-row tile is counting-sorted by
+// sub-partition in LDS and written out as runs (~64 rows = 1 KiB per run, coalesced).
+// sub_count[p][s] = rows written; a region that would overflow raises the flag (the caller
+// falls back to the classic table) and the excess rows are dropped.
 __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__restrict__ in,
                                                            const uint32_t *__restrict__ starts,
                                                            const uint32_t *__restrict__ totals, uint32_t smask,
-                                                           ulonglong2 *__restrict__ out, uint32_t *__restrict__ sub_start,
-                                                           uint32_t *__restrict__ sub_count, uint32_t *__restrict__ overflow) {
+                                                           ulonglong2 *__restrict__ out, uint32_t *__restrict__ sub_count,
+                                                           uint32_t *__restrict__ overflow) {
+  constexpr int THREADS = 1024, ROWS = 4, TILE = THREADS * ROWS;
   const int p = blockIdx.x;
   const uint32_t nsub = smask + 1;
-  __shared__ uint32_t hw[16][64];
-  __shared__ uint32_t cur[64];
-  hw[threadIdx.x >> 6][threadIdx.x & 63] = 0;
+  __shared__ ulonglong2 stage[TILE];
+  __shared__ uint32_t tcnt[64], tstart[64], cur[64];
+  if (threadIdx.x < 64) tcnt[threadIdx.x] = 0, cur[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t s0 = starts[p], n = totals[p];
-  const int wave = threadIdx.x >> 6;
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&hw[wave][rsub(fmix64(in[s0 + i].x), smask)], 1u);
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    uint32_t c = 0;
-    if (threadIdx.x < nsub)
-      for (int w = 0; w < 16; w++) c += hw[w][threadIdx.x];
-    const uint32_t padded = (c + 7u) & ~7u;
-    const uint32_t incl = wave_incl_scan_u32(padded);
-    if (threadIdx.x < nsub) {
-      const uint32_t base = s0 + static_cast<uint32_t>(kRadixSubPad) * p + incl - padded;
-      cur[threadIdx.x] = base;
-      sub_start[p * nsub + threadIdx.x] = base;
-      sub_count[p * nsub + threadIdx.x] = c;
-      if (c > static_cast<uint32_t>(kRadixSubCap)) atomicOr(overflow, 1u);
+  ulonglong2 *obase = out + static_cast<int64_t>(p) * nsub * kRadixSubCap;
+  for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+    ulonglong2 row[ROWS];
+    uint32_t sp[ROWS], rk[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const uint32_t i = t0 + j * THREADS + threadIdx.x;
+      sp[j] = 0xFFFFFFFFu;
+      if (i < n) {
+        row[j] = in[s0 + i];
+        sp[j] = rsub(fmix64(row[j].x), smask);
+        rk[j] = atomicAdd(&tcnt[sp[j]], 1u);
+      }
     }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const uint32_t c = tcnt[threadIdx.x];
+      tstart[threadIdx.x] = wave_incl_scan_u32(c) - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      if (sp[j] != 0xFFFFFFFFu) stage[tstart[sp[j]] + rk[j]] = row[j];
+    __syncthreads();
+    const uint32_t tile_rows = n - t0 < static_cast<uint32_t>(TILE) ? n - t0 : TILE;
+    for (uint32_t i = threadIdx.x; i < tile_rows; i += THREADS) {
+      const ulonglong2 r = stage[i];
+      const uint32_t s = rsub(fmix64(r.x), smask);
+      const uint32_t pos = cur[s] + (i - tstart[s]);
+      if (pos < static_cast<uint32_t>(kRadixSubCap)) obase[static_cast<int64_t>(s) * kRadixSubCap + pos] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      cur[threadIdx.x] += tcnt[threadIdx.x];
+      tcnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-    const ulonglong2 row = in[s0 + i];
-    const uint32_t pos = atomicAdd(&cur[rsub(fmix64(row.x), smask)], 1u);
-    out[pos] = row;
+  if (threadIdx.x < nsub) {
+    const uint32_t c = cur[threadIdx.x];
+    sub_count[p * nsub + threadIdx.x] = c;
+    if (c > static_cast<uint32_t>(kRadixSubCap)) atomicOr(overflow, 1u);
   }
 }
 
@@ -289,7 +315,6 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
 // A lookup reads at most three slots (1.6 on average for a hit; an EMPTY slot ends a miss early
 // because occupied slots never become empty again).  The 48 KiB image is written out coalesced.
 __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__restrict__ rows,
-                                                          const uint32_t *__restrict__ sub_start,
                                                           const uint32_t *__restrict__ sub_count,
                                                           ulonglong2 *__restrict__ table,
                                                           RadixSpecial *__restrict__ special, uint32_t *__restrict__ failed) {
@@ -298,7 +323,7 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
   __shared__ ulonglong2 srow[kRadixSubCap];
   __shared__ uint32_t tab[kRadixSlots];
   const int q = blockIdx.x;
-  const uint32_t base = sub_start[q];
+  const int64_t base = static_cast<int64_t>(q) * kRadixSubCap;
   uint32_t n = sub_count[q];
   if (n > static_cast<uint32_t>(kRadixSubCap)) n = kRadixSubCap;  // overflow is reported by the split kernel
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) srow[i] = rows[base + i];
@@ -353,7 +378,7 @@ struct RadixProbeArgs {
   uint32_t smask;
   int32_t sub_bits;
   int32_t wg_per_part;
-  int32_t debug;
+  int32_t _pad;
   RadixEmit emit;
 };
 
@@ -400,14 +425,9 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
       look[j] = false, knull[j] = false, found[j] = false;
       k[j] = 0, pay[j] = 0, val[j] = 0;
       if (MODE == 0) {
-        if (inb[j]) {
-          if (a.debug & 4) {
-            const ulonglong2 row = a.prow[r];
-            k[j] = row.x, pay[j] = row.y;
-          } else {
-            const ull2 row = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(a.prow) + r);
-            k[j] = row.x, pay[j] = row.y;
-          }
+        if (inb[j]) {  // (prefetching the next tile here was measured: no gain, the kernel is L2-request bound)
+          const ull2 row = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(a.prow) + r);
+          k[j] = row.x, pay[j] = row.y;
           look[j] = true;
         }
       } else if (inb[j]) {
@@ -437,7 +457,6 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
           val[j] = a.special->val;
           look[j] = false;
         }
-        if (a.debug & 1) { found[j] = look[j]; val[j] = k[j]; look[j] = false; }
         tb[j] = a.table;
         s1[j] = s2[j] = 0;
         if (look[j]) {
@@ -499,14 +518,14 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
         if (q < RPT * kWaves) s_pre[q] = ex;
         ex += e[t];
       }
-      if (lane_id() == 63) s_base = (a.debug & 8) ? static_cast<unsigned long long>(tbase) : (incl ? atomicAdd(a.emit.out_count, static_cast<unsigned long long>(incl)) : 0ull);
+      if (lane_id() == 63) s_base = incl ? atomicAdd(a.emit.out_count, static_cast<unsigned long long>(incl)) : 0ull;
     }
     __syncthreads();
     const unsigned long long obase = s_base;
     int64_t pos[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; j++) pos[j] = static_cast<int64_t>(obase + s_pre[j * kWaves + wave] + rank[j]);
-    for (int c = 0; c < ((a.debug & 2) ? 0 : a.emit.ncopy); c++) {
+    for (int c = 0; c < a.emit.ncopy; c++) {
       const RadixCopy cc = a.emit.copy[c];
 #pragma unroll
       for (int j = 0; j < RPT; j++) {
@@ -603,10 +622,8 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   if (sb > kRadixMaxSubBits) sb = kRadixMaxSubBits;
   t.sub_bits = sb;
   const uint32_t nsub = 1u << sb;
-  const int64_t extra = static_cast<int64_t>(kRadixSubPad) * kRadixP1;
   CRGPU_TRY(radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter"));
-  CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(n + 8 * kRadixP1 + extra) * 16));
-  CRGPU_TRY(t.sub_start.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
+  CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSubCap * 16));
   CRGPU_TRY(t.sub_count.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
   CRGPU_TRY(t.table.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSlots * 16));
   CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
@@ -617,34 +634,30 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
     ProfScope prof("radix_build_split");
     hipLaunchKernelGGL(radix_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
                        t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
-                       t.sub_start.as<uint32_t>(), t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>());
+                       t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
   }
   uint32_t overflow = 0;
   CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
-  if (overflow && std::getenv("CRGPU_DEBUG_RADIX")) fprintf(stderr, "radix build: split kernel flag %u\n", overflow);
   if (overflow) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
   {
     ProfScope prof("radix_build_table");
     hipLaunchKernelGGL(radix_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
-                       t.sub_start.as<uint32_t>(), t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(),
+                       t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(),
                        t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
   }
   CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
-  if (overflow && std::getenv("CRGPU_DEBUG_RADIX")) fprintf(stderr, "radix build: table kernel flag %u\n", overflow);
   if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (>= 4 equal keys, or an unlucky hash): classic table
   t.ready = true;
   *ok = true;
   return CRGPU_OK;
 }
 
-static constexpr int kProbeTB = 512, kProbeRPT = 4;
-template <int MODE>
-static crgpu_status launch_probe(int jt, const RadixProbeArgs &a, int grid) {
-  constexpr int TB = kProbeTB, RPT = kProbeRPT;
+template <int MODE, int TB, int RPT>
+static crgpu_status launch_probe_cfg(int jt, const RadixProbeArgs &a, int grid) {
   hipStream_t st = stream();
   switch (jt) {
     case CRGPU_INNER: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_INNER, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
@@ -656,11 +669,18 @@ static crgpu_status launch_probe(int jt, const RadixProbeArgs &a, int grid) {
   CRGPU_HIP(hipGetLastError());
   return CRGPU_OK;
 }
+// 512 threads x 4 rows per tile, 64 workgroups per partition: the best of the shapes measured
+// ((256,4) 7.5 ms, (1024,2) 7.3, (512,2) 6.9, (256,8) 8.3, (512,8) 8.6 against 6.6 on config J).
+static constexpr int kProbeTB = 512, kProbeRPT = 4, kProbeTile = kProbeTB * kProbeRPT, kProbeWgPerPart = 64;
+template <int MODE>
+static crgpu_status launch_probe(int jt, const RadixProbeArgs &a, int grid) {
+  return launch_probe_cfg<MODE, kProbeTB, kProbeRPT>(jt, a, grid);
+}
 
 crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, const RadixEmit &emit, bool partitioned) {
   if (!t.ready) return fail(CRGPU_ERR_STATE, "radix probe: table not built");
   if (n <= 0) return CRGPU_OK;
-  constexpr int kTile = kProbeTB * kProbeRPT;
+  constexpr int kTile = kProbeTile;
   RadixProbeArgs a;
   std::memset(&a, 0, sizeof(a));
   a.src = src;
@@ -670,7 +690,6 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
   a.smask = (1u << t.sub_bits) - 1;
   a.sub_bits = t.sub_bits;
   a.emit = emit;
-  { const char *d = std::getenv("CRGPU_DEBUG_PROBE"); a.debug = d ? std::atoi(d) : 0; }
   const bool keeps_unmatched = jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_ANTI;
   if (partitioned) {
     CRGPU_TRY(radix_partition(src, n, t.p_hist, t.p_totals, t.p_starts, t.p_rows, 0, "radix_probe_hist", "radix_probe_scatter"));
@@ -679,7 +698,7 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
     a.pcount = t.p_totals.as<uint32_t>();
     int64_t w = (n / kRadixP1 + kTile - 1) / kTile;
     if (w < 1) w = 1;
-    if (w > 64) w = 64;  // all workgroups resident on an XCD (32 CUs x 2) share one partition
+    if (w > kProbeWgPerPart) w = kProbeWgPerPart;  // = the workgroups resident on one XCD (32 CUs x 2)
     a.wg_per_part = static_cast<int32_t>(w);
     ProfScope prof("join_probe");
     CRGPU_TRY(launch_probe<0>(jt, a, kRadixP1 * static_cast<int>(w)));
