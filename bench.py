@@ -11,8 +11,11 @@ reference's router hash (crgpu_dev_partition), exchanges the regions with one
 all-to-all per column and joins locally -- BASELINE.json configs[3] shape.
 
 Prints ONE JSON line (see the repo contract); `roofline` is for the dominant
-kernel (packed_probe_kernel), `cpu_baseline` times the oracle port on a bounded
-sample at N=1.
+kernel of the step (largest HIP-event time; on config J the radix probe kernel),
+`cpu_baseline` times the oracle port on a bounded sample at N=1.
+`roofline.traffic` comes from the committed rocprofv3 --pmc passes of this same
+command (profiles/r01/bench_J_radix_pmc_summary.txt, scripts/prof_pmc.sh): it is
+only reported for the default sizes those passes were taken at.
 """
 from __future__ import annotations
 
@@ -36,8 +39,8 @@ def parse():
     ap.add_argument("--log2-build", type=int, default=27)
     ap.add_argument("--log2-probe", type=int, default=29)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2-build", type=int, default=24)
-    ap.add_argument("--cpu-log2-probe", type=int, default=26)
+    ap.add_argument("--cpu-log2-build", type=int, default=25)
+    ap.add_argument("--cpu-log2-probe", type=int, default=27)
     return ap.parse_args()
 
 
@@ -68,6 +71,33 @@ def cpu_baseline(lb, lp):
     return {"value": (nb + npr) / dt, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"same workload at 2^{lb} build x 2^{lp} probe rows (oracle/crdb_oracle.c, 1 thread, "
                       f"1024-tuple batches), {dt:.1f} s"}
+
+
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_J_radix_pmc_summary.txt")
+KERNEL_SYMBOL = {"join_probe": "radix_probe_kernel<0, 0", "radix_build_split": "radix_split_kernel",
+                 "radix_build_table": "radix_table_kernel"}
+
+
+def pmc_traffic(prof_name, streamed_read_bytes):
+    """HBM bytes per launch of one kernel from the committed --pmc passes: WRITE_SIZE (KiB) is exact;
+    FETCH_SIZE (KiB) counts the wide coalesced input stream at half its size on gfx950
+    (MI355X_MICROARCH.md, HBM), so the missing half of that known stream is added back."""
+    sym = KERNEL_SYMBOL.get(prof_name)
+    if sym is None or not os.path.exists(PMC_SUMMARY):
+        return None
+    fetch = write = None
+    with open(PMC_SUMMARY) as f:
+        for line in f:
+            if not line.startswith("pmc,") or sym not in line:
+                continue
+            val = float(line.split("per_launch=")[1].split(",")[0])
+            if ",FETCH_SIZE," in line:
+                fetch = val
+            elif ",WRITE_SIZE," in line:
+                write = val
+    if fetch is None or write is None:
+        return None
+    return fetch * 1024.0 + streamed_read_bytes / 2.0 + write * 1024.0
 
 
 def main():
@@ -189,6 +219,9 @@ def main():
         dom_alg = bpr * rows_l
         avg_s = (dom_ms / max(dom_n, 1)) / 1e3
         achieved = dom_alg / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        if world == 1 and args.log2_build == 27 and args.log2_probe == 29:
+            traffic = pmc_traffic(dom, 16.0 * rows_l)  # the kernel's 16 B/row input stream
         line = {
             "metric": "rows/s hash join (build+probe rows per second)", "value": value, "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -200,7 +233,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"hash repartition all-to-all over {world} GPUs",
                        "result_check": "ok" if ok else "MISMATCH"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_s * 1e3, "launches": dom_n,
                          "algorithmic_bytes_per_launch": dom_alg},
             "kernels_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in kern.items()},
