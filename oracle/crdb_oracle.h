@@ -16,7 +16,7 @@
  *     in hashtable.go:512-625, hashtable_tmpl.go:584-731, hash_aggregator.go:288-352.
  *   - join / aggregation results: pinned by the literal case tables of
  *     hashjoiner_test.go:50-925, aggregators_test.go:186-785,
- *     hash_aggregator_test.go:34-397 (transcribed to tests/golden/*.json).
+ *     hash_aggregator_test.go:34-397 (transcribed to tests/golden/ JSON files).
  *   - memhash over byte strings / float hashing: the reference holds no literal
  *     vector => exact hash VALUES for bytes/floats are "parity unpinned"
  *     (pinned only through join/agg results and memhash(8B)==memhash64).

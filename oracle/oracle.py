@@ -88,15 +88,17 @@ def make_cols(vecs):
     return arr, vecs
 
 
-def _result_to_vecs(res):
+def _result_to_vecs(res, prefix="ora_result"):
     L = lib()
     if not res:
         return None
-    ncols, nrows = L.ora_result_ncols(res), L.ora_result_nrows(res)
+    f_ncols, f_nrows = getattr(L, prefix + "_ncols"), getattr(L, prefix + "_nrows")
+    f_col, f_free = getattr(L, prefix + "_col"), getattr(L, prefix + "_free")
+    ncols, nrows = f_ncols(res), f_nrows(res)
     out = []
     for i in range(ncols):
         c = OraCol()
-        L.ora_result_col(res, i, C.byref(c))
+        f_col(res, i, C.byref(c))
         valid = None
         if c.valid:
             valid = np.ctypeslib.as_array(C.cast(c.valid, C.POINTER(C.c_uint8)), shape=((nrows + 7) // 8,)).copy()
@@ -114,7 +116,7 @@ def _result_to_vecs(res):
             else:
                 data = np.zeros(0, dt)
             out.append(cd.Vec(c.type, data, valid))
-    L.ora_result_free(res)
+    f_free(res)
     return out
 
 
@@ -218,3 +220,153 @@ def last_agg_state(nkeys_hint=4096):
     nkeys = C.c_int64(0)
     lib().ora_test_last_agg_state(_ptr(first), C.addressof(nfirst), _ptr(nxt), C.addressof(nkeys))
     return dict(first=first[: nfirst.value].tolist(), next=nxt[: nkeys.value + 1].tolist())
+
+
+# ---------------------------------------------------------------------------
+# KV codec (oracle/crdb_kv.c): encoder + cFetcher-style decoder
+# ---------------------------------------------------------------------------
+class OraKvTable(C.Structure):
+    _fields_ = [("table_id", C.c_int32), ("index_id", C.c_int32), ("n_key_cols", C.c_int32), ("n_val_cols", C.c_int32),
+                ("key_types", C.c_void_p), ("key_dirs", C.c_void_p), ("val_col_ids", C.c_void_p), ("val_types", C.c_void_p)]
+
+
+class OraKvFetch(C.Structure):
+    _fields_ = [("key_prefix_len", C.c_int32), ("n_key_cols", C.c_int32), ("key_types", C.c_void_p),
+                ("key_dirs", C.c_void_p), ("key_out", C.c_void_p), ("n_val_cols", C.c_int32), ("n_out", C.c_int32),
+                ("val_col_ids", C.c_void_p), ("val_types", C.c_void_p), ("val_out", C.c_void_p)]
+
+
+def _i32arr(xs):
+    return np.ascontiguousarray(np.asarray(list(xs), dtype=np.int32))
+
+
+def _kv_setup():
+    L = lib()
+    if getattr(L, "_kv_ready", False):
+        return L
+    for name in ("ora_enc_uvarint_asc", "ora_enc_varint_asc", "ora_enc_varint_desc", "ora_enc_nonsorting_uvarint",
+                 "ora_enc_stdlib_varint"):
+        getattr(L, name).restype = C.c_int
+    L.ora_enc_uvarint_asc.argtypes = [C.c_void_p, C.c_uint64]
+    L.ora_enc_varint_asc.argtypes = [C.c_void_p, C.c_int64]
+    L.ora_enc_varint_desc.argtypes = [C.c_void_p, C.c_int64]
+    L.ora_enc_nonsorting_uvarint.argtypes = [C.c_void_p, C.c_uint64]
+    L.ora_enc_stdlib_varint.argtypes = [C.c_void_p, C.c_int64]
+    L.ora_enc_float_asc.restype = C.c_int
+    L.ora_enc_float_asc.argtypes = [C.c_void_p, C.c_double]
+    L.ora_enc_float_desc.restype = C.c_int
+    L.ora_enc_float_desc.argtypes = [C.c_void_p, C.c_double]
+    L.ora_enc_bytes_asc.restype = C.c_int64
+    L.ora_enc_bytes_asc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.ora_enc_bytes_desc.restype = C.c_int64
+    L.ora_enc_bytes_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    for name, outt in (("ora_dec_uvarint_asc", C.c_uint64), ("ora_dec_varint_asc", C.c_int64),
+                       ("ora_dec_varint_desc", C.c_int64), ("ora_dec_float_asc", C.c_double),
+                       ("ora_dec_float_desc", C.c_double), ("ora_dec_nonsorting_uvarint", C.c_uint64),
+                       ("ora_dec_stdlib_varint", C.c_int64)):
+        fn = getattr(L, name)
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_int64, C.POINTER(outt)]
+    L.ora_dec_bytes.restype = C.c_int64
+    L.ora_dec_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+    L.ora_kv_encode.restype = C.c_int
+    L.ora_kv_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.ora_kv_free.argtypes = [C.c_void_p]
+    L.ora_kv_decode.restype = C.c_int
+    L.ora_kv_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    L.ora_kv_result_ncols.restype = C.c_int32
+    L.ora_kv_result_ncols.argtypes = [C.c_void_p]
+    L.ora_kv_result_nrows.restype = C.c_int64
+    L.ora_kv_result_nrows.argtypes = [C.c_void_p]
+    L.ora_kv_result_col.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.ora_kv_result_free.argtypes = [C.c_void_p]
+    L._kv_ready = True
+    return L
+
+
+def kv_enc(kind: str, value) -> bytes:
+    """One primitive encoding: kind in uvarint_asc, varint_asc, varint_desc, float_asc, float_desc,
+    bytes_asc, bytes_desc, nonsorting_uvarint, stdlib_varint."""
+    L = _kv_setup()
+    if kind.startswith("bytes"):
+        data = bytes(value)
+        buf = C.create_string_buffer(2 * len(data) + 8)
+        src = C.create_string_buffer(data, max(len(data), 1))
+        n = getattr(L, "ora_enc_" + kind)(buf, src, len(data))
+    else:
+        buf = C.create_string_buffer(16)
+        n = getattr(L, "ora_enc_" + kind)(buf, value)
+    return buf.raw[:n]
+
+
+def kv_dec(kind: str, data: bytes):
+    """Inverse of kv_enc: returns (value, bytes consumed)."""
+    L = _kv_setup()
+    src = C.create_string_buffer(bytes(data), max(len(data), 1))
+    if kind.startswith("bytes"):
+        out = C.create_string_buffer(len(data) + 1)
+        outlen = C.c_int64()
+        n = L.ora_dec_bytes(src, len(data), 1 if kind.endswith("desc") else 0, out, C.byref(outlen))
+        return (out.raw[:outlen.value] if n >= 0 else None), n
+    ctype = {"uvarint_asc": C.c_uint64, "nonsorting_uvarint": C.c_uint64, "float_asc": C.c_double,
+             "float_desc": C.c_double}.get(kind, C.c_int64)
+    v = ctype()
+    n = getattr(L, "ora_dec_" + kind)(src, len(data), C.byref(v))
+    return (v.value if n >= 0 else None), n
+
+
+class KvTable:
+    """The encoder's table: key columns (type, direction) and value columns (id, type), one family."""
+
+    def __init__(self, table_id, index_id, key_types, key_dirs, val_col_ids, val_types):
+        self.table_id, self.index_id = table_id, index_id
+        self.key_types, self.key_dirs = list(key_types), list(key_dirs)
+        self.val_col_ids, self.val_types = list(val_col_ids), list(val_types)
+
+    def prefix_len(self):
+        return len(kv_enc("uvarint_asc", self.table_id)) + len(kv_enc("uvarint_asc", self.index_id))
+
+
+def kv_encode(table: KvTable, key_vecs, val_vecs, max_batch_bytes=10 << 20, explicit_null_every=0):
+    """Rows -> (uint8 array of concatenated MVCCScan batch responses, int64 batch offsets[nbatches+1])."""
+    L = _kv_setup()
+    n = len(key_vecs[0]) if key_vecs else len(val_vecs[0])
+    keep = [_i32arr(table.key_types), _i32arr(table.key_dirs), _i32arr(table.val_col_ids), _i32arr(table.val_types)]
+    t = OraKvTable(table.table_id, table.index_id, len(table.key_types), len(table.val_types),
+                   keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data)
+    kc, _k1 = make_cols(key_vecs)
+    vc, _k2 = make_cols(val_vecs)
+    out, out_len, offs, nb = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    rc = L.ora_kv_encode(C.byref(t), kc, vc, n, max_batch_bytes, explicit_null_every, C.byref(out), C.byref(out_len),
+                         C.byref(offs), C.byref(nb))
+    assert rc == 0
+    data = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(out_len.value, 1),))[:out_len.value].copy()
+    offsets = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_int64)), shape=(nb.value + 1,)).copy()
+    L.ora_kv_free(out)
+    L.ora_kv_free(offs)
+    return data, offsets
+
+
+class KvDecodeError(Exception):
+    def __init__(self, code):
+        super().__init__(f"oracle kv decode error {code}")
+        self.code = code
+
+
+def kv_decode(key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_types, val_out, out_types, data, offsets):
+    """cFetcher-style decode of batch responses -> list[Vec] (one per output ordinal)."""
+    L = _kv_setup()
+    keep = [_i32arr(key_types), _i32arr(key_dirs), _i32arr(key_out), _i32arr(val_col_ids), _i32arr(val_types),
+            _i32arr(val_out), _i32arr(out_types)]
+    f = OraKvFetch(key_prefix_len, len(key_types), keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data,
+                   len(val_col_ids), len(out_types), keep[3].ctypes.data, keep[4].ctypes.data, keep[5].ctypes.data)
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    res = C.c_void_p()
+    rc = L.ora_kv_decode(C.byref(f), keep[6].ctypes.data, data.ctypes.data if data.size else None, offsets.ctypes.data,
+                         len(offsets) - 1, C.byref(res))
+    if rc != 0:
+        L.ora_kv_result_free(res)
+        raise KvDecodeError(rc)
+    return _result_to_vecs(res, prefix="ora_kv_result")

@@ -233,3 +233,57 @@ def prepare_agg_case(c):
             row.append(v)
         expected.append(tuple(row))
     return cols, list(c["group_cols"]), aggs, expected
+
+
+# ---------------------------------------------------------------------------
+# KV fetch-decode cases
+# ---------------------------------------------------------------------------
+def kv_random_rows(rng, n, key_types, val_types, null_frac=0.15):
+    """Random key / value columns of the given type ids (NULLs in both)."""
+    def col(t, allow_null=True):
+        pres = rng.random(n) >= (null_frac if allow_null else 0.0)
+        if t == cd.BOOL:
+            return cd.Vec.from_numpy(cd.BOOL, rng.integers(0, 2, n).astype(np.uint8), pres)
+        if t in (cd.INT16, cd.INT32, cd.INT64):
+            bits = {cd.INT16: 15, cd.INT32: 31, cd.INT64: 63}[t]
+            mag = rng.integers(0, bits + 1, n)  # spread over every encoded length
+            v = (rng.integers(0, 2**62, n, dtype=np.int64) >> (62 - np.minimum(mag, 62))) * rng.choice([-1, 1], n)
+            if t == cd.INT64:
+                v[: min(n, 4)] = np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).max, 0, -1])[: min(n, 4)]
+            return cd.Vec.from_numpy(t, v.astype(cd.NP_DTYPE[t]), pres)
+        if t == cd.FLOAT64:
+            v = rng.standard_normal(n) * 10.0 ** rng.integers(-5, 6, n)
+            sp = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 5e-324, -1.7976931348623157e308])
+            v[: min(n, len(sp))] = sp[: min(n, len(sp))]
+            return cd.Vec.from_numpy(cd.FLOAT64, v, pres)
+        words = [b"", b"a", b"\x00", b"a\x00b", b"\xff\x00\xff", b"hello world", b"x" * 40, bytes(range(256))]
+        vals = [None if not pres[i] else words[rng.integers(len(words))] + (b"%d" % i if i % 3 else b"") for i in range(n)]
+        return cd.Vec.from_values(cd.BYTES, vals)
+    return [col(t) for t in key_types], [col(t) for t in val_types]
+
+
+def assert_vecs_equal(got, want, msg=""):
+    """Bit-exact column comparison (NULL slots compare by validity only)."""
+    assert len(got) == len(want), f"{msg}: {len(got)} columns != {len(want)}"
+    for c, (g, w) in enumerate(zip(got, want)):
+        assert g.type == w.type and len(g) == len(w), f"{msg}: column {c} type/len {g.type}/{len(g)} vs {w.type}/{len(w)}"
+        gp, wp = g.present(), w.present()
+        assert np.array_equal(gp, wp), f"{msg}: column {c} validity differs at rows {np.nonzero(gp != wp)[0][:10]}"
+        if g.type == cd.BYTES:
+            assert np.array_equal(g.offsets, w.offsets), f"{msg}: column {c} offsets differ"
+            assert np.array_equal(g.data, w.data), f"{msg}: column {c} bytes differ"
+        else:
+            gv = g.data.view(np.uint8).reshape(len(g), -1)[gp]
+            wv = w.data.view(np.uint8).reshape(len(w), -1)[wp]
+            assert np.array_equal(gv, wv), f"{msg}: column {c} values differ"
+
+
+def kv_key_canonical(vec):
+    """What a key-encoded column decodes to: float keys lose the sign of zero and the NaN payload
+    (float.go:36-39 "encodes both positive and negative zero the same")."""
+    if vec.type != cd.FLOAT64:
+        return vec
+    d = vec.data.copy()
+    d[d == 0] = 0.0
+    d[np.isnan(d)] = np.nan
+    return cd.Vec(cd.FLOAT64, d, vec.valid)
