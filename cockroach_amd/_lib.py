@@ -48,6 +48,13 @@ class AggSpec(C.Structure):  # crgpu_agg_spec
                 ("aggs", C.POINTER(AggDesc))]
 
 
+class FetchSpec(C.Structure):  # crgpu_fetch_spec
+    _fields_ = [("key_prefix_len", C.c_int32), ("n_key_cols", C.c_int32), ("key_types", C.POINTER(C.c_int32)),
+                ("key_dirs", C.POINTER(C.c_int32)), ("key_out", C.POINTER(C.c_int32)), ("n_val_cols", C.c_int32),
+                ("n_out_cols", C.c_int32), ("val_col_ids", C.POINTER(C.c_int32)), ("val_types", C.POINTER(C.c_int32)),
+                ("val_out", C.POINTER(C.c_int32)), ("out_types", C.POINTER(C.c_int32))]
+
+
 class Col(C.Structure):  # crgpu_col (host, coldata layout)
     _fields_ = [("type", C.c_int32), ("maybe_has_nulls", C.c_int32), ("data", C.c_void_p), ("nulls", C.c_void_p),
                 ("bytes_buf", C.c_void_p), ("bytes_buf_len", C.c_int64)]
@@ -98,6 +105,9 @@ SYMBOLS = [
     ("crgpu_dev_partitioner_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(_VP)]),
     ("crgpu_dev_partition", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult), C.POINTER(_I64)]),
     ("crgpu_dev_partitioner_destroy", None, [_VP]),
+    ("crgpu_dev_decoder_create", _I32, [C.POINTER(FetchSpec), C.POINTER(_VP)]),
+    ("crgpu_dev_decode_kv", _I32, [_VP, _VP, C.POINTER(_I64), _I64, C.POINTER(DevResult)]),
+    ("crgpu_dev_decoder_destroy", None, [_VP]),
     ("crgpu_hash_cols", _I32, [C.POINTER(Col), _I32, _I64, _VP, _U64, _I32, _U64, _VP]),
     ("crgpu_hj_new", _I32, [C.POINTER(JoinSpec), C.POINTER(_VP)]),
     ("crgpu_hj_build_append", _I32, [_VP, C.POINTER(Batch)]),

@@ -1,0 +1,651 @@
+// kv.hip -- KV -> column fetch decode on the device.
+//
+// Replaces colfetcher.cFetcher.NextBatch for indexes with one KV per row
+// (MaxKeysPerRow == 1, pkg/sql/colfetcher/cfetcher.go:758-1093, fast path :937-941):
+// MVCCScan batch framing (pkg/storage/enginepb/decode.go:77-128), DecodeKeyValsToCols /
+// decodeTableKeyToCol (pkg/sql/colencoding/key_encoding.go:43-218), processValueBytes
+// (cfetcher.go:1313-1399), DecodeTableValueToCol (colencoding/value_encoding.go:24-116),
+// fillNulls (cfetcher.go:1401-1427) and the primitive codecs of pkg/util/encoding
+// (encoding.go:374-403,569-591,788-824,2617-2673,3032-3060,3420-3486; float.go:61-98).
+//
+// Record boundaries form a dependent chain inside one batch response (each record's
+// length is in its own header), so one wavefront walks each batch through an LDS window;
+// batches (<= 10 MiB each in production, rowinfra/base.go:53) are walked concurrently.
+// Everything after that is row-parallel: one lane per KV, byte-serial parsing of ~170 B
+// that neighbouring lanes share cache lines of.  BYTES outputs take two passes
+// (lengths -> scan -> copy).  Bound: HBM stream of the input bytes (read three times:
+// two walks + decode) plus the decoded columns.
+#include <cstring>
+
+#include "device.h"
+
+namespace crgpu {
+
+static constexpr int kMaxKeyFetch = 8, kMaxValFetch = 32, kMaxOutFetch = 32;
+static constexpr int kWalkWindow = 8192;
+
+struct FetchSpec {
+  int32_t key_prefix_len, n_key, n_val, n_out;
+  int32_t key_types[kMaxKeyFetch], key_dirs[kMaxKeyFetch], key_out[kMaxKeyFetch];
+  int32_t val_ids[kMaxValFetch], val_types[kMaxValFetch], val_out[kMaxValFetch];
+  int32_t out_types[kMaxOutFetch];
+};
+struct FetchOut {
+  void *data[kMaxOutFetch];        // fixed-width values, or the BYTES payload buffer (pass 1)
+  uint8_t *valid[kMaxOutFetch];    // one byte per row
+  uint32_t *lens[kMaxOutFetch];    // BYTES: decoded length per row (pass 0)
+  const uint32_t *offs[kMaxOutFetch];  // BYTES: offsets (pass 1)
+};
+
+enum : int32_t { KV_OK = 0, KV_TRUNCATED = 1, KV_BAD_MVCC_KEY = 2, KV_BAD_KEY = 3, KV_NOT_TUPLE = 4, KV_BAD_VALUE = 5 };
+struct KvError {
+  unsigned long long first_row;  // smallest failing row (atomicMin)
+  int32_t code;
+  int32_t _pad;
+};
+
+// ------------------------------------------------------------------ primitive decoders (device)
+__device__ __forceinline__ int dec_uvarint_asc(const uint8_t *b, int64_t len, uint64_t *out) {  // encoding.go:569-591
+  if (len <= 0) return -1;
+  int length = static_cast<int>(b[0]) - 136;
+  if (length <= 109) {
+    *out = static_cast<uint64_t>(static_cast<int64_t>(length));
+    return length < 0 ? -1 : 1;
+  }
+  length -= 109;
+  if (length < 0 || length > 8 || len - 1 < length) return -1;
+  uint64_t v = 0;
+  for (int i = 0; i < length; i++) v = (v << 8) | b[1 + i];
+  *out = v;
+  return 1 + length;
+}
+__device__ __forceinline__ int dec_varint_asc(const uint8_t *b, int64_t len, int64_t *out) {  // encoding.go:374-403
+  if (len <= 0) return -1;
+  int length = static_cast<int>(b[0]) - 136;
+  if (length < 0) {
+    length = -length;
+    if (len - 1 < length) return -1;
+    uint64_t v = 0;
+    for (int i = 0; i < length; i++) v = (v << 8) | static_cast<uint8_t>(~b[1 + i]);
+    *out = static_cast<int64_t>(~v);
+    return 1 + length;
+  }
+  uint64_t u;
+  const int n = dec_uvarint_asc(b, len, &u);
+  if (n < 0 || u > 0x7FFFFFFFFFFFFFFFull) return -1;
+  *out = static_cast<int64_t>(u);
+  return n;
+}
+__device__ __forceinline__ uint64_t get_be64(const uint8_t *b) {
+  uint64_t u = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) u = (u << 8) | b[i];
+  return u;
+}
+__device__ __forceinline__ int dec_float_key(const uint8_t *b, int64_t len, bool desc, double *out) {  // float.go:61-98
+  if (len <= 0) return -1;
+  int n;
+  double r;
+  switch (b[0]) {
+    case 0x02: case 0x06: r = __longlong_as_double(0x7FF8000000000000ll); n = 1; break;
+    case 0x04: r = 0; n = 1; break;
+    case 0x03: if (len < 9) return -1; r = __longlong_as_double(static_cast<long long>(~get_be64(b + 1))); n = 9; break;
+    case 0x05: if (len < 9) return -1; r = __longlong_as_double(static_cast<long long>(get_be64(b + 1))); n = 9; break;
+    default: return -1;
+  }
+  if (desc && r != 0 && r == r) r = -r;
+  *out = r;
+  return n;
+}
+// decodeBytesInternal (encoding.go:788-824) / DecodeBytesDescending (:776-782); out may be null
+__device__ __forceinline__ int64_t dec_bytes_key(const uint8_t *b, int64_t len, bool desc, uint8_t *out, uint32_t *outlen) {
+  const uint8_t marker = desc ? 0x13 : 0x12, esc = desc ? 0xff : 0x00, term = desc ? 0xfe : 0x01, e00 = desc ? 0x00 : 0xff;
+  if (len <= 0 || b[0] != marker) return -1;
+  int64_t i = 1;
+  uint32_t o = 0;
+  for (;;) {
+    if (i >= len) return -1;
+    const uint8_t c = b[i];
+    if (c != esc) {
+      if (out) out[o] = desc ? static_cast<uint8_t>(~c) : c;
+      o++, i++;
+      continue;
+    }
+    if (i + 1 >= len) return -1;
+    const uint8_t v = b[i + 1];
+    if (v == term) {
+      *outlen = o;
+      return i + 2;
+    }
+    if (v != e00) return -1;
+    if (out) out[o] = 0x00;
+    o++, i += 2;
+  }
+}
+__device__ __forceinline__ int dec_nonsorting_uvarint(const uint8_t *b, int64_t len, uint64_t *out) {  // :2663-2673
+  uint64_t v = 0;
+  for (int64_t i = 0; i < len; i++) {
+    v += static_cast<uint64_t>(b[i] & 0x7f);
+    if (b[i] < 0x80) {
+      *out = v;
+      return static_cast<int>(i + 1);
+    }
+    v <<= 7;
+  }
+  return -1;
+}
+__device__ __forceinline__ int dec_stdlib_varint(const uint8_t *b, int64_t len, int64_t *out) {  // binary.Varint (:2617)
+  uint64_t ux = 0;
+  int s = 0;
+  for (int64_t i = 0; i < len && i < 10; i++) {
+    if (b[i] < 0x80) {
+      if (i == 9 && b[i] > 1) return -1;
+      ux |= static_cast<uint64_t>(b[i]) << s;
+      int64_t x = static_cast<int64_t>(ux >> 1);
+      if (ux & 1) x = ~x;
+      *out = x;
+      return static_cast<int>(i + 1);
+    }
+    ux |= static_cast<uint64_t>(b[i] & 0x7f) << s;
+    s += 7;
+  }
+  return -1;
+}
+__device__ __forceinline__ int dec_value_tag(const uint8_t *b, int64_t len, uint32_t *delta, int *typ) {  // :3032-3060
+  uint64_t tag;
+  int n = dec_nonsorting_uvarint(b, len, &tag);
+  if (n < 0) return -1;
+  *delta = static_cast<uint32_t>(tag >> 4);
+  *typ = static_cast<int>(tag & 0xf);
+  if (*typ == 15) {
+    uint64_t t2;
+    const int n2 = dec_nonsorting_uvarint(b + n, len - n, &t2);
+    if (n2 < 0) return -1;
+    *typ = static_cast<int>(t2);
+    n += n2;
+  }
+  return n;
+}
+// PeekValueLengthWithOffsetsAndType (:3420-3486) for the value types a table row can carry
+__device__ __forceinline__ int64_t peek_value_len(const uint8_t *b, int64_t len, int data_off, int typ) {
+  const uint8_t *d = b + data_off;
+  const int64_t rem = len - data_off;
+  uint64_t u;
+  int64_t s;
+  int n;
+  switch (typ) {
+    case 1: case 10: case 11: return data_off;                       // Null, True, False
+    case 3: n = dec_stdlib_varint(d, rem, &s); return n < 0 ? -1 : data_off + n;  // Int
+    case 4: return data_off + 8;                                      // Float
+    case 6: case 13: n = dec_nonsorting_uvarint(d, rem, &u); return n < 0 ? -1 : data_off + n + static_cast<int64_t>(u);
+    case 5: {                                                         // Decimal: binary.Uvarint length + bytes
+      uint64_t x = 0;
+      int sh = 0, i = 0;
+      for (; i < rem && i < 10; i++) {
+        x |= static_cast<uint64_t>(d[i] & 0x7f) << sh;
+        sh += 7;
+        if (d[i] < 0x80) break;
+      }
+      if (i >= rem || i >= 10) return -1;
+      return data_off + i + 1 + static_cast<int64_t>(x);
+    }
+    case 8: case 9: {                                                 // Time (2 varints), Duration (3)
+      int tot = 0;
+      for (int k = 0; k < (typ == 8 ? 2 : 3); k++) {
+        n = dec_stdlib_varint(d + tot, rem - tot, &s);
+        if (n < 0) return -1;
+        tot += n;
+      }
+      return data_off + tot;
+    }
+    case 12: return data_off + 16;                                    // UUID
+    default: return -1;
+  }
+}
+
+// ------------------------------------------------------------------ record boundaries
+// One wavefront per batch response.  The batch is pulled through an 8 KiB LDS window with
+// coalesced 16-byte loads; lane 0 follows the chain of {valLen u32, keyLen u32} headers inside it.
+template <bool WRITE>
+__global__ __launch_bounds__(64) void kv_walk_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ batch_offs,
+                                                     const int64_t *__restrict__ row_base, int64_t *__restrict__ counts,
+                                                     int64_t *__restrict__ rec_off, KvError *__restrict__ err) {
+  __shared__ __align__(16) uint8_t win[kWalkWindow + 16];
+  __shared__ int64_t s_pos;
+  __shared__ int s_stop;
+  const int b = blockIdx.x;
+  const int64_t lo = batch_offs[b], hi = batch_offs[b + 1];
+  int64_t pos = lo, nrec = 0;
+  const int64_t out_base = WRITE ? row_base[b] : 0;
+  while (pos < hi) {
+    // window starts at the 16-byte aligned address at or below pos
+    const int64_t wbase = pos & ~int64_t(15);
+    for (int i = threadIdx.x * 16; i < kWalkWindow; i += 64 * 16) {
+      const int64_t g = wbase + i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g + 16 <= hi) {
+        v = *reinterpret_cast<const uint4 *>(repr + g);
+      } else if (g < hi) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; k++)
+          if (g + k < hi) w[k >> 2] |= static_cast<uint32_t>(repr[g + k]) << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      *reinterpret_cast<uint4 *>(win + i) = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int stop = 0;
+      const int64_t wend = wbase + kWalkWindow < hi ? wbase + kWalkWindow : hi;
+      while (pos < hi) {
+        if (pos + 8 > wend) {
+          if (pos + 8 > hi) stop = KV_TRUNCATED;  // "unexpected batch EOF" (decode.go:109-111)
+          break;                                   // otherwise: header not in this window, reload
+        }
+        const uint8_t *h = win + (pos - wbase);
+        const uint32_t vl = h[0] | (h[1] << 8) | (h[2] << 16) | (static_cast<uint32_t>(h[3]) << 24);
+        const uint32_t kl = h[4] | (h[5] << 8) | (h[6] << 16) | (static_cast<uint32_t>(h[7]) << 24);
+        const int64_t next = pos + 8 + static_cast<int64_t>(kl) + vl;
+        if (next > hi) {
+          stop = KV_TRUNCATED;
+          break;
+        }
+        if (WRITE) rec_off[out_base + nrec] = pos;
+        nrec++;
+        pos = next;
+      }
+      s_pos = pos;
+      s_stop = stop;
+    }
+    __syncthreads();
+    pos = s_pos;
+    if (s_stop) {
+      if (threadIdx.x == 0) {
+        atomicMin(&err->first_row, static_cast<unsigned long long>(b));
+        err->code = s_stop;
+      }
+      break;
+    }
+    __syncthreads();
+  }
+  if (!WRITE && threadIdx.x == 0) counts[b] = nrec;
+}
+
+// ------------------------------------------------------------------ row decode
+__device__ __forceinline__ void put_fixed(void *dst, int type, int64_t row, int64_t iv, double fv) {
+  switch (type) {
+    case CRGPU_BOOL: static_cast<uint8_t *>(dst)[row] = iv != 0; break;
+    case CRGPU_INT16: static_cast<int16_t *>(dst)[row] = static_cast<int16_t>(iv); break;
+    case CRGPU_INT32: static_cast<int32_t *>(dst)[row] = static_cast<int32_t>(iv); break;
+    case CRGPU_INT64: static_cast<int64_t *>(dst)[row] = iv; break;
+    default: static_cast<double *>(dst)[row] = fv; break;
+  }
+}
+
+// PASS 0: fixed-width values, validity bytes, BYTES lengths.  PASS 1: BYTES payloads.
+template <int PASS>
+__global__ __launch_bounds__(256) void kv_decode_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ rec_off,
+                                                        int64_t n, FetchSpec f, FetchOut o, KvError *__restrict__ err) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+    const uint8_t *p = repr + rec_off[row];
+    const uint32_t vl = p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
+    const uint32_t kl = p[4] | (p[5] << 8) | (p[6] << 16) | (static_cast<uint32_t>(p[7]) << 24);
+    const uint8_t *mk = p + 8, *val = p + 8 + kl;
+    int code = KV_OK;
+    uint32_t seen = 0;
+    // SplitMVCCKey (decode.go:26-49)
+    const int ts_len = kl ? mk[kl - 1] : 1;
+    const int64_t key_end = static_cast<int64_t>(kl) - 1 - ts_len;
+    if (kl == 0 || ts_len == 1 || key_end < 0) code = KV_BAD_MVCC_KEY;
+    const uint8_t *key = mk + f.key_prefix_len;
+    int64_t klen = key_end - f.key_prefix_len;
+    if (code == KV_OK && klen < 0) code = KV_BAD_KEY;
+    // DecodeKeyValsToCols (key_encoding.go:43-81)
+    for (int c = 0; c < f.n_key && code == KV_OK; c++) {
+      const bool desc = f.key_dirs[c] != 0;
+      const int oc = f.key_out[c];
+      if (klen <= 0) {
+        code = KV_BAD_KEY;
+        break;
+      }
+      if (key[0] == (desc ? 0xff : 0x00)) {  // NULL (DecodeIfNull, :101-104)
+        if (oc >= 0) {
+          seen |= 1u << oc;
+          if (PASS == 0) {
+            o.valid[oc][row] = 0;
+            if (f.out_types[oc] == CRGPU_BYTES) o.lens[oc][row] = 0;
+            else put_fixed(o.data[oc], f.out_types[oc], row, 0, 0);
+          }
+        }
+        key++, klen--;
+        continue;
+      }
+      int64_t used;
+      if (f.key_types[c] == CRGPU_FLOAT64) {
+        double d;
+        used = dec_float_key(key, klen, desc, &d);
+        if (used >= 0 && oc >= 0 && PASS == 0) put_fixed(o.data[oc], CRGPU_FLOAT64, row, 0, d);
+      } else if (f.key_types[c] == CRGPU_BYTES) {
+        uint32_t dl = 0;
+        uint8_t *dst = (PASS == 1 && oc >= 0) ? static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row] : nullptr;
+        used = dec_bytes_key(key, klen, desc, dst, &dl);
+        if (used >= 0 && oc >= 0 && PASS == 0) o.lens[oc][row] = dl;
+      } else {
+        int64_t v;
+        used = dec_varint_asc(key, klen, &v);
+        if (desc) v = ~v;  // DecodeVarintDescending (:407-410)
+        if (used >= 0 && oc >= 0 && PASS == 0) put_fixed(o.data[oc], f.out_types[oc], row, v, 0);
+      }
+      if (used < 0) {
+        code = KV_BAD_KEY;
+        break;
+      }
+      if (oc >= 0) {
+        seen |= 1u << oc;
+        if (PASS == 0) o.valid[oc][row] = 1;
+      }
+      key += used, klen -= used;
+    }
+    // processValue (cfetcher.go:1167-1190): RawBytes = checksum[4] tag[1] payload
+    if (code == KV_OK && f.n_val > 0 && vl != 0) {
+      if (vl < 5 || val[4] != 10) {
+        code = KV_NOT_TUPLE;
+      } else {
+        const uint8_t *vb = val + 5;
+        int64_t vrem = static_cast<int64_t>(vl) - 5;
+        int32_t last_id = 0;
+        int idx = 0, remaining = f.n_val;
+        while (vrem > 0 && remaining > 0) {  // processValueBytes (:1342-1394)
+          uint32_t delta;
+          int typ;
+          const int doff = dec_value_tag(vb, vrem, &delta, &typ);
+          if (doff < 0) {
+            code = KV_BAD_VALUE;
+            break;
+          }
+          const int32_t id = last_id + static_cast<int32_t>(delta);
+          last_id = id;
+          int vec = -1;
+          for (; idx < f.n_val; idx++) {
+            if (f.val_ids[idx] == id) {
+              vec = idx++;
+              break;
+            }
+            if (f.val_ids[idx] > id) break;
+          }
+          if (vec < 0) {  // not requested: skip by its encoded length (:1365-1373)
+            const int64_t l = peek_value_len(vb, vrem, doff, typ);
+            if (l < 0 || l > vrem) {
+              code = KV_BAD_VALUE;
+              break;
+            }
+            vb += l, vrem -= l;
+            continue;
+          }
+          const int oc = f.val_out[vec];
+          const int vt = f.val_types[vec];
+          seen |= 1u << oc;
+          remaining--;
+          if (typ == 1) {  // Null (value_encoding.go:35-38)
+            if (PASS == 0) {
+              o.valid[oc][row] = 0;
+              if (vt == CRGPU_BYTES) o.lens[oc][row] = 0;
+              else put_fixed(o.data[oc], vt, row, 0, 0);
+            }
+            vb += doff, vrem -= doff;
+            continue;
+          }
+          const uint8_t *d = vb + doff;
+          const int64_t drem = vrem - doff;
+          int64_t used = 0;
+          if (vt == CRGPU_BOOL) {
+            if (typ != 10 && typ != 11) code = KV_BAD_VALUE;
+            else if (PASS == 0) put_fixed(o.data[oc], vt, row, typ == 10, 0);
+          } else if (vt == CRGPU_FLOAT64) {
+            if (drem < 8) code = KV_BAD_VALUE;
+            else {
+              if (PASS == 0) put_fixed(o.data[oc], vt, row, 0, __longlong_as_double(static_cast<long long>(get_be64(d))));
+              used = 8;
+            }
+          } else if (vt == CRGPU_BYTES) {
+            uint64_t l;
+            const int nn = dec_nonsorting_uvarint(d, drem, &l);
+            if (nn < 0 || static_cast<int64_t>(l) > drem - nn) code = KV_BAD_VALUE;
+            else {
+              if (PASS == 0) o.lens[oc][row] = static_cast<uint32_t>(l);
+              else {
+                uint8_t *dst = static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row];
+                for (uint64_t t = 0; t < l; t++) dst[t] = d[nn + t];
+              }
+              used = nn + static_cast<int64_t>(l);
+            }
+          } else {
+            int64_t v;
+            const int nn = dec_stdlib_varint(d, drem, &v);
+            if (nn < 0) code = KV_BAD_VALUE;
+            else {
+              if (PASS == 0) put_fixed(o.data[oc], vt, row, v, 0);
+              used = nn;
+            }
+          }
+          if (code != KV_OK) break;
+          if (PASS == 0) o.valid[oc][row] = 1;
+          vb += doff + used, vrem -= doff + used;
+        }
+      }
+    }
+    if (PASS == 0) {
+      // fillNulls (cfetcher.go:1401-1427); a failed row is zero-filled so that later passes stay in bounds
+      for (int c = 0; c < f.n_out; c++) {
+        if (code != KV_OK || !(seen & (1u << c))) {
+          o.valid[c][row] = 0;
+          if (f.out_types[c] == CRGPU_BYTES) o.lens[c][row] = 0;
+          else put_fixed(o.data[c], f.out_types[c], row, 0, 0);
+        }
+      }
+      if (code != KV_OK) {
+        const unsigned long long old = atomicMin(&err->first_row, static_cast<unsigned long long>(row));
+        if (static_cast<unsigned long long>(row) <= old) err->code = code;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kv_narrow_offsets_kernel(const uint64_t *__restrict__ in, int64_t n,
+                                                                uint32_t *__restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = static_cast<uint32_t>(in[i]);
+}
+
+static inline int kv_grid(int64_t n, int block) {
+  int64_t want = (n + block - 1) / block, cap = static_cast<int64_t>(num_cus()) * 16;
+  if (want < 1) want = 1;
+  return static_cast<int>(want < cap ? want : cap);
+}
+
+}  // namespace crgpu
+
+using namespace crgpu;
+
+struct crgpu_decoder {
+  FetchSpec spec;
+  DevBuf batch_offs, row_base, counts, rec_off, err, scratch, offs64;
+  std::vector<OutCol> out;
+  std::vector<DevBuf> valid_bytes, lens;
+  std::vector<crgpu_dcol> views;
+};
+
+extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgpu_decoder **out) {
+  CRGPU_TRY(ensure_init());
+  if (s == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decoder_create: null argument");
+  if (s->n_key_cols < 0 || s->n_key_cols > kMaxKeyFetch || s->n_val_cols < 0 || s->n_val_cols > kMaxValFetch ||
+      s->n_out_cols < 0 || s->n_out_cols > kMaxOutFetch || s->key_prefix_len < 0)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decoder_create: at most 8 key columns, 32 value columns, 32 outputs");
+  auto d = new crgpu_decoder();
+  FetchSpec &f = d->spec;
+  std::memset(&f, 0, sizeof(f));
+  f.key_prefix_len = s->key_prefix_len;
+  f.n_key = s->n_key_cols;
+  f.n_val = s->n_val_cols;
+  f.n_out = s->n_out_cols;
+  auto bad = [&](const char *msg) {
+    delete d;
+    return fail(CRGPU_ERR_INVALID, msg);
+  };
+  for (int c = 0; c < f.n_out; c++) {
+    f.out_types[c] = s->out_types[c];
+    if (!valid_type(f.out_types[c])) return bad("crgpu_dev_decoder_create: unsupported output column type");
+  }
+  uint32_t used = 0;
+  for (int c = 0; c < f.n_key; c++) {
+    f.key_types[c] = s->key_types[c];
+    f.key_dirs[c] = s->key_dirs[c];
+    f.key_out[c] = s->key_out[c];
+    if (!valid_type(f.key_types[c])) return bad("crgpu_dev_decoder_create: unsupported key column type");
+    if (f.key_dirs[c] != 0 && f.key_dirs[c] != 1) return bad("crgpu_dev_decoder_create: invalid direction");  // key_encoding.go:97-99
+    if (f.key_out[c] >= f.n_out) return bad("crgpu_dev_decoder_create: key output ordinal out of range");
+    if (f.key_out[c] >= 0) {
+      if (f.out_types[f.key_out[c]] != f.key_types[c] || (used >> f.key_out[c]) & 1) return bad("crgpu_dev_decoder_create: key output type mismatch or duplicate output");
+      used |= 1u << f.key_out[c];
+    }
+  }
+  for (int c = 0; c < f.n_val; c++) {
+    f.val_ids[c] = s->val_col_ids[c];
+    f.val_types[c] = s->val_types[c];
+    f.val_out[c] = s->val_out[c];
+    if (c > 0 && f.val_ids[c] <= f.val_ids[c - 1]) return bad("crgpu_dev_decoder_create: value column ids must increase");
+    if (f.val_out[c] < 0 || f.val_out[c] >= f.n_out || f.out_types[f.val_out[c]] != f.val_types[c] || (used >> f.val_out[c]) & 1)
+      return bad("crgpu_dev_decoder_create: value output ordinal out of range, type mismatch or duplicate output");
+    used |= 1u << f.val_out[c];
+  }
+  if (f.n_out < 32 && used != (1u << f.n_out) - 1) return bad("crgpu_dev_decoder_create: an output column has no source");
+  d->out = std::vector<OutCol>(f.n_out);
+  d->valid_bytes = std::vector<DevBuf>(f.n_out);
+  d->lens = std::vector<DevBuf>(f.n_out);
+  d->views.resize(f.n_out);
+  *out = d;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_dev_decoder_destroy(crgpu_decoder *d) {
+  if (d == nullptr) return;
+  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
+  delete d;
+}
+
+static crgpu_status kv_check_error(crgpu_decoder *d, const char *phase) {
+  KvError e;
+  CRGPU_HIP(hipMemcpyAsync(&e, d->err.p, sizeof(e), hipMemcpyDeviceToHost, stream()));
+  CRGPU_HIP(hipStreamSynchronize(stream()));
+  if (e.first_row == ~0ull) return CRGPU_OK;
+  static const char *names[] = {"", "truncated batch response", "invalid MVCC key", "key column decode error",
+                                "value is not a TUPLE", "value column decode error"};
+  return fail(CRGPU_ERR_INVALID, std::string("crgpu_dev_decode_kv: ") + names[e.code >= 1 && e.code <= 5 ? e.code : 0] +
+                                     " (" + phase + " " + std::to_string(e.first_row) + ")");
+}
+
+extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
+                                            int64_t n_batches, crgpu_dev_result *res) {
+  if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: null argument");
+  if (n_batches < 0 || (n_batches > 0 && (batch_offsets_host == nullptr || repr_dev == nullptr)))
+    return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: null batches");
+  if (n_batches > 0x7FFFFFFF) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: too many batches");
+  for (int64_t b = 0; b < n_batches; b++)
+    if (batch_offsets_host[b + 1] < batch_offsets_host[b]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: batch offsets must not decrease");
+  if ((reinterpret_cast<uintptr_t>(repr_dev) & 15u) != 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: the batch buffer must be 16-byte aligned");
+  hipStream_t st = stream();
+  const FetchSpec &f = d->spec;
+  int64_t n = 0;
+  CRGPU_TRY(d->err.ensure(sizeof(KvError)));
+  CRGPU_HIP(hipMemsetAsync(d->err.p, 0xFF, 8, st));
+  CRGPU_HIP(hipMemsetAsync(d->err.as<uint8_t>() + 8, 0, 8, st));
+  if (n_batches > 0) {
+    CRGPU_TRY(d->batch_offs.ensure(static_cast<size_t>(n_batches + 1) * 8));
+    CRGPU_TRY(d->row_base.ensure(static_cast<size_t>(n_batches + 1) * 8));
+    CRGPU_TRY(d->counts.ensure(static_cast<size_t>(n_batches) * 8));
+    CRGPU_HIP(hipMemcpyAsync(d->batch_offs.p, batch_offsets_host, static_cast<size_t>(n_batches + 1) * 8, hipMemcpyHostToDevice, st));
+    {
+      ProfScope prof("kv_walk");
+      hipLaunchKernelGGL(kv_walk_kernel<false>, dim3(static_cast<unsigned>(n_batches)), dim3(64), 0, st, repr_dev,
+                         d->batch_offs.as<int64_t>(), static_cast<const int64_t *>(nullptr), d->counts.as<int64_t>(),
+                         static_cast<int64_t *>(nullptr), d->err.as<KvError>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    std::vector<int64_t> counts(static_cast<size_t>(n_batches)), base(static_cast<size_t>(n_batches) + 1);
+    CRGPU_HIP(hipMemcpyAsync(counts.data(), d->counts.p, static_cast<size_t>(n_batches) * 8, hipMemcpyDeviceToHost, st));
+    CRGPU_TRY(kv_check_error(d, "batch"));
+    base[0] = 0;
+    for (int64_t b = 0; b < n_batches; b++) base[b + 1] = base[b] + counts[b];
+    n = base[n_batches];
+    if (n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: more than 2^31 rows in one call");
+    if (n > 0) {
+      CRGPU_TRY(d->rec_off.ensure(static_cast<size_t>(n) * 8));
+      CRGPU_HIP(hipMemcpyAsync(d->row_base.p, base.data(), static_cast<size_t>(n_batches + 1) * 8, hipMemcpyHostToDevice, st));
+      ProfScope prof("kv_walk");
+      hipLaunchKernelGGL(kv_walk_kernel<true>, dim3(static_cast<unsigned>(n_batches)), dim3(64), 0, st, repr_dev,
+                         d->batch_offs.as<int64_t>(), d->row_base.as<int64_t>(), static_cast<int64_t *>(nullptr),
+                         d->rec_off.as<int64_t>(), d->err.as<KvError>());
+      CRGPU_HIP(hipGetLastError());
+      CRGPU_HIP(hipStreamSynchronize(st));  // `base` is read by the copy above
+    }
+  }
+  const int64_t cap = n > 0 ? n : 1;
+  FetchOut o;
+  std::memset(&o, 0, sizeof(o));
+  bool any_bytes = false;
+  for (int c = 0; c < f.n_out; c++) {
+    OutCol &oc = d->out[c];
+    oc.type = f.out_types[c];
+    oc.nullable = true;
+    CRGPU_TRY(d->valid_bytes[c].ensure(static_cast<size_t>(cap)));
+    CRGPU_TRY(oc.valid.ensure(static_cast<size_t>((cap + 7) / 8 + 1)));
+    o.valid[c] = d->valid_bytes[c].as<uint8_t>();
+    if (oc.type == CRGPU_BYTES) {
+      any_bytes = true;
+      CRGPU_TRY(d->lens[c].ensure(static_cast<size_t>(cap) * 4));
+      CRGPU_TRY(oc.offsets.ensure(static_cast<size_t>(cap + 1) * 4));
+      o.lens[c] = d->lens[c].as<uint32_t>();
+      if (n == 0) CRGPU_HIP(hipMemsetAsync(oc.offsets.p, 0, 4, st));
+    } else {
+      CRGPU_TRY(oc.data.ensure(static_cast<size_t>(cap) * type_width(oc.type)));
+      o.data[c] = oc.data.p;
+    }
+  }
+  if (n > 0) {
+    {
+      ProfScope prof("kv_decode");
+      hipLaunchKernelGGL(kv_decode_kernel<0>, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
+                         d->err.as<KvError>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    CRGPU_TRY(kv_check_error(d, "row"));
+    if (any_bytes) {
+      CRGPU_TRY(d->offs64.ensure(static_cast<size_t>(n + 1) * 8));
+      for (int c = 0; c < f.n_out; c++) {
+        if (f.out_types[c] != CRGPU_BYTES) continue;
+        uint64_t total = 0;
+        CRGPU_TRY(exclusive_scan_u32(d->lens[c].as<uint32_t>(), n, d->offs64.as<uint64_t>(), d->scratch, &total));
+        if (total > 0xFFFFFFFFull) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: a BYTES column exceeds 4 GiB; decode fewer batches per call");
+        hipLaunchKernelGGL(kv_narrow_offsets_kernel, dim3(kv_grid(n + 1, 256)), dim3(256), 0, st, d->offs64.as<uint64_t>(), n + 1,
+                           d->out[c].offsets.as<uint32_t>());
+        CRGPU_TRY(d->out[c].data.ensure(static_cast<size_t>(total ? total : 1)));
+        o.data[c] = d->out[c].data.p;
+        o.offs[c] = d->out[c].offsets.as<uint32_t>();
+      }
+      ProfScope prof("kv_decode");
+      hipLaunchKernelGGL(kv_decode_kernel<1>, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
+                         d->err.as<KvError>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    for (int c = 0; c < f.n_out; c++) CRGPU_TRY(pack_bitmap(o.valid[c], n, d->out[c].valid.as<uint8_t>()));
+  }
+  CRGPU_HIP(hipStreamSynchronize(st));
+  for (int c = 0; c < f.n_out; c++) d->views[c] = d->out[c].view();
+  res->n = n;
+  res->ncols = f.n_out;
+  res->_pad = 0;
+  res->cols = d->views.data();
+  return CRGPU_OK;
+}

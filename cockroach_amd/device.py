@@ -239,6 +239,37 @@ class Partitioner:
             pass
 
 
+class Decoder:
+    """crgpu_decoder handle: KV batch responses (device bytes) -> columns (cFetcher for one-KV-per-row indexes)."""
+
+    def __init__(self, key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_types, val_out, out_types):
+        self._keep = (_i32arr(key_types), _i32arr(key_dirs), _i32arr(key_out), _i32arr(val_col_ids), _i32arr(val_types),
+                      _i32arr(val_out), _i32arr(out_types))
+        k = self._keep
+        spec = _lib.FetchSpec(key_prefix_len, len(list(key_types)), k[0], k[1], k[2], len(list(val_col_ids)),
+                              len(list(out_types)), k[3], k[4], k[5], k[6])
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_decoder_create(C.byref(spec), C.byref(self.h)))
+
+    def decode(self, repr_buf: DeviceBuffer, batch_offsets):
+        offs = np.ascontiguousarray(batch_offsets, dtype=np.int64)
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_decode_kv(self.h, repr_buf.ptr, offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                   len(offs) - 1, C.byref(res)))
+        return res
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_decoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def prof_enable(on=True):
     _lib.load().crgpu_prof_enable(int(on))
 

@@ -199,6 +199,38 @@ crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, i
                                  int64_t *counts_host);
 void crgpu_dev_partitioner_destroy(crgpu_partitioner *p);
 
+/* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for indexes that store one KV per
+ * row (MaxKeysPerRow == 1 fast path, sql/colfetcher/cfetcher.go:758-1093,937-941) together with
+ * colencoding.DecodeKeyValsToCols (colencoding/key_encoding.go:43), processValueBytes
+ * (cfetcher.go:1313), colencoding.DecodeTableValueToCol (value_encoding.go:24) and fillNulls
+ * (cfetcher.go:1401).  The spec is the subset of fetchpb.IndexFetchSpec the decode needs
+ * (sql/catalog/fetchpb/index_fetch.proto:112: KeyPrefixLength, key columns with direction,
+ * fetched columns by column id).  Types: crgpu_type; other families (DECIMAL, TIMESTAMP, ...)
+ * stay on the CPU fetcher; such columns may still be PRESENT in the rows, they are skipped. */
+typedef struct crgpu_fetch_spec {
+  int32_t key_prefix_len;  /* IndexFetchSpec.KeyPrefixLength: tenant/table/index prefix bytes */
+  int32_t n_key_cols;      /* index key columns, in key order (<= 8) */
+  const int32_t *key_types;
+  const int32_t *key_dirs; /* 0 ascending, 1 descending (catenumpb.IndexColumn_Direction) */
+  const int32_t *key_out;  /* output ordinal, or -1 when the column is not fetched */
+  int32_t n_val_cols;      /* fetched value columns, by increasing column id (<= 32) */
+  int32_t n_out_cols;      /* <= 32 */
+  const int32_t *val_col_ids;
+  const int32_t *val_types;
+  const int32_t *val_out;
+  const int32_t *out_types; /* crgpu_type per output column */
+} crgpu_fetch_spec;
+
+typedef struct crgpu_decoder crgpu_decoder;
+crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *spec, crgpu_decoder **out);
+/* repr_dev: concatenated MVCCScan batch responses (storage/enginepb/decode.go:77-128) in device
+ * memory, 16-byte aligned; batch b spans [batch_offsets_host[b], batch_offsets_host[b+1]).
+ * out: one row per KV in scan order, one column per output ordinal; columns requested but
+ * absent from a row are NULL.  Malformed input => CRGPU_ERR_INVALID naming the first bad row. */
+crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
+                                 int64_t n_batches, crgpu_dev_result *out);
+void crgpu_dev_decoder_destroy(crgpu_decoder *d);
+
 /* ============================================================ layer (2) */
 /* One coldata.Vec as Go lays it out (col/coldata/vec.go:44, native_types.go:15-37,
  * bytes.go:45-74,156-165): fixed-width families -> the slice's backing array;

@@ -1,0 +1,112 @@
+"""GPU parity of the KV fetch decode (crgpu_dev_decode_kv) against the oracle's
+cFetcher restatement on the same encoded batches, bit-exact, plus the reference's
+own KV dump (docs/tech-notes/encoding.md) and the error paths."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from cockroach_amd import _lib
+from cockroach_amd import coldata as cd
+from cockroach_amd import device as dev
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_decode(prefix_len, kt, kd, ko, ids, vt, vo, out_types, data, offs):
+    d = dev.Decoder(prefix_len, kt, kd, ko, ids, vt, vo, out_types)
+    pad = (-len(data)) % 16
+    buf = dev.DeviceBuffer.from_numpy(np.concatenate([data, np.zeros(pad + 16, np.uint8)]))
+    try:
+        return dev.result_to_vecs(d.decode(buf, offs))
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("dirs", [(0, 0, 0, 0), (1, 1, 1, 1), (0, 1, 0, 1)])
+@pytest.mark.parametrize("batch_bytes", [4 << 10, 1 << 20])
+def test_decode_matches_oracle(oracle, dirs, batch_bytes):
+    rng = np.random.default_rng(sum(dirs) * 7 + batch_bytes % 13)
+    n = 20_000
+    kt = [cd.INT64, cd.BYTES, cd.FLOAT64, cd.INT32]
+    vt = [cd.INT64, cd.FLOAT64, cd.BYTES, cd.BOOL, cd.INT16, cd.BYTES]
+    ids = [5, 6, 9, 10, 40, 300]
+    keys, vals = H.kv_random_rows(rng, n, kt, vt)
+    t = oracle.KvTable(106, 1, kt, list(dirs), ids, vt)
+    data, offs = oracle.kv_encode(t, keys, vals, max_batch_bytes=batch_bytes, explicit_null_every=3)
+    full = (t.prefix_len(), kt, list(dirs), [0, 1, 2, 3], ids, vt, [4, 5, 6, 7, 8, 9], kt + vt)
+    H.assert_vecs_equal(gpu_decode(*full, data, offs), oracle.kv_decode(*full, data, offs), "all columns")
+    proj = (t.prefix_len(), kt, list(dirs), [-1, 2, -1, 0], [6, 10, 300], [vt[1], vt[3], vt[5]], [1, 4, 3],
+            [cd.INT32, cd.FLOAT64, cd.BYTES, cd.BYTES, cd.BOOL])
+    got = gpu_decode(*proj, data, offs)
+    H.assert_vecs_equal(got, oracle.kv_decode(*proj, data, offs), "projection")
+    H.assert_vecs_equal(got, [H.kv_key_canonical(keys[3]), vals[1], H.kv_key_canonical(keys[1]), vals[5], vals[3]],
+                        "projection vs source rows")
+
+
+def test_decode_reference_kv_dump(oracle):
+    with open(os.path.join(H.GOLDEN, "encoding_vectors.json")) as f:
+        vec = json.load(f)
+    data = b""
+    for i, kv in enumerate(vec["kv_values"]):
+        key = oracle.kv_enc("uvarint_asc", 51) + oracle.kv_enc("uvarint_asc", 1) + oracle.kv_enc("varint_asc", i + 1) + b"\x88"
+        mvcc = key + b"\x00" + (1489504989617188491).to_bytes(8, "big") + b"\x09"
+        value = bytes.fromhex(kv["value"])
+        data += len(value).to_bytes(4, "little") + len(mvcc).to_bytes(4, "little") + mvcc + value
+    arr = np.frombuffer(data, dtype=np.uint8)
+    out = gpu_decode(2, [cd.INT64], [0], [0], [2], [cd.BYTES], [1], [cd.INT64, cd.BYTES], arr, [0, len(arr)])
+    assert out[0].to_values() == [1, 2, 3, 4, 5]
+    assert out[1].to_values() == [None if kv["owner"] is None else bytes.fromhex(kv["owner"]) for kv in vec["kv_values"]]
+
+
+def test_decode_lineitem_shape_large(oracle):
+    """TPC-H lineitem-like rows (2 int key columns, 14 value columns: ints/dates, 4 floats, 6 strings),
+    2e5 rows in ~64 KiB batches; only the Q1 columns are fetched."""
+    rng = np.random.default_rng(3)
+    n = 200_000
+    kt, kd = [cd.INT64, cd.INT64], [0, 0]
+    vt = [cd.INT64, cd.INT64, cd.FLOAT64, cd.FLOAT64, cd.FLOAT64, cd.FLOAT64, cd.BYTES, cd.BYTES, cd.INT64, cd.INT64,
+          cd.INT64, cd.BYTES, cd.BYTES, cd.BYTES]
+    ids = list(range(3, 17))
+    keys = [cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64) // 4 + 1),
+            cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64) % 4 + 1)]
+    vals = []
+    for t in vt:
+        if t == cd.INT64:
+            vals.append(cd.Vec.from_numpy(cd.INT64, rng.integers(0, 200_000, n, dtype=np.int64)))
+        elif t == cd.FLOAT64:
+            vals.append(cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.random(n) * 1e5, 2)))
+        else:
+            w = int(rng.integers(1, 26))
+            vals.append(cd.Vec.bytes_from_fixed(rng.integers(65, 91, (n, w)).astype(np.uint8)))
+    t = oracle.KvTable(110, 1, kt, kd, ids, vt)
+    data, offs = oracle.kv_encode(t, keys, vals, max_batch_bytes=64 << 10)
+    assert len(offs) > 300
+    # l_quantity(5), l_extendedprice(6), l_discount(7), l_tax(8), l_returnflag(9), l_linestatus(10), l_shipdate(11)
+    sel = [2, 3, 4, 5, 6, 7, 8]
+    spec = (t.prefix_len(), kt, kd, [-1, -1], [ids[i] for i in sel], [vt[i] for i in sel], list(range(7)), [vt[i] for i in sel])
+    got = gpu_decode(*spec, data, offs)
+    H.assert_vecs_equal(got, [vals[i] for i in sel], "lineitem Q1 columns")
+
+
+def test_decode_errors_and_empty(oracle):
+    t = oracle.KvTable(60, 1, [cd.INT64], [0], [2], [cd.INT64])
+    k = cd.Vec.from_numpy(cd.INT64, np.arange(50, dtype=np.int64))
+    data, offs = oracle.kv_encode(t, [k], [k])
+    args = (t.prefix_len(), [cd.INT64], [0], [0], [2], [cd.INT64], [1], [cd.INT64, cd.INT64])
+    assert gpu_decode(*args, data, offs)[1].to_values() == list(range(50))
+    out = gpu_decode(*args, np.zeros(0, np.uint8), [0, 0])
+    assert len(out) == 2 and len(out[0]) == 0
+    with pytest.raises(_lib.CrgpuError) as e:
+        gpu_decode(*args, data[:-3], [0, len(data) - 3])
+    assert e.value.code == _lib.ERR_INVALID and "truncated" in str(e.value)
+    bad = data.copy()
+    rec0_key_len = int.from_bytes(bytes(bad[4:8]), "little")
+    bad[8 + rec0_key_len + 4] = 3  # BYTES-tagged value where a TUPLE is expected
+    with pytest.raises(_lib.CrgpuError) as e:
+        gpu_decode(*args, bad, offs)
+    assert "TUPLE" in str(e.value) and "row 0" in str(e.value)
+    with pytest.raises(_lib.CrgpuError):  # value column ids must increase
+        dev.Decoder(2, [cd.INT64], [0], [0], [5, 3], [cd.INT64, cd.INT64], [1, 2], [cd.INT64] * 3)
