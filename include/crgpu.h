@@ -224,7 +224,7 @@ typedef struct crgpu_fetch_spec {
 typedef struct crgpu_decoder crgpu_decoder;
 crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *spec, crgpu_decoder **out);
 /* repr_dev: concatenated MVCCScan batch responses (storage/enginepb/decode.go:77-128) in device
- * memory, 16-byte aligned; batch b spans [batch_offsets_host[b], batch_offsets_host[b+1]).
+ * memory, 16-byte aligned and followed by >= 16 readable bytes; batch b spans [batch_offsets_host[b], batch_offsets_host[b+1]).
  * out: one row per KV in scan order, one column per output ordinal; columns requested but
  * absent from a row are NULL.  Malformed input => CRGPU_ERR_INVALID naming the first bad row. */
 crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Throughput of crgpu_dev_decode_kv on lineitem-shaped rows (SURVEY.md 8(d), config Q1 point (ii)):
+rows encoded by the oracle's encoder (test infrastructure, outside the timed region), batch responses
+resident in HBM, the Q1 columns fetched.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cockroach_amd import _lib, coldata as cd, device as dev  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    batch_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 10 << 20
+    _lib.check(_lib.load().crgpu_init(0))
+    rng = np.random.default_rng(3)
+    kt, kd = [cd.INT64, cd.INT64], [0, 0]
+    vt = [cd.INT64, cd.INT64, cd.FLOAT64, cd.FLOAT64, cd.FLOAT64, cd.FLOAT64, cd.BYTES, cd.BYTES, cd.INT64, cd.INT64,
+          cd.INT64, cd.BYTES, cd.BYTES, cd.BYTES]
+    widths = {6: 1, 7: 1, 11: 25, 12: 10, 13: 44}
+    ids = list(range(3, 17))
+    keys = [cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64) // 4 + 1),
+            cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64) % 4 + 1)]
+    vals = []
+    for i, t in enumerate(vt):
+        if t == cd.INT64:
+            vals.append(cd.Vec.from_numpy(cd.INT64, rng.integers(0, 200_000, n, dtype=np.int64)))
+        elif t == cd.FLOAT64:
+            vals.append(cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.random(n) * 1e5, 2)))
+        else:
+            vals.append(cd.Vec.bytes_from_fixed(rng.integers(65, 91, (n, widths[i])).astype(np.uint8)))
+    t = O.KvTable(110, 1, kt, kd, ids, vt)
+    data, offs = O.kv_encode(t, keys, vals, max_batch_bytes=batch_bytes)
+    one = len(data)
+    # replicate the encoded batches to get enough concurrent batch walks
+    data = np.tile(np.concatenate([data, np.zeros((-one) % 16, np.uint8)]), reps)
+    step = one + (-one) % 16
+    all_offs = np.concatenate([np.concatenate([offs[:-1], [offs[-1]]])[None, :] + r * step for r in range(reps)], 0)
+    batches = []
+    for r in range(reps):
+        for b in range(len(offs) - 1):
+            batches.append((all_offs[r, b], all_offs[r, b + 1]))
+    # batches must be contiguous for the API: pad records are not allowed, so decode each replica's range
+    # through a flat offsets array where replica boundaries coincide (padding is zero bytes => use one call per replica)
+    buf = dev.DeviceBuffer.from_numpy(np.concatenate([data, np.zeros(16, np.uint8)]))
+    sel = [2, 3, 4, 5, 6, 7, 8]
+    d = dev.Decoder(t.prefix_len(), kt, kd, [-1, -1], [ids[i] for i in sel], [vt[i] for i in sel], list(range(7)),
+                    [vt[i] for i in sel])
+    lib = _lib.load()
+
+    class Sub:  # a view into the device buffer
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+    def run():
+        rows = 0
+        for r in range(reps):
+            res = d.decode(Sub(buf.ptr + r * step), offs)
+            rows += int(res.n)
+        return rows
+
+    run()
+    dev.prof_enable(True)
+    dev.prof_reset()
+    t0 = time.perf_counter()
+    rows = run()
+    lib.crgpu_dev_synchronize()
+    dt = time.perf_counter() - t0
+    walk_ms, _ = dev.prof_get("kv_walk")
+    dec_ms, _ = dev.prof_get("kv_decode")
+    in_bytes = one * reps
+    out_bytes = rows * (4 * 8 + 2 * (1 + 4) + 8)
+    print(json.dumps({"rows": rows, "input_bytes": in_bytes, "bytes_per_row": in_bytes / rows, "batches_per_call": len(offs) - 1,
+                      "wall_ms": dt * 1e3, "kv_walk_ms": walk_ms, "kv_decode_ms": dec_ms,
+                      "rows_per_s": rows / dt, "input_GBps_wall": in_bytes / dt / 1e9,
+                      "decode_kernel_GBps": (in_bytes + out_bytes) / (dec_ms / 1e3) / 1e9 if dec_ms else None,
+                      "walk_kernel_GBps": 2 * in_bytes / (walk_ms / 1e3) / 1e9 if walk_ms else None}))
+
+
+if __name__ == "__main__":
+    main()
