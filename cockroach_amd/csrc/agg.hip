@@ -5,20 +5,27 @@
 // (pkg/sql/colexec/colexecagg/hash_{sum,sum_int,avg,count,min_max,any_not_null,bool_and_or}_agg.eg.go).
 //
 // Design (not the reference's 4096-tuple buffer + equality chains + virtual Compute calls):
-//  * ONE open-addressing table keyed by the group columns.  A slot holds either
-//    EMPTY, OCCUPIED (key lives in the per-slot key store) or -- while a chunk is
-//    being consumed -- the chunk row id of the row that claimed it.  Input columns
-//    are immutable during the kernel, so "compare against the claimant's row" needs
-//    no cross-workgroup publication protocol: the only mutable words are the slots,
-//    and those are touched with atomics only.
-//  * find-or-insert and aggregation are fused in one pass over the chunk; every
-//    accumulator is a per-slot 64-bit word updated with HBM atomics
-//    (global_atomic_add_f64 / add_u64 / smin / smax / umin / umax / and / or).
-//    While few groups exist the lanes of a wave that hit the same slot are first
-//    combined in registers (one atomic per wave and group instead of 64).
-//  * after each chunk the newly claimed slots get their keys copied into the key
-//    store; when the table passes 50 % load it is rebuilt at twice the size.
-//    Rows that cannot be placed (probe limit) are deferred and replayed after growth.
+//  * Groups are numbered densely in creation order (group id, "gid").  Everything that
+//    belongs to a group -- its key (key store), its accumulator words, its hash word --
+//    lives in arrays indexed by gid; they only ever grow at the end, so growing the hash
+//    index never moves them and the result columns are read straight out of them.
+//  * The hash INDEX is an open-addressing array of 64-bit entries
+//    {tag:23 | null mask:8 | gid:32}.  The tag filters nearly all non-matching keys before
+//    the key store is touched; the null mask makes NULL == NULL (GROUP BY semantics,
+//    hash_aggregator.go:269 allowNullEquality=true) a register compare.  While a chunk is
+//    resolved an entry may instead hold {claim bit | tag | mask | chunk position} of the
+//    row that claimed it: input columns are immutable during the kernel, so other rows
+//    compare against the claimant's ROW and no publication protocol is needed.
+//  * Measured on MI355X (experiments/atomics.hip): random 8-byte HBM atomics run at
+//    ~24 G/s whatever the table size or scope, while LDS atomics sustain > 1 T rows/s.
+//    So accumulation is LDS-privatised whenever the groups fit: each workgroup owns a
+//    partial table in LDS ([word][group][replica]; replicas spread same-group lanes over
+//    banks), accumulates with ds_add_f64 / ds_add_u64 / ds_min / ds_max, and merges it into
+//    the HBM accumulators with one atomic per (workgroup, group, word) at the end.  When the
+//    groups exceed one LDS table the kernel sweeps gid ranges (re-reading the 4-byte gid per
+//    row) as long as that is cheaper than HBM atomics; beyond that it falls back to them.
+//  * Steady state is ONE fused pass (hash -> index lookup -> accumulate); only rows whose
+//    group does not exist yet go through find-or-insert (resolve -> fixup -> accumulate).
 //  * SUM_INT accumulates in 128 bits (two words) so the overflow test does not
 //    depend on summation order: CRGPU_ERR_INT_OUT_OF_RANGE iff the exact group total
 //    leaves int64 (the reference errors on transient overflow in arrival order,
@@ -26,7 +33,7 @@
 //  * float SUM/AVG use fp64 atomics: order-dependent in the last bits (stated
 //    tolerance rel 1e-9).
 //
-// Roofline: HBM-bound (streaming input + random 8-byte atomics).
+// Roofline: HBM-bound (streaming input; LDS atomics are far from their limit).
 #include <cstring>
 #include <memory>
 
@@ -34,11 +41,17 @@
 
 namespace crgpu {
 
-static constexpr uint32_t kSlotEmpty = 0xFFFFFFFFu;
-static constexpr uint32_t kSlotOccupied = 0xFFFFFFFEu;
-static constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 static constexpr int kMaxAggs = 64;
-static constexpr int kMaxProbe = 512;
+static constexpr int kMaxProbe = 128;                  // index slots inspected before a row is deferred / reported as a miss
+static constexpr unsigned long long kMetaEmpty = ~0ull;
+static constexpr uint32_t kClaimBit = 0x80000000u;     // upper word of an index entry: claimed during the current launch
+static constexpr uint32_t kGidDefer = 0xFFFFFFFFu;     // out_gid: row could not be placed in this round
+static constexpr uint32_t kGidSlotRef = 0x80000000u;   // out_gid: low 31 bits name an index slot whose gid the fixup assigns
+static constexpr uint32_t kMaxCap = 1u << 30;          // index entries (=> at most 2^29 groups per GPU)
+static constexpr uint32_t kIdxHashMask = kMaxCap - 1;
+static constexpr size_t kLdsSmall = 64 * 1024;         // two 512-thread workgroups per CU
+static constexpr size_t kLdsLarge = 152 * 1024;        // one 1024-thread workgroup per CU
+static constexpr int kMaxReplicas = 32;
 
 enum AccKind : int32_t {
   ACC_COUNT_ROWS = 0, ACC_COUNT, ACC_SUM_F64, ACC_AVG_F64, ACC_SUM_I128, ACC_MIN_I64, ACC_MAX_I64, ACC_MIN_F64,
@@ -48,22 +61,22 @@ enum AccKind : int32_t {
 struct AggOpDev {
   int32_t kind;
   int32_t has_filter;
-  int32_t key_idx;  // ACC_ANY_KEY: which group column
-  int32_t _pad;
+  int32_t key_idx;           // ACC_ANY_KEY: which group column
+  int32_t lw0, lw1, lseen;   // LDS partial table: word / seen-byte plane numbers (-1: none)
   DCol col;
   DCol filter;
-  unsigned long long *w0;
-  unsigned long long *w1;
-  uint8_t *seen;
+  unsigned long long *w0;    // [gid]
+  unsigned long long *w1;    // [gid] (AVG count, SUM_INT high word, ANY_NOT_NULL value)
+  uint8_t *seen;             // [gid] a non-NULL input was accumulated
 };
 
 struct KeyStoreCol {
   int32_t type;
   int32_t _pad;
-  uint8_t *data;       // fixed-width: value per slot
-  uint8_t *present;    // one byte per slot (0 => NULL key)
-  uint64_t *b_off;     // BYTES: offset into b_buf per slot
-  uint32_t *b_len;     // BYTES: length per slot
+  uint8_t *data;       // fixed-width: value per gid
+  uint8_t *present;    // one byte per gid (0 => NULL key); only read when results are produced
+  uint64_t *b_off;     // BYTES: offset into b_buf per gid
+  uint32_t *b_len;     // BYTES: length per gid
   uint8_t *b_buf;      // BYTES: append-only payload buffer
 };
 struct KeyStore {
@@ -85,40 +98,74 @@ __device__ __forceinline__ double ordered_to_f64(unsigned long long m) {
   return __longlong_as_double(static_cast<long long>(b));
 }
 
-// chunk row vs stored key of an OCCUPIED slot (NULLs are equal: GROUP BY semantics,
-// hash_aggregator.go:269 allowNullEquality=true)
-__device__ inline bool key_equals_store(const KeyCols &k, int64_t row, const KeyStore &st, uint32_t slot) {
+// ------------------------------------------------------------------ row hash (internal: only results must match the reference)
+struct RowHash {
+  uint32_t idx;    // 30 bits: index position before masking
+  uint32_t upper;  // tag << 8 | null mask (claim bit clear)
+};
+__device__ __forceinline__ uint64_t hash_step(uint64_t h, uint64_t v) {
+  return (((h << 27) | (h >> 37)) ^ v) * 0x9FB21C651E98DF25ull;
+}
+__device__ inline RowHash agg_hash(const KeyCols &k, int64_t row) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  uint32_t nm = 0;
   for (int c = 0; c < k.n; c++) {
     const DCol &x = k.c[c];
-    const KeyStoreCol &s = st.c[c];
-    const bool xn = col_is_null(x, row), sn = s.present[slot] == 0;
-    if (xn || sn) {
-      if (xn && sn) continue;
-      return false;
+    if (col_is_null(x, row)) {
+      nm |= 1u << c;
+      h = hash_step(h, 0x6E756C6Cull);
+      continue;
     }
+    if (x.type == CRGPU_BYTES) {
+      const uint32_t a0 = x.offsets[row], len = x.offsets[row + 1] - a0;
+      const uint8_t *p = reinterpret_cast<const uint8_t *>(x.data) + a0;
+      for (uint32_t t = 0; t < len; t += 8) {
+        const uint32_t kk = len - t < 8 ? len - t : 8;
+        uint64_t w = 0;
+        for (uint32_t j = 0; j < kk; j++) w |= static_cast<uint64_t>(p[t + j]) << (8 * j);
+        h = hash_step(h, w);
+      }
+      h = hash_step(h, 0xB17E5ull + len);
+    } else {
+      h = hash_step(h, pack_key(x, row));  // ints sign-extended, floats canonical (NaN == NaN, +0 == -0)
+    }
+  }
+  h = fmix64(h);
+  RowHash r;
+  r.idx = static_cast<uint32_t>(h) & kIdxHashMask;
+  r.upper = (static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8 | nm;
+  return r;
+}
+
+// chunk row vs stored key of group `gid`; `nm` is the (equal) null mask of both sides
+__device__ inline bool key_equals_store(const KeyCols &k, int64_t row, const KeyStore &st, uint32_t gid, uint32_t nm) {
+  for (int c = 0; c < k.n; c++) {
+    if ((nm >> c) & 1u) continue;
+    const DCol &x = k.c[c];
+    const KeyStoreCol &s = st.c[c];
     switch (x.type) {
       case CRGPU_BOOL:
-        if (col_get_bool(x, row) != (s.data[slot] != 0)) return false;
+        if (col_get_bool(x, row) != (s.data[gid] != 0)) return false;
         break;
       case CRGPU_INT16:
-        if (reinterpret_cast<const int16_t *>(x.data)[row] != reinterpret_cast<const int16_t *>(s.data)[slot]) return false;
+        if (reinterpret_cast<const int16_t *>(x.data)[row] != reinterpret_cast<const int16_t *>(s.data)[gid]) return false;
         break;
       case CRGPU_INT32:
-        if (reinterpret_cast<const int32_t *>(x.data)[row] != reinterpret_cast<const int32_t *>(s.data)[slot]) return false;
+        if (reinterpret_cast<const int32_t *>(x.data)[row] != reinterpret_cast<const int32_t *>(s.data)[gid]) return false;
         break;
       case CRGPU_INT64:
-        if (reinterpret_cast<const int64_t *>(x.data)[row] != reinterpret_cast<const int64_t *>(s.data)[slot]) return false;
+        if (reinterpret_cast<const int64_t *>(x.data)[row] != reinterpret_cast<const int64_t *>(s.data)[gid]) return false;
         break;
       case CRGPU_FLOAT64: {
-        double p = col_get_f64(x, row), q = reinterpret_cast<const double *>(s.data)[slot];
+        double p = col_get_f64(x, row), q = reinterpret_cast<const double *>(s.data)[gid];
         if (!(p == q || (p != p && q != q))) return false;
         break;
       }
       case CRGPU_BYTES: {
         uint32_t xa = x.offsets[row], xl = x.offsets[row + 1] - xa;
-        if (xl != s.b_len[slot]) return false;
+        if (xl != s.b_len[gid]) return false;
         const uint8_t *px = reinterpret_cast<const uint8_t *>(x.data) + xa;
-        const uint8_t *ps = s.b_buf + s.b_off[slot];
+        const uint8_t *ps = s.b_buf + s.b_off[gid];
         for (uint32_t t = 0; t < xl; t++)
           if (px[t] != ps[t]) return false;
         break;
@@ -129,25 +176,23 @@ __device__ inline bool key_equals_store(const KeyCols &k, int64_t row, const Key
   return true;
 }
 
-struct AggArgs {
-  KeyCols keys;
-  const KeyStore *store;  // device copy
-  const AggOpDev *ops;    // device copy
-  int32_t naggs;
-  int32_t combine;  // 1: combine lanes of a wave that share a slot before touching memory
-  int64_t n;
-  unsigned long long seq_base;  // global arrival number of row 0 of this chunk
-  uint32_t *slots;
-  uint32_t mask;
-  int32_t only_deferred;
-  uint32_t *hstore;
-  uint8_t *deferred;
-  unsigned int *counters;  // [0] new representatives, [1] deferred rows
-  uint32_t *rep_rows, *rep_slots;
-  uint32_t *slot_of_row;  // optional (ANY_NOT_NULL over non-group columns)
-};
+// read-only index lookup: gid of the row's group or kGidDefer when it does not exist (yet)
+__device__ inline uint32_t index_lookup(const KeyCols &keys, int64_t row, const KeyStore &store,
+                                        const unsigned long long *__restrict__ meta, uint32_t mask) {
+  const RowHash rh = agg_hash(keys, row);
+  uint32_t idx = rh.idx & mask;
+  for (int probes = 0; probes < kMaxProbe; probes++) {
+    const unsigned long long e = meta[idx];
+    if (e == kMetaEmpty) return kGidDefer;
+    if (static_cast<uint32_t>(e >> 32) == rh.upper &&
+        key_equals_store(keys, row, store, static_cast<uint32_t>(e), rh.upper & 0xFFu))
+      return static_cast<uint32_t>(e);
+    idx = (idx + 1) & mask;
+  }
+  return kGidDefer;
+}
 
-// ------------------------------------------------------------------ per-row accumulation (one atomic per lane)
+// ------------------------------------------------------------------ accumulation (one atomic per lane; HBM or LDS words)
 __device__ __forceinline__ void add_i128(unsigned long long *lo, unsigned long long *hi, unsigned long long vlo,
                                          unsigned long long vhi) {
   const unsigned long long old = atomicAdd(lo, vlo);
@@ -156,263 +201,376 @@ __device__ __forceinline__ void add_i128(unsigned long long *lo, unsigned long l
   if (d != 0ull) atomicAdd(hi, d);
 }
 
-__device__ inline void accumulate_direct(const AggOpDev &op, int64_t row, uint32_t slot, unsigned long long seq) {
+__device__ __forceinline__ void accum_row(const AggOpDev &op, int64_t row, unsigned long long seq, unsigned long long *w0,
+                                          unsigned long long *w1, uint8_t *seen) {
+  if (op.kind == ACC_ANY_KEY) return;
   if (op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row))) return;  // aggregators_util.go:216-234
   if (op.kind == ACC_COUNT_ROWS) {
-    atomicAdd(&op.w0[slot], 1ull);
+    atomicAdd(w0, 1ull);
     return;
   }
-  if (op.kind == ACC_ANY_KEY) return;
   if (col_is_null(op.col, row)) return;  // aggregates skip NULL inputs
   switch (op.kind) {
-    case ACC_COUNT: atomicAdd(&op.w0[slot], 1ull); break;
+    case ACC_COUNT: atomicAdd(w0, 1ull); break;
     case ACC_SUM_F64:
-      atomicAdd(reinterpret_cast<double *>(&op.w0[slot]), col_get_f64(op.col, row));
-      op.seen[slot] = 1;
+      unsafeAtomicAdd(reinterpret_cast<double *>(w0), col_get_f64(op.col, row));
+      *seen = 1;
       break;
     case ACC_AVG_F64:
-      atomicAdd(reinterpret_cast<double *>(&op.w0[slot]), col_get_f64(op.col, row));
-      atomicAdd(&op.w1[slot], 1ull);
+      unsafeAtomicAdd(reinterpret_cast<double *>(w0), col_get_f64(op.col, row));
+      atomicAdd(w1, 1ull);
       break;
     case ACC_SUM_I128: {
       const long long v = col_get_int(op.col, row);
-      add_i128(&op.w0[slot], &op.w1[slot], static_cast<unsigned long long>(v), v < 0 ? ~0ull : 0ull);
-      op.seen[slot] = 1;
+      add_i128(w0, w1, static_cast<unsigned long long>(v), v < 0 ? ~0ull : 0ull);
+      *seen = 1;
       break;
     }
     case ACC_MIN_I64:
     case ACC_MAX_I64: {
       const long long v = op.col.type == CRGPU_BOOL ? static_cast<long long>(col_get_bool(op.col, row)) : col_get_int(op.col, row);
-      if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(&op.w0[slot]), v);
-      else atomicMax(reinterpret_cast<long long *>(&op.w0[slot]), v);
-      op.seen[slot] = 1;
+      if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(w0), v);
+      else atomicMax(reinterpret_cast<long long *>(w0), v);
+      *seen = 1;
       break;
     }
-    case ACC_MIN_F64: atomicMin(&op.w0[slot], f64_to_ordered(col_get_f64(op.col, row))); op.seen[slot] = 1; break;
-    case ACC_MAX_F64: atomicMax(&op.w0[slot], f64_to_ordered(col_get_f64(op.col, row))); op.seen[slot] = 1; break;
-    case ACC_BOOL_AND: if (!col_get_bool(op.col, row)) atomicAnd(&op.w0[slot], 0ull); op.seen[slot] = 1; break;
-    case ACC_BOOL_OR: if (col_get_bool(op.col, row)) atomicOr(&op.w0[slot], 1ull); op.seen[slot] = 1; break;
-    case ACC_ANY_ROW: atomicMin(&op.w0[slot], seq); break;  // first non-NULL in arrival order
+    case ACC_MIN_F64: atomicMin(w0, f64_to_ordered(col_get_f64(op.col, row))); *seen = 1; break;
+    case ACC_MAX_F64: atomicMax(w0, f64_to_ordered(col_get_f64(op.col, row))); *seen = 1; break;
+    case ACC_BOOL_AND: if (!col_get_bool(op.col, row)) atomicAnd(w0, 0ull); *seen = 1; break;
+    case ACC_BOOL_OR: if (col_get_bool(op.col, row)) atomicOr(w0, 1ull); *seen = 1; break;
+    case ACC_ANY_ROW: atomicMin(w0, seq); break;  // first non-NULL in arrival order
     default: break;
   }
 }
 
-// ------------------------------------------------------------------ wave-combined accumulation
-template <typename T, typename F>
-__device__ __forceinline__ T wave_reduce(T v, F f) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = f(v, __shfl_xor(v, d, 64));
-  return v;
+__device__ __forceinline__ unsigned long long acc_init_w0(int kind) {
+  switch (kind) {
+    case ACC_MIN_I64: return 0x7FFFFFFFFFFFFFFFull;
+    case ACC_MAX_I64: return 0x8000000000000000ull;
+    case ACC_MIN_F64: return ~0ull;
+    case ACC_BOOL_AND: return 1ull;
+    case ACC_ANY_ROW: return ~0ull;
+    default: return 0ull;
+  }
 }
 
-// All lanes of the wave call this (converged); `mine` = this lane belongs to the
-// group being flushed; the leader lane issues the memory update.
-__device__ inline void accumulate_combined(const AggOpDev &op, int64_t row, uint32_t slot, unsigned long long seq,
-                                           bool mine, bool leader) {
-  bool take = mine;
-  if (take && op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row))) take = false;
+// merge the replicas of group g (LDS) into the HBM accumulators of group gid
+__device__ inline void lds_flush_op(const AggOpDev &op, const unsigned long long *ldsw, const uint8_t *ldss, uint32_t G,
+                                    uint32_t R, uint32_t g, uint32_t gid) {
   if (op.kind == ACC_ANY_KEY) return;
-  if (op.kind == ACC_COUNT_ROWS) {
-    const unsigned long long c = popc64(__ballot(take));
-    if (leader && c) atomicAdd(&op.w0[slot], c);
-    return;
+  const unsigned long long *p0 = ldsw + (static_cast<size_t>(op.lw0) * G + g) * R;
+  const unsigned long long *p1 = op.lw1 >= 0 ? ldsw + (static_cast<size_t>(op.lw1) * G + g) * R : nullptr;
+  bool seen = false;
+  if (op.lseen >= 0) {
+    const uint8_t *ps = ldss + (static_cast<size_t>(op.lseen) * G + g) * R;
+    for (uint32_t r = 0; r < R; r++) seen |= ps[r] != 0;
+    if (!seen) return;
   }
-  if (take && col_is_null(op.col, row)) take = false;
-  const unsigned long long cnt = popc64(__ballot(take));
-  if (cnt == 0) return;  // wave-uniform
   switch (op.kind) {
-    case ACC_COUNT:
-      if (leader) atomicAdd(&op.w0[slot], cnt);
+    case ACC_COUNT_ROWS:
+    case ACC_COUNT: {
+      unsigned long long c = 0;
+      for (uint32_t r = 0; r < R; r++) c += p0[r];
+      if (c) atomicAdd(&op.w0[gid], c);
       break;
-    case ACC_SUM_F64:
+    }
+    case ACC_SUM_F64: {
+      double s = 0;
+      for (uint32_t r = 0; r < R; r++) s += __longlong_as_double(static_cast<long long>(p0[r]));
+      unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[gid]), s);
+      op.seen[gid] = 1;
+      break;
+    }
     case ACC_AVG_F64: {
-      double v = take ? col_get_f64(op.col, row) : 0.0;
-      v = wave_reduce(v, [](double a, double b) { return a + b; });
-      if (leader) {
-        atomicAdd(reinterpret_cast<double *>(&op.w0[slot]), v);
-        if (op.kind == ACC_AVG_F64) atomicAdd(&op.w1[slot], cnt);
-        else op.seen[slot] = 1;
+      double s = 0;
+      unsigned long long c = 0;
+      for (uint32_t r = 0; r < R; r++) {
+        s += __longlong_as_double(static_cast<long long>(p0[r]));
+        c += p1[r];
+      }
+      if (c) {
+        unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[gid]), s);
+        atomicAdd(&op.w1[gid], c);
       }
       break;
     }
     case ACC_SUM_I128: {
-      const long long x = take ? col_get_int(op.col, row) : 0;
-      unsigned long long lo = static_cast<unsigned long long>(x), hi = x < 0 ? ~0ull : 0ull;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long olo = __shfl_xor(lo, d, 64), ohi = __shfl_xor(hi, d, 64);
-        const unsigned long long s = lo + olo;
-        hi = hi + ohi + (s < lo ? 1ull : 0ull);
+      unsigned long long lo = 0, hi = 0;
+      for (uint32_t r = 0; r < R; r++) {
+        const unsigned long long s = lo + p0[r];
+        hi += p1[r] + (s < lo ? 1ull : 0ull);
         lo = s;
       }
-      if (leader) {
-        add_i128(&op.w0[slot], &op.w1[slot], lo, hi);
-        op.seen[slot] = 1;
-      }
+      add_i128(&op.w0[gid], &op.w1[gid], lo, hi);
+      op.seen[gid] = 1;
       break;
     }
     case ACC_MIN_I64:
     case ACC_MAX_I64: {
-      const bool mn = op.kind == ACC_MIN_I64;
-      long long v = mn ? 0x7FFFFFFFFFFFFFFFll : static_cast<long long>(0x8000000000000000ull);
-      if (take) v = op.col.type == CRGPU_BOOL ? static_cast<long long>(col_get_bool(op.col, row)) : col_get_int(op.col, row);
-      v = mn ? wave_reduce(v, [](long long a, long long b) { return a < b ? a : b; })
-             : wave_reduce(v, [](long long a, long long b) { return a > b ? a : b; });
-      if (leader) {
-        if (mn) atomicMin(reinterpret_cast<long long *>(&op.w0[slot]), v);
-        else atomicMax(reinterpret_cast<long long *>(&op.w0[slot]), v);
-        op.seen[slot] = 1;
+      long long v = static_cast<long long>(p0[0]);
+      for (uint32_t r = 1; r < R; r++) {
+        const long long t = static_cast<long long>(p0[r]);
+        v = op.kind == ACC_MIN_I64 ? (t < v ? t : v) : (t > v ? t : v);
       }
+      if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(&op.w0[gid]), v);
+      else atomicMax(reinterpret_cast<long long *>(&op.w0[gid]), v);
+      op.seen[gid] = 1;
       break;
     }
     case ACC_MIN_F64:
     case ACC_MAX_F64: {
-      const bool mn = op.kind == ACC_MIN_F64;
-      unsigned long long v = mn ? ~0ull : 0ull;
-      if (take) v = f64_to_ordered(col_get_f64(op.col, row));
-      v = mn ? wave_reduce(v, [](unsigned long long a, unsigned long long b) { return a < b ? a : b; })
-             : wave_reduce(v, [](unsigned long long a, unsigned long long b) { return a > b ? a : b; });
-      if (leader) {
-        if (mn) atomicMin(&op.w0[slot], v);
-        else atomicMax(&op.w0[slot], v);
-        op.seen[slot] = 1;
-      }
+      unsigned long long v = p0[0];
+      for (uint32_t r = 1; r < R; r++) v = op.kind == ACC_MIN_F64 ? (p0[r] < v ? p0[r] : v) : (p0[r] > v ? p0[r] : v);
+      if (op.kind == ACC_MIN_F64) atomicMin(&op.w0[gid], v);
+      else atomicMax(&op.w0[gid], v);
+      op.seen[gid] = 1;
       break;
     }
     case ACC_BOOL_AND: {
-      const bool any_false = __ballot(take && !col_get_bool(op.col, row)) != 0;
-      if (leader) {
-        if (any_false) atomicAnd(&op.w0[slot], 0ull);
-        op.seen[slot] = 1;
-      }
+      unsigned long long v = 1;
+      for (uint32_t r = 0; r < R; r++) v &= p0[r];
+      if (!v) atomicAnd(&op.w0[gid], 0ull);
+      op.seen[gid] = 1;
       break;
     }
     case ACC_BOOL_OR: {
-      const bool any_true = __ballot(take && col_get_bool(op.col, row)) != 0;
-      if (leader) {
-        if (any_true) atomicOr(&op.w0[slot], 1ull);
-        op.seen[slot] = 1;
-      }
+      unsigned long long v = 0;
+      for (uint32_t r = 0; r < R; r++) v |= p0[r];
+      if (v) atomicOr(&op.w0[gid], 1ull);
+      op.seen[gid] = 1;
       break;
     }
     case ACC_ANY_ROW: {
-      unsigned long long v = take ? seq : ~0ull;
-      v = wave_reduce(v, [](unsigned long long a, unsigned long long b) { return a < b ? a : b; });
-      if (leader) atomicMin(&op.w0[slot], v);
+      unsigned long long v = ~0ull;
+      for (uint32_t r = 0; r < R; r++) v = p0[r] < v ? p0[r] : v;
+      if (v != ~0ull) atomicMin(&op.w0[gid], v);
       break;
     }
     default: break;
   }
 }
 
-// ------------------------------------------------------------------ fused find-or-insert + aggregate
-__global__ __launch_bounds__(256) void agg_consume_kernel(AggArgs a) {
+struct AccArgs {
+  KeyCols keys;
+  const KeyStore *store;   // device copy
+  const AggOpDev *ops;     // device copy
+  int32_t naggs;
+  int32_t _pad;
+  int64_t m;               // rows of this pass (positions into `list`, or chunk rows when list == nullptr)
+  const uint32_t *list;    // chunk row of each position, or nullptr for the identity
+  const uint32_t *out_gid; // !FUSED: group of each position (resolve kernel)
+  const unsigned long long *meta;
+  uint32_t mask;
+  uint32_t gid_lo;         // LDS: first group of this sweep
+  uint32_t G;              // LDS: groups held by the partial table
+  uint32_t R;              // LDS: replicas (power of two)
+  uint32_t nwords, nseen;  // LDS: planes
+  unsigned long long seq_base;  // global arrival number of row 0 of this chunk
+  uint32_t *miss_list;     // FUSED: chunk rows whose group does not exist yet
+  unsigned int *counters;  // [0] new groups, [1] deferred / missed rows
+};
+
+// FUSED: hash -> index lookup -> accumulate (misses are listed);  !FUSED: the group comes from out_gid.
+// LDS: accumulate into the workgroup's partial table and merge it at the end;  !LDS: HBM atomics.
+template <bool FUSED, bool LDS>
+__global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
+  extern __shared__ unsigned long long lds_words[];
+  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * a.G * a.R);
   const KeyStore &store = *a.store;
+  if (LDS) {
+    const uint32_t per = a.G * a.R;
+    for (int f = 0; f < a.naggs; f++) {
+      const AggOpDev &op = a.ops[f];
+      if (op.lw0 >= 0) {
+        const unsigned long long init = acc_init_w0(op.kind);
+        for (uint32_t i = threadIdx.x; i < per; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * per + i] = init;
+      }
+      if (op.lw1 >= 0)
+        for (uint32_t i = threadIdx.x; i < per; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * per + i] = 0ull;
+    }
+    for (uint32_t i = threadIdx.x; i < a.nseen * per; i += blockDim.x) lds_seen[i] = 0;
+    __syncthreads();
+  }
+  const uint32_t rep = threadIdx.x & (a.R - 1);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  const int64_t nround = (a.n + 63) & ~int64_t(63);  // keep whole waves in the loop (wave-level collectives below)
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < nround; row += stride) {
-    bool active = row < a.n;
-    if (active && a.only_deferred) active = a.deferred[row] != 0;
-    uint32_t slot = kNoSlot;
-    bool is_new = false, gave_up = false;
-    uint32_t h = 0;
+  const int64_t mround = (a.m + 63) & ~int64_t(63);  // whole waves stay in the loop (wave-level collectives below)
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < mround; i += stride) {
+    const bool active = i < a.m;
+    const int64_t row = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
+    uint32_t gid = kGidDefer;
     if (active) {
-      h = hash_row32(a.keys, row, 1u);
-      uint32_t idx = h & a.mask;
-      for (int probes = 0;; probes++) {
-        uint32_t cur = __hip_atomic_load(&a.slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == kSlotEmpty) {
-          const uint32_t old = atomicCAS(&a.slots[idx], kSlotEmpty, static_cast<uint32_t>(row));
-          if (old == kSlotEmpty) {
-            slot = idx;
-            is_new = true;
-            break;
-          }
-          cur = old;
-        }
-        const bool eq = cur == kSlotOccupied ? key_equals_store(a.keys, row, store, idx)
-                                             : (cur == static_cast<uint32_t>(row) ||
-                                                keys_equal(a.keys, row, a.keys, static_cast<int64_t>(cur), true));
-        if (eq) {
-          slot = idx;
-          break;
-        }
-        idx = (idx + 1) & a.mask;
-        if (probes >= kMaxProbe) {
-          gave_up = true;
-          break;
-        }
+      if (FUSED) {
+        gid = index_lookup(a.keys, row, store, a.meta, a.mask);
+      } else {
+        gid = a.out_gid[i];
+        if (gid != kGidDefer && (gid & kGidSlotRef)) gid = static_cast<uint32_t>(a.meta[gid & ~kGidSlotRef]);
       }
     }
-    // bookkeeping: representatives of new groups and deferred rows (wave-aggregated counters)
-    {
-      const uint64_t m_new = __ballot(is_new);
-      if (m_new) {
+    if (FUSED) {
+      const bool miss = active && gid == kGidDefer;
+      const uint64_t mm = __ballot(miss);
+      if (mm) {
+        const int lead = __ffsll(static_cast<long long>(mm)) - 1;
         unsigned int base = 0;
-        if (lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m_new)) - 1))
-          base = atomicAdd(&a.counters[0], static_cast<unsigned int>(popc64(m_new)));
-        base = __shfl(base, __ffsll(static_cast<long long>(m_new)) - 1, 64);
-        if (is_new) {
-          const unsigned int p = base + rank_in_mask(m_new);
-          a.rep_rows[p] = static_cast<uint32_t>(row);
-          a.rep_slots[p] = slot;
-          a.hstore[slot] = h;
-        }
+        if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(mm)));
+        base = __shfl(base, lead, 64);
+        if (miss) a.miss_list[base + rank_in_mask(mm)] = static_cast<uint32_t>(row);
       }
-      const uint64_t m_def = __ballot(gave_up);
-      if (m_def) {
-        if (lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(m_def)) - 1))
-          atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(m_def)));
-      }
-      if (active) a.deferred[row] = gave_up ? 1 : 0;
     }
-    if (a.slot_of_row != nullptr && row < a.n) a.slot_of_row[row] = active ? slot : kNoSlot;
+    if (gid == kGidDefer) continue;
     const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row);
-    if (!a.combine) {
-      if (slot != kNoSlot)
-        for (int f = 0; f < a.naggs; f++) accumulate_direct(a.ops[f], row, slot, seq);
-    } else {
-      uint64_t todo = __ballot(slot != kNoSlot);
-      while (todo) {  // wave-uniform loop: one iteration per distinct slot in the wave
-        const int lead = __ffsll(static_cast<long long>(todo)) - 1;
-        const uint32_t s = __shfl(slot, lead, 64);
-        const uint64_t peers = __ballot(slot == s);
-        const bool mine = slot == s;
-        const bool leader = lane_id() == static_cast<uint32_t>(lead);
-        for (int f = 0; f < a.naggs; f++) accumulate_combined(a.ops[f], row < a.n ? row : 0, s, seq, mine, leader);
-        todo &= ~peers;
+    if (LDS) {
+      const uint32_t g = gid - a.gid_lo;
+      if (g >= a.G) continue;  // another sweep's group (unsigned compare covers gid < gid_lo)
+      for (int f = 0; f < a.naggs; f++) {
+        const AggOpDev &op = a.ops[f];
+        unsigned long long *w0 = lds_words + (static_cast<size_t>(op.lw0) * a.G + g) * a.R + rep;
+        unsigned long long *w1 = lds_words + (static_cast<size_t>(op.lw1) * a.G + g) * a.R + rep;
+        uint8_t *seen = lds_seen + (static_cast<size_t>(op.lseen) * a.G + g) * a.R + rep;
+        accum_row(op, row, seq, w0, w1, seen);
       }
+    } else {
+      for (int f = 0; f < a.naggs; f++) {
+        const AggOpDev &op = a.ops[f];
+        accum_row(op, row, seq, op.w0 + gid, op.w1 + gid, op.seen + gid);
+      }
+    }
+  }
+  if (LDS) {
+    __syncthreads();
+    const uint32_t pairs = a.G * static_cast<uint32_t>(a.naggs);
+    for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
+      const uint32_t f = t / a.G, g = t - f * a.G;
+      lds_flush_op(a.ops[f], lds_words, lds_seen, a.G, a.R, g, a.gid_lo + g);
     }
   }
 }
 
-// copy the keys of newly claimed slots into the key store and mark them OCCUPIED
-__global__ __launch_bounds__(256) void agg_fixup_kernel(KeyCols keys, const KeyStore *store_p, unsigned int nrep,
-                                                        const uint32_t *__restrict__ rep_rows,
-                                                        const uint32_t *__restrict__ rep_slots,
-                                                        uint32_t *__restrict__ slots,
-                                                        unsigned long long *__restrict__ b_tails) {
-  const KeyStore &st = *store_p;
+// ------------------------------------------------------------------ find-or-insert (rows whose group may not exist yet)
+struct ResolveArgs {
+  KeyCols keys;
+  const KeyStore *store;
+  int64_t m;
+  const uint32_t *list;
+  unsigned long long *meta;
+  uint32_t mask;
+  uint32_t _pad;
+  uint32_t *out_gid;              // [m]
+  uint32_t *rep_pos, *rep_slot;   // [new groups]: claimant position / index slot
+  unsigned long long *rep_word;   // [new groups]: {upper:32 | idx hash:32}
+  uint32_t *next_list;            // deferred chunk rows
+  unsigned int *counters;         // [0] new groups, [1] deferred rows
+};
+__global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
+  const KeyStore &store = *a.store;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t mround = (a.m + 63) & ~int64_t(63);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < mround; i += stride) {
+    const bool active = i < a.m;
+    const int64_t row = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
+    uint32_t res = kGidDefer, slot = 0;
+    bool is_new = false;
+    RowHash rh{0, 0};
+    if (active) {
+      rh = agg_hash(a.keys, row);
+      uint32_t idx = rh.idx & a.mask;
+      for (int probes = 0; probes < kMaxProbe; probes++) {
+        unsigned long long e = __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == kMetaEmpty) {
+          const unsigned long long claim = (static_cast<unsigned long long>(rh.upper | kClaimBit) << 32) | static_cast<uint32_t>(i);
+          const unsigned long long old = atomicCAS(&a.meta[idx], kMetaEmpty, claim);
+          if (old == kMetaEmpty) {
+            is_new = true;
+            slot = idx;
+            res = kGidSlotRef | idx;
+            break;
+          }
+          e = old;
+        }
+        const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
+        if ((up & ~kClaimBit) == rh.upper) {
+          if (up & kClaimBit) {
+            const int64_t other = a.list != nullptr ? static_cast<int64_t>(a.list[lo]) : static_cast<int64_t>(lo);
+            if (keys_equal(a.keys, row, a.keys, other, true)) {
+              res = kGidSlotRef | idx;
+              break;
+            }
+          } else if (key_equals_store(a.keys, row, store, lo, rh.upper & 0xFFu)) {
+            res = lo;
+            break;
+          }
+        }
+        idx = (idx + 1) & a.mask;
+      }
+    }
+    const uint64_t m_new = __ballot(is_new);
+    if (m_new) {
+      const int lead = __ffsll(static_cast<long long>(m_new)) - 1;
+      unsigned int base = 0;
+      if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[0], static_cast<unsigned int>(popc64(m_new)));
+      base = __shfl(base, lead, 64);
+      if (is_new) {
+        const unsigned int p = base + rank_in_mask(m_new);
+        a.rep_pos[p] = static_cast<uint32_t>(i);
+        a.rep_slot[p] = slot;
+        a.rep_word[p] = (static_cast<unsigned long long>(rh.upper) << 32) | rh.idx;
+      }
+    }
+    const bool deferred = active && res == kGidDefer;
+    const uint64_t m_def = __ballot(deferred);
+    if (m_def) {
+      const int lead = __ffsll(static_cast<long long>(m_def)) - 1;
+      unsigned int base = 0;
+      if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(m_def)));
+      base = __shfl(base, lead, 64);
+      if (deferred) a.next_list[base + rank_in_mask(m_def)] = static_cast<uint32_t>(row);
+    }
+    if (active) a.out_gid[i] = res;
+  }
+}
+
+// new groups: gid = g0 + p; copy the claimant's key into the key store, initialise the
+// accumulators, publish the gid in the index entry
+struct FixupArgs {
+  KeyCols keys;
+  const KeyStore *store;
+  const AggOpDev *ops;
+  int32_t naggs;
+  uint32_t nnew;
+  uint32_t g0;
+  uint32_t _pad;
+  const uint32_t *list;
+  const uint32_t *rep_pos, *rep_slot;
+  const unsigned long long *rep_word;
+  unsigned long long *meta;
+  unsigned long long *gword;
+  unsigned long long *b_tails;
+  uint64_t *const *any_off;  // [naggs] BYTES ANY_NOT_NULL value store (or nullptr entries)
+  uint32_t *const *any_len;
+};
+__global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
+  const KeyStore &st = *a.store;
   const unsigned int stride = gridDim.x * blockDim.x;
-  for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrep; r += stride) {
-    const int64_t row = rep_rows[r];
-    const uint32_t slot = rep_slots[r];
-    for (int c = 0; c < keys.n; c++) {
-      const DCol &x = keys.c[c];
+  for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.nnew; p += stride) {
+    const uint32_t gid = a.g0 + p;
+    const uint32_t pos = a.rep_pos[p];
+    const int64_t row = a.list != nullptr ? static_cast<int64_t>(a.list[pos]) : static_cast<int64_t>(pos);
+    for (int c = 0; c < a.keys.n; c++) {
+      const DCol &x = a.keys.c[c];
       const KeyStoreCol &s = st.c[c];
       const bool isnull = col_is_null(x, row);
-      s.present[slot] = isnull ? 0 : 1;
+      s.present[gid] = isnull ? 0 : 1;
       switch (x.type) {
-        case CRGPU_BOOL: s.data[slot] = isnull ? 0 : static_cast<uint8_t>(col_get_bool(x, row)); break;
-        case CRGPU_INT16: reinterpret_cast<int16_t *>(s.data)[slot] = isnull ? 0 : reinterpret_cast<const int16_t *>(x.data)[row]; break;
-        case CRGPU_INT32: reinterpret_cast<int32_t *>(s.data)[slot] = isnull ? 0 : reinterpret_cast<const int32_t *>(x.data)[row]; break;
-        case CRGPU_INT64: reinterpret_cast<int64_t *>(s.data)[slot] = isnull ? 0 : reinterpret_cast<const int64_t *>(x.data)[row]; break;
-        case CRGPU_FLOAT64: reinterpret_cast<double *>(s.data)[slot] = isnull ? 0.0 : col_get_f64(x, row); break;
+        case CRGPU_BOOL: s.data[gid] = isnull ? 0 : static_cast<uint8_t>(col_get_bool(x, row)); break;
+        case CRGPU_INT16: reinterpret_cast<int16_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int16_t *>(x.data)[row]; break;
+        case CRGPU_INT32: reinterpret_cast<int32_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int32_t *>(x.data)[row]; break;
+        case CRGPU_INT64: reinterpret_cast<int64_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int64_t *>(x.data)[row]; break;
+        case CRGPU_FLOAT64: reinterpret_cast<double *>(s.data)[gid] = isnull ? 0.0 : col_get_f64(x, row); break;
         case CRGPU_BYTES: {
           uint32_t a0 = x.offsets[row], len = isnull ? 0 : x.offsets[row + 1] - a0;
-          unsigned long long off = len ? atomicAdd(&b_tails[c], static_cast<unsigned long long>(len)) : 0ull;
-          s.b_off[slot] = off;
-          s.b_len[slot] = len;
+          unsigned long long off = len ? atomicAdd(&a.b_tails[c], static_cast<unsigned long long>(len)) : 0ull;
+          s.b_off[gid] = off;
+          s.b_len[gid] = len;
           const uint8_t *src = reinterpret_cast<const uint8_t *>(x.data) + a0;
           for (uint32_t t = 0; t < len; t++) s.b_buf[off + t] = src[t];
           break;
@@ -420,7 +578,31 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(KeyCols keys, const KeyS
         default: break;
       }
     }
-    slots[slot] = kSlotOccupied;
+    for (int f = 0; f < a.naggs; f++) {
+      const AggOpDev &op = a.ops[f];
+      if (op.w0 != nullptr) op.w0[gid] = acc_init_w0(op.kind);
+      if (op.w1 != nullptr) op.w1[gid] = 0ull;
+      if (op.seen != nullptr) op.seen[gid] = 0;
+      if (a.any_off[f] != nullptr) {
+        a.any_off[f][gid] = 0;
+        a.any_len[f][gid] = 0;
+      }
+    }
+    const unsigned long long w = a.rep_word[p];
+    a.gword[gid] = w;
+    a.meta[a.rep_slot[p]] = (w & 0xFFFFFFFF00000000ull) | gid;
+  }
+}
+
+// rebuild the index at a new capacity from the per-group hash words
+__global__ __launch_bounds__(256) void agg_reindex_kernel(const unsigned long long *__restrict__ gword, uint32_t ngroups,
+                                                          unsigned long long *__restrict__ meta, uint32_t mask) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < ngroups; gid += stride) {
+    const unsigned long long w = gword[gid];
+    const unsigned long long e = (w & 0xFFFFFFFF00000000ull) | gid;
+    uint32_t idx = static_cast<uint32_t>(w) & mask;
+    while (atomicCAS(&meta[idx], kMetaEmpty, e) != kMetaEmpty) idx = (idx + 1) & mask;
   }
 }
 
@@ -430,10 +612,11 @@ struct AnyFixArgs {
   const AggOpDev *ops;
   int32_t naggs;
   int32_t _pad;
-  int64_t n;
+  int64_t m;
+  const uint32_t *list;
+  const uint32_t *out_gid;
+  const unsigned long long *meta;
   unsigned long long seq_base;
-  const uint32_t *slot_of_row;
-  // BYTES values of ANY_ROW ops: indexed by op
   uint64_t *const *any_off;
   uint32_t *const *any_len;
   uint8_t *const *any_buf;
@@ -441,82 +624,38 @@ struct AnyFixArgs {
 };
 __global__ __launch_bounds__(256) void agg_any_fixup_kernel(AnyFixArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < a.n; row += stride) {
-    const uint32_t slot = a.slot_of_row[row];
-    if (slot == kNoSlot) continue;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.m; i += stride) {
+    uint32_t gid = a.out_gid[i];
+    if (gid == kGidDefer) continue;
+    if (gid & kGidSlotRef) gid = static_cast<uint32_t>(a.meta[gid & ~kGidSlotRef]);
+    const int64_t row = a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i;
     for (int f = 0; f < a.naggs; f++) {
       const AggOpDev &op = a.ops[f];
       if (op.kind != ACC_ANY_ROW) continue;
-      if (op.w0[slot] != a.seq_base + static_cast<unsigned long long>(row)) continue;
+      if (op.w0[gid] != a.seq_base + static_cast<unsigned long long>(row)) continue;
       switch (op.col.type) {
-        case CRGPU_BOOL: op.w1[slot] = col_get_bool(op.col, row); break;
-        case CRGPU_FLOAT64: op.w1[slot] = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); break;
+        case CRGPU_BOOL: op.w1[gid] = col_get_bool(op.col, row); break;
+        case CRGPU_FLOAT64: op.w1[gid] = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); break;
         case CRGPU_BYTES: {
           uint32_t a0 = op.col.offsets[row], len = op.col.offsets[row + 1] - a0;
           unsigned long long off = len ? atomicAdd(&a.any_tails[f], static_cast<unsigned long long>(len)) : 0ull;
-          a.any_off[f][slot] = off;
-          a.any_len[f][slot] = len;
+          a.any_off[f][gid] = off;
+          a.any_len[f][gid] = len;
           const uint8_t *src = reinterpret_cast<const uint8_t *>(op.col.data) + a0;
           for (uint32_t t = 0; t < len; t++) a.any_buf[f][off + t] = src[t];
           break;
         }
-        default: op.w1[slot] = static_cast<unsigned long long>(col_get_int(op.col, row)); break;
+        default: op.w1[gid] = static_cast<unsigned long long>(col_get_int(op.col, row)); break;
       }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *p, uint64_t n, unsigned long long v) {
-  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
-
-// rebuild into a larger table: every OCCUPIED slot moves with its key-store entry and accumulators
-struct RehashArgs {
-  const uint32_t *old_slots;
-  const uint32_t *old_h;
-  uint32_t old_cap;
-  uint32_t *new_slots;
-  uint32_t *new_h;
-  uint32_t new_mask;
-  uint32_t *move_to;  // [old_cap]: new slot of each old slot (kNoSlot if empty)
-};
-__global__ __launch_bounds__(256) void agg_rehash_kernel(RehashArgs a) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < a.old_cap; s += stride) {
-    uint32_t to = kNoSlot;
-    if (a.old_slots[s] == kSlotOccupied) {
-      const uint32_t h = a.old_h[s];
-      uint32_t idx = h & a.new_mask;
-      while (atomicCAS(&a.new_slots[idx], kSlotEmpty, kSlotOccupied) != kSlotEmpty) idx = (idx + 1) & a.new_mask;
-      a.new_h[idx] = h;
-      to = idx;
-    }
-    a.move_to[s] = to;
-  }
-}
-template <typename T>
-__global__ __launch_bounds__(256) void move_slots_kernel(const T *__restrict__ src, T *__restrict__ dst,
-                                                         const uint32_t *__restrict__ move_to, uint32_t old_cap) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < old_cap; s += stride) {
-    const uint32_t to = move_to[s];
-    if (to != kNoSlot) dst[to] = src[s];
-  }
-}
-
-__global__ __launch_bounds__(256) void occupied_flags_kernel(const uint32_t *__restrict__ slots, uint32_t cap,
-                                                             uint8_t *__restrict__ flags) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += stride) flags[s] = slots[s] == kSlotOccupied;
-}
-
-// finalisation: one output value per group (Flush, e.g. hash_sum_agg.eg.go:562-572)
+// finalisation: one output value per group (Flush, e.g. hash_sum_agg.eg.go:562-572); group g is row g
 struct FinalArgs {
   AggOpDev op;
   int32_t out_type;
   int32_t _pad;
-  const int32_t *slot_list;
   int64_t ngroups;
   uint8_t *out_data;
   uint8_t *out_present;  // byte per group
@@ -526,8 +665,7 @@ struct FinalArgs {
 };
 __global__ __launch_bounds__(256) void agg_finalize_kernel(FinalArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < a.ngroups; g += stride) {
-    const uint32_t s = static_cast<uint32_t>(a.slot_list[g]);
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < a.ngroups; s += stride) {
     uint8_t present = 1;
     unsigned long long v = 0;
     switch (a.op.kind) {
@@ -573,37 +711,33 @@ __global__ __launch_bounds__(256) void agg_finalize_kernel(FinalArgs a) {
     }
     if (!present) v = 0;
     switch (a.out_type) {
-      case CRGPU_BOOL: a.out_data[g] = static_cast<uint8_t>(v != 0); break;
-      case CRGPU_INT16: reinterpret_cast<uint16_t *>(a.out_data)[g] = static_cast<uint16_t>(v); break;
-      case CRGPU_INT32: reinterpret_cast<uint32_t *>(a.out_data)[g] = static_cast<uint32_t>(v); break;
-      default: reinterpret_cast<unsigned long long *>(a.out_data)[g] = v; break;
+      case CRGPU_BOOL: a.out_data[s] = static_cast<uint8_t>(v != 0); break;
+      case CRGPU_INT16: reinterpret_cast<uint16_t *>(a.out_data)[s] = static_cast<uint16_t>(v); break;
+      case CRGPU_INT32: reinterpret_cast<uint32_t *>(a.out_data)[s] = static_cast<uint32_t>(v); break;
+      default: reinterpret_cast<unsigned long long *>(a.out_data)[s] = v; break;
     }
-    a.out_present[g] = present;
+    a.out_present[s] = present;
   }
 }
 
-// BYTES outputs (ANY_NOT_NULL of a BYTES group key or column): build a temporary
-// {offsets64, len, buf} view as an Arrow column and reuse gather_bytes.
-__global__ __launch_bounds__(256) void bytes_view_kernel(const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-                                                         const uint8_t *__restrict__ present_in, bool any_row,
-                                                         const unsigned long long *__restrict__ w0,
-                                                         const int32_t *__restrict__ slot_list, int64_t ngroups,
-                                                         uint32_t *__restrict__ lens_out, uint8_t *__restrict__ present_out) {
+// BYTES outputs (ANY_NOT_NULL of a BYTES group key or column): lengths -> offsets -> payload copy
+__global__ __launch_bounds__(256) void bytes_view_kernel(const uint32_t *__restrict__ len, const uint8_t *__restrict__ present_in,
+                                                         bool any_row, const unsigned long long *__restrict__ w0,
+                                                         int64_t ngroups, uint32_t *__restrict__ lens_out,
+                                                         uint8_t *__restrict__ present_out) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
-    const uint32_t s = static_cast<uint32_t>(slot_list[g]);
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < ngroups; s += stride) {
     const uint8_t p = any_row ? (w0[s] != ~0ull) : present_in[s];
-    lens_out[g] = p ? len[s] : 0;
-    present_out[g] = p;
+    lens_out[s] = p ? len[s] : 0;
+    present_out[s] = p;
   }
 }
-__global__ __launch_bounds__(256) void bytes_copy_slots_kernel(const uint64_t *__restrict__ off, const uint8_t *__restrict__ buf,
-                                                               const int32_t *__restrict__ slot_list, int64_t ngroups,
-                                                               const uint32_t *__restrict__ dst_off, uint8_t *__restrict__ dst) {
+__global__ __launch_bounds__(256) void bytes_copy_groups_kernel(const uint64_t *__restrict__ off, const uint8_t *__restrict__ buf,
+                                                                int64_t ngroups, const uint32_t *__restrict__ dst_off,
+                                                                uint8_t *__restrict__ dst) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ngroups; g += stride) {
-    const uint32_t s = static_cast<uint32_t>(slot_list[g]);
-    const uint32_t o = dst_off[g], len = dst_off[g + 1] - o;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < ngroups; s += stride) {
+    const uint32_t o = dst_off[s], len = dst_off[s + 1] - o;
     const uint8_t *src = buf + off[s];
     for (uint32_t t = 0; t < len; t++) dst[o + t] = src[t];
   }
@@ -632,6 +766,8 @@ using namespace crgpu;
 // ====================================================================== handle
 struct AggOpHost {
   int func = 0, col = -1, filter_col = -1, kind = 0, key_idx = -1, in_type = 0, out_type = 0;
+  int lw0 = -1, lw1 = -1, lseen = -1;
+  bool has_w0 = false, has_w1 = false, has_seen = false;
   DevBuf w0, w1, seen;
   // BYTES value store for ACC_ANY_ROW
   DevBuf any_off, any_len, any_buf;
@@ -641,119 +777,31 @@ struct AggOpHost {
 struct crgpu_agg {
   std::vector<int> types, group_cols;
   std::vector<AggOpHost> ops;
-  bool need_slot_of_row = false;
+  bool need_any_fix = false;
+  bool bytes_keys = false;
+  int lds_words = 0, lds_seen = 0;  // planes of the LDS partial table
+  int acc_words = 0;                // HBM atomics per row on the fallback path (cost model)
 
+  // hash index
   uint32_t cap = 0;
+  DevBuf meta;
+  // per-group arrays
   int64_t ngroups = 0;
-  unsigned long long seq = 0;
-  DevBuf slots, hstore;
-  // key store
+  size_t gcap = 0;
+  DevBuf gword;
   struct KS { DevBuf data, present, b_off, b_len, b_buf; uint64_t tail = 0; };
   std::vector<KS> ks;
+
+  unsigned long long seq = 0;
+  double new_ratio = 1.0;  // new groups per input row in the previous chunk (1: unknown)
+  bool descriptors_dirty = true;
+
   DevBuf store_dev, ops_dev, tails_dev, any_tails_dev, any_ptrs_dev;
-  DevBuf deferred, counters, rep_rows, rep_slots, slot_of_row, move_to, flags, slot_list, scratch, err_dev;
+  DevBuf counters, out_gid, list_a, list_b, rep_pos, rep_slot, rep_word, scratch, err_dev;
   DevBuf lens_tmp, offs64_tmp, present_tmp;
   std::vector<OutCol> out;
   std::vector<crgpu_dcol> views;
 };
-
-static unsigned long long acc_init_w0(int kind) {
-  switch (kind) {
-    case ACC_MIN_I64: return 0x7FFFFFFFFFFFFFFFull;
-    case ACC_MAX_I64: return 0x8000000000000000ull;
-    case ACC_MIN_F64: return ~0ull;
-    case ACC_BOOL_AND: return 1ull;
-    case ACC_ANY_ROW: return ~0ull;
-    default: return 0ull;
-  }
-}
-
-static crgpu_status fill_u64(void *p, uint64_t n, unsigned long long v) {
-  if (n == 0) return CRGPU_OK;
-  if (v == 0) {
-    CRGPU_HIP(hipMemsetAsync(p, 0, n * 8, stream()));
-    return CRGPU_OK;
-  }
-  hipLaunchKernelGGL(fill_u64_kernel, dim3(grid_for(static_cast<int64_t>(n), 256)), dim3(256), 0, stream(),
-                     static_cast<unsigned long long *>(p), n, v);
-  CRGPU_HIP(hipGetLastError());
-  return CRGPU_OK;
-}
-
-// (Re)allocate per-slot arrays for capacity `cap` into fresh buffers and initialise them.
-struct SlotArrays {
-  DevBuf slots, hstore;
-  std::vector<DevBuf> w0, w1, seen, any_off, any_len;
-  std::vector<DevBuf> k_data, k_present, k_off, k_len;
-};
-
-static crgpu_status alloc_slot_arrays(crgpu_agg *a, uint32_t cap, SlotArrays &sa) {
-  CRGPU_TRY(sa.slots.ensure(static_cast<size_t>(cap) * 4));
-  CRGPU_TRY(sa.hstore.ensure(static_cast<size_t>(cap) * 4));
-  CRGPU_HIP(hipMemsetAsync(sa.slots.p, 0xFF, static_cast<size_t>(cap) * 4, stream()));
-  const size_t nops = a->ops.size(), nk = a->group_cols.size();
-  sa.w0 = std::vector<DevBuf>(nops);
-  sa.w1 = std::vector<DevBuf>(nops);
-  sa.seen = std::vector<DevBuf>(nops);
-  sa.any_off = std::vector<DevBuf>(nops);
-  sa.any_len = std::vector<DevBuf>(nops);
-  for (size_t f = 0; f < nops; f++) {
-    const AggOpHost &op = a->ops[f];
-    if (op.kind == ACC_ANY_KEY) continue;
-    CRGPU_TRY(sa.w0[f].ensure(static_cast<size_t>(cap) * 8));
-    CRGPU_TRY(fill_u64(sa.w0[f].p, cap, acc_init_w0(op.kind)));
-    CRGPU_TRY(sa.w1[f].ensure(static_cast<size_t>(cap) * 8));
-    CRGPU_HIP(hipMemsetAsync(sa.w1[f].p, 0, static_cast<size_t>(cap) * 8, stream()));
-    CRGPU_TRY(sa.seen[f].ensure(cap));
-    CRGPU_HIP(hipMemsetAsync(sa.seen[f].p, 0, cap, stream()));
-    if (op.kind == ACC_ANY_ROW && op.in_type == CRGPU_BYTES) {
-      CRGPU_TRY(sa.any_off[f].ensure(static_cast<size_t>(cap) * 8));
-      CRGPU_TRY(sa.any_len[f].ensure(static_cast<size_t>(cap) * 4));
-      CRGPU_HIP(hipMemsetAsync(sa.any_off[f].p, 0, static_cast<size_t>(cap) * 8, stream()));
-      CRGPU_HIP(hipMemsetAsync(sa.any_len[f].p, 0, static_cast<size_t>(cap) * 4, stream()));
-    }
-  }
-  sa.k_data = std::vector<DevBuf>(nk);
-  sa.k_present = std::vector<DevBuf>(nk);
-  sa.k_off = std::vector<DevBuf>(nk);
-  sa.k_len = std::vector<DevBuf>(nk);
-  for (size_t k = 0; k < nk; k++) {
-    const int t = a->types[a->group_cols[k]];
-    CRGPU_TRY(sa.k_present[k].ensure(cap));
-    CRGPU_HIP(hipMemsetAsync(sa.k_present[k].p, 0, cap, stream()));
-    if (t == CRGPU_BYTES) {
-      CRGPU_TRY(sa.k_off[k].ensure(static_cast<size_t>(cap) * 8));
-      CRGPU_TRY(sa.k_len[k].ensure(static_cast<size_t>(cap) * 4));
-    } else {
-      CRGPU_TRY(sa.k_data[k].ensure(static_cast<size_t>(cap) * type_width(t)));
-    }
-  }
-  return CRGPU_OK;
-}
-
-static void swap_buf(DevBuf &a, DevBuf &b) {
-  std::swap(a.p, b.p);
-  std::swap(a.cap, b.cap);
-}
-
-static void install_slot_arrays(crgpu_agg *a, SlotArrays &sa, uint32_t cap) {
-  swap_buf(a->slots, sa.slots);
-  swap_buf(a->hstore, sa.hstore);
-  for (size_t f = 0; f < a->ops.size(); f++) {
-    swap_buf(a->ops[f].w0, sa.w0[f]);
-    swap_buf(a->ops[f].w1, sa.w1[f]);
-    swap_buf(a->ops[f].seen, sa.seen[f]);
-    swap_buf(a->ops[f].any_off, sa.any_off[f]);
-    swap_buf(a->ops[f].any_len, sa.any_len[f]);
-  }
-  for (size_t k = 0; k < a->ks.size(); k++) {
-    swap_buf(a->ks[k].data, sa.k_data[k]);
-    swap_buf(a->ks[k].present, sa.k_present[k]);
-    swap_buf(a->ks[k].b_off, sa.k_off[k]);
-    swap_buf(a->ks[k].b_len, sa.k_len[k]);
-  }
-  a->cap = cap;
-}
 
 // upload device descriptors (ops + key store) for the current buffers and the given chunk columns
 static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *chunk) {
@@ -765,6 +813,9 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
     d.kind = h.kind;
     d.has_filter = h.filter_col >= 0;
     d.key_idx = h.key_idx;
+    d.lw0 = h.lw0;
+    d.lw1 = h.lw1;
+    d.lseen = h.lseen;
     if (chunk != nullptr) {
       if (h.col >= 0) d.col = (*chunk)[h.col];
       if (h.filter_col >= 0) d.filter = (*chunk)[h.filter_col];
@@ -791,66 +842,67 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
   }
   CRGPU_TRY(a->store_dev.ensure(sizeof(KeyStore)));
   CRGPU_HIP(hipMemcpyAsync(a->store_dev.p, &st, sizeof(KeyStore), hipMemcpyHostToDevice, stream()));
-  CRGPU_HIP(hipStreamSynchronize(stream()));  // `ops`/`st` are stack/heap temporaries
+  // pointer table of the BYTES ANY_NOT_NULL value stores: [off | len | buf] x naggs
+  const size_t nops = a->ops.size();
+  std::vector<void *> ptrs(nops * 3, nullptr);
+  for (size_t f = 0; f < nops; f++) {
+    ptrs[f] = a->ops[f].any_off.p;
+    ptrs[nops + f] = a->ops[f].any_len.p;
+    ptrs[2 * nops + f] = a->ops[f].any_buf.p;
+  }
+  CRGPU_TRY(a->any_ptrs_dev.ensure(ptrs.size() * 8));
+  CRGPU_HIP(hipMemcpyAsync(a->any_ptrs_dev.p, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, stream()));
+  CRGPU_HIP(hipStreamSynchronize(stream()));  // the sources are stack/heap temporaries
+  a->descriptors_dirty = false;
   return CRGPU_OK;
 }
 
-static crgpu_status agg_grow(crgpu_agg *a, uint32_t new_cap) {
-  SlotArrays sa;
-  CRGPU_TRY(alloc_slot_arrays(a, new_cap, sa));
-  if (a->cap > 0 && a->ngroups > 0) {
-    CRGPU_TRY(a->move_to.ensure(static_cast<size_t>(a->cap) * 4));
-    RehashArgs r{a->slots.as<uint32_t>(), a->hstore.as<uint32_t>(), a->cap, sa.slots.as<uint32_t>(),
-                 sa.hstore.as<uint32_t>(), new_cap - 1, a->move_to.as<uint32_t>()};
-    const int grid = grid_for(a->cap, 256);
-    hipLaunchKernelGGL(agg_rehash_kernel, dim3(grid), dim3(256), 0, stream(), r);
-    const uint32_t *mv = a->move_to.as<uint32_t>();
-    auto mv64 = [&](DevBuf &src, DevBuf &dst) {
-      if (src.p && dst.p)
-        hipLaunchKernelGGL(move_slots_kernel<unsigned long long>, dim3(grid), dim3(256), 0, stream(),
-                           src.as<unsigned long long>(), dst.as<unsigned long long>(), mv, a->cap);
-    };
-    auto mv32 = [&](DevBuf &src, DevBuf &dst) {
-      if (src.p && dst.p)
-        hipLaunchKernelGGL(move_slots_kernel<uint32_t>, dim3(grid), dim3(256), 0, stream(), src.as<uint32_t>(),
-                           dst.as<uint32_t>(), mv, a->cap);
-    };
-    auto mv16 = [&](DevBuf &src, DevBuf &dst) {
-      if (src.p && dst.p)
-        hipLaunchKernelGGL(move_slots_kernel<uint16_t>, dim3(grid), dim3(256), 0, stream(), src.as<uint16_t>(),
-                           dst.as<uint16_t>(), mv, a->cap);
-    };
-    auto mv8 = [&](DevBuf &src, DevBuf &dst) {
-      if (src.p && dst.p)
-        hipLaunchKernelGGL(move_slots_kernel<uint8_t>, dim3(grid), dim3(256), 0, stream(), src.as<uint8_t>(),
-                           dst.as<uint8_t>(), mv, a->cap);
-    };
-    for (size_t f = 0; f < a->ops.size(); f++) {
-      mv64(a->ops[f].w0, sa.w0[f]);
-      mv64(a->ops[f].w1, sa.w1[f]);
-      mv8(a->ops[f].seen, sa.seen[f]);
-      mv64(a->ops[f].any_off, sa.any_off[f]);
-      mv32(a->ops[f].any_len, sa.any_len[f]);
+// per-group arrays: capacity for `need` groups (contents kept; new entries are initialised by the fixup)
+static crgpu_status ensure_groups(crgpu_agg *a, size_t need) {
+  if (need <= a->gcap) return CRGPU_OK;
+  size_t ncap = a->gcap ? a->gcap : 1024;
+  while (ncap < need) ncap *= 2;
+  CRGPU_TRY(a->gword.ensure(ncap * 8, true));
+  for (auto &op : a->ops) {
+    if (op.has_w0) CRGPU_TRY(op.w0.ensure(ncap * 8, true));
+    if (op.has_w1) CRGPU_TRY(op.w1.ensure(ncap * 8, true));
+    if (op.has_seen) CRGPU_TRY(op.seen.ensure(ncap, true));
+    if (op.kind == ACC_ANY_ROW && op.in_type == CRGPU_BYTES) {
+      CRGPU_TRY(op.any_off.ensure(ncap * 8, true));
+      CRGPU_TRY(op.any_len.ensure(ncap * 4, true));
     }
-    for (size_t k = 0; k < a->ks.size(); k++) {
-      const int t = a->types[a->group_cols[k]];
-      mv8(a->ks[k].present, sa.k_present[k]);
-      if (t == CRGPU_BYTES) {
-        mv64(a->ks[k].b_off, sa.k_off[k]);
-        mv32(a->ks[k].b_len, sa.k_len[k]);
-      } else {
-        switch (type_width(t)) {
-          case 1: mv8(a->ks[k].data, sa.k_data[k]); break;
-          case 2: mv16(a->ks[k].data, sa.k_data[k]); break;
-          case 4: mv32(a->ks[k].data, sa.k_data[k]); break;
-          default: mv64(a->ks[k].data, sa.k_data[k]); break;
-        }
-      }
+  }
+  for (size_t k = 0; k < a->ks.size(); k++) {
+    const int t = a->types[a->group_cols[k]];
+    CRGPU_TRY(a->ks[k].present.ensure(ncap, true));
+    if (t == CRGPU_BYTES) {
+      CRGPU_TRY(a->ks[k].b_off.ensure(ncap * 8, true));
+      CRGPU_TRY(a->ks[k].b_len.ensure(ncap * 4, true));
+    } else {
+      CRGPU_TRY(a->ks[k].data.ensure(ncap * type_width(t), true));
     }
+  }
+  a->gcap = ncap;
+  a->descriptors_dirty = true;
+  return CRGPU_OK;
+}
+
+// (re)build the index with `new_cap` entries from the per-group hash words
+static crgpu_status reindex(crgpu_agg *a, uint32_t new_cap) {
+  DevBuf fresh;
+  CRGPU_TRY(fresh.ensure(static_cast<size_t>(new_cap) * 8));
+  CRGPU_HIP(hipMemsetAsync(fresh.p, 0xFF, static_cast<size_t>(new_cap) * 8, stream()));
+  if (a->ngroups > 0) {
+    ProfScope prof("agg_reindex");
+    hipLaunchKernelGGL(agg_reindex_kernel, dim3(grid_for(a->ngroups, 256)), dim3(256), 0, stream(),
+                       a->gword.as<unsigned long long>(), static_cast<uint32_t>(a->ngroups),
+                       fresh.as<unsigned long long>(), new_cap - 1);
     CRGPU_HIP(hipGetLastError());
   }
   CRGPU_HIP(hipStreamSynchronize(stream()));
-  install_slot_arrays(a, sa, new_cap);  // old buffers are released when `sa` goes out of scope
+  std::swap(a->meta.p, fresh.p);
+  std::swap(a->meta.cap, fresh.cap);
+  a->cap = new_cap;
   return CRGPU_OK;
 }
 
@@ -868,6 +920,7 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
   for (int i = 0; i < spec->n_group; i++) {
     if (spec->group_cols[i] < 0 || spec->group_cols[i] >= spec->n_cols) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: grouping column ordinal out of range");
     a->group_cols.push_back(spec->group_cols[i]);
+    if (a->types[spec->group_cols[i]] == CRGPU_BYTES) a->bytes_keys = true;
   }
   a->ks = std::vector<crgpu_agg::KS>(spec->n_group);
   a->ops = std::vector<AggOpHost>(spec->n_aggs);
@@ -912,17 +965,43 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
         if (d.filter_col < 0)
           for (int k = 0; k < spec->n_group; k++)
             if (spec->group_cols[k] == d.col) { op.kind = ACC_ANY_KEY; op.key_idx = k; break; }
-        if (op.kind == ACC_ANY_ROW) a->need_slot_of_row = true;
+        if (op.kind == ACC_ANY_ROW) a->need_any_fix = true;
         break;
       }
       default: return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: aggregate function outside the GPU path");
     }
+    // accumulator words: HBM arrays and planes of the LDS partial table
+    op.has_w0 = op.kind != ACC_ANY_KEY;
+    op.has_w1 = op.kind == ACC_AVG_F64 || op.kind == ACC_SUM_I128 || op.kind == ACC_ANY_ROW;
+    op.has_seen = op.kind == ACC_SUM_F64 || op.kind == ACC_SUM_I128 || (op.kind >= ACC_MIN_I64 && op.kind <= ACC_BOOL_OR);
+    if (op.has_w0) {
+      op.lw0 = a->lds_words++;
+      a->acc_words++;
+    }
+    if (op.kind == ACC_AVG_F64 || op.kind == ACC_SUM_I128) {
+      op.lw1 = a->lds_words++;
+      if (op.kind == ACC_AVG_F64) a->acc_words++;
+    }
+    if (op.has_seen) op.lseen = a->lds_seen++;
   }
   a->out = std::vector<OutCol>(spec->n_aggs);
   a->views.resize(spec->n_aggs);
   CRGPU_TRY(a->counters.ensure(16));
   CRGPU_TRY(a->err_dev.ensure(4));
-  CRGPU_TRY(agg_grow(a.get(), 256));  // hashAggregator starts with 256 buckets too (hash_aggregator.go:217)
+  CRGPU_TRY(a->tails_dev.ensure(kMaxKeyCols * 8));
+  CRGPU_TRY(a->any_tails_dev.ensure(static_cast<size_t>(spec->n_aggs) * 8));
+  CRGPU_HIP(hipMemsetAsync(a->tails_dev.p, 0, kMaxKeyCols * 8, stream()));
+  CRGPU_HIP(hipMemsetAsync(a->any_tails_dev.p, 0, static_cast<size_t>(spec->n_aggs) * 8, stream()));
+  CRGPU_TRY(ensure_groups(a.get(), 1024));
+  CRGPU_TRY(reindex(a.get(), 256));  // hashAggregator starts with 256 buckets too (hash_aggregator.go:217)
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsLarge)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsLarge)));
+    lds_attr_set = true;
+  }
   *out = a.release();
   return CRGPU_OK;
 }
@@ -937,23 +1016,123 @@ extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   if (a == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_reset: null handle");
   a->ngroups = 0;
   a->seq = 0;
+  a->new_ratio = 1.0;
   for (auto &k : a->ks) k.tail = 0;
   for (auto &o : a->ops) o.any_tail = 0;
-  const uint32_t cap = a->cap;
-  a->cap = 0;
-  return agg_grow(a, cap ? cap : 256);
+  CRGPU_HIP(hipMemsetAsync(a->tails_dev.p, 0, kMaxKeyCols * 8, stream()));
+  CRGPU_HIP(hipMemsetAsync(a->any_tails_dev.p, 0, a->ops.size() * 8, stream()));
+  CRGPU_HIP(hipMemsetAsync(a->meta.p, 0xFF, static_cast<size_t>(a->cap) * 8, stream()));
+  return CRGPU_OK;
+}
+
+// ---------------------------------------------------------------------- accumulation passes
+struct AccPlan {
+  bool lds = false;
+  uint32_t G = 0, R = 1, sweeps = 1;
+  int block = 256;
+  size_t lds_bytes = 0;
+};
+// How to accumulate `m` rows into `ngroups` groups: LDS partial tables (one sweep, or several
+// gid ranges while 4 bytes/row/sweep stays cheaper than `acc_words` HBM atomics per row), else HBM atomics.
+static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m) {
+  AccPlan p;
+  const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
+  if (bpg == 0 || ngroups <= 0) return p;
+  const size_t total = bpg * static_cast<size_t>(ngroups);
+  if (total <= kLdsSmall) {
+    p.lds = true;
+    p.G = static_cast<uint32_t>(ngroups);
+    uint32_t r = 1;
+    while (r < kMaxReplicas && total * (r * 2) <= kLdsSmall) r *= 2;
+    p.R = r;
+    p.block = 512;
+    p.lds_bytes = total * r;
+    return p;
+  }
+  const uint32_t per_sweep = static_cast<uint32_t>(kLdsLarge / bpg);
+  const uint32_t sweeps = static_cast<uint32_t>((static_cast<uint64_t>(ngroups) + per_sweep - 1) / per_sweep);
+  // cost model (measured rates): a sweep streams 4 B/row at ~4 TB/s plus its share of the value columns;
+  // an HBM atomic costs 1/24 ns.  8 B/row/sweep covers the partial value re-reads.
+  const double sweep_cost = static_cast<double>(sweeps) * 8.0 / 4e12;
+  const double atomic_cost = static_cast<double>(a->acc_words > 0 ? a->acc_words : 1) / 24e9;
+  if (m >= 65536 && sweep_cost < atomic_cost) {
+    p.lds = true;
+    p.G = sweeps == 1 ? static_cast<uint32_t>(ngroups) : per_sweep;
+    p.R = 1;
+    p.sweeps = sweeps;
+    p.block = 1024;
+    p.lds_bytes = bpg * p.G;
+  }
+  return p;
+}
+
+struct PassInput {
+  const std::vector<DCol> *cols;
+  KeyCols keys;
+  const uint32_t *list;
+  int64_t m;
+};
+
+static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fused, uint32_t *miss_list, const AccPlan &plan) {
+  AccArgs args;
+  std::memset(&args, 0, sizeof(args));
+  args.keys = in.keys;
+  args.store = a->store_dev.as<KeyStore>();
+  args.ops = a->ops_dev.as<AggOpDev>();
+  args.naggs = static_cast<int>(a->ops.size());
+  args.m = in.m;
+  args.list = in.list;
+  args.out_gid = a->out_gid.as<uint32_t>();
+  args.meta = a->meta.as<unsigned long long>();
+  args.mask = a->cap - 1;
+  args.R = 1;
+  args.seq_base = a->seq;
+  args.miss_list = miss_list;
+  args.counters = a->counters.as<unsigned int>();
+  hipStream_t st = stream();
+  if (!plan.lds) {
+    ProfScope prof(fused ? "agg_fused_hbm" : "agg_accum_hbm");
+    const dim3 grid(grid_for(in.m, 256)), block(256);
+    if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false>), grid, block, 0, st, args);
+    else hipLaunchKernelGGL((agg_accum_kernel<false, false>), grid, block, 0, st, args);
+    CRGPU_HIP(hipGetLastError());
+    return CRGPU_OK;
+  }
+  args.R = plan.R;
+  args.nwords = static_cast<uint32_t>(a->lds_words);
+  args.nseen = static_cast<uint32_t>(a->lds_seen);
+  // persistent workgroups: every one initialises and merges a whole partial table
+  const int per_cu = plan.block == 512 ? 2 : 1;
+  int64_t want = (in.m + plan.block * 8 - 1) / (plan.block * 8);
+  if (want < 1) want = 1;
+  const int64_t max_grid = static_cast<int64_t>(num_cus()) * per_cu;
+  const dim3 grid(static_cast<unsigned int>(want < max_grid ? want : max_grid)), block(plan.block);
+  const size_t lds = (plan.lds_bytes + 15) & ~size_t(15);
+  for (uint32_t s = 0; s < plan.sweeps; s++) {
+    args.gid_lo = s * plan.G;
+    const int64_t left = a->ngroups - static_cast<int64_t>(args.gid_lo);
+    args.G = static_cast<uint32_t>(left < static_cast<int64_t>(plan.G) ? left : plan.G);
+    if (plan.sweeps == 1) args.G = plan.G;
+    ProfScope prof(fused ? "agg_fused_lds" : "agg_accum_lds");
+    if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, true>), grid, block, lds, st, args);
+    else hipLaunchKernelGGL((agg_accum_kernel<false, true>), grid, block, lds, st, args);
+    CRGPU_HIP(hipGetLastError());
+  }
+  return CRGPU_OK;
+}
+
+static crgpu_status read_counters(crgpu_agg *a, unsigned int *out2) {
+  unsigned int c[4] = {0, 0, 0, 0};
+  CRGPU_HIP(hipMemcpyAsync(c, a->counters.p, 16, hipMemcpyDeviceToHost, stream()));
+  CRGPU_HIP(hipStreamSynchronize(stream()));
+  out2[0] = c[0];
+  out2[1] = c[1];
+  return CRGPU_OK;
 }
 
 static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n) {
   hipStream_t st = stream();
-  // keep the load factor <= 0.5 at chunk start
-  if (static_cast<uint64_t>(a->ngroups) * 2 > a->cap) CRGPU_TRY(agg_grow(a, static_cast<uint32_t>(next_pow2(static_cast<uint64_t>(a->ngroups) * 4))));
-  CRGPU_TRY(a->deferred.ensure(static_cast<size_t>(n)));
-  CRGPU_TRY(a->rep_rows.ensure(static_cast<size_t>(n) * 4));
-  CRGPU_TRY(a->rep_slots.ensure(static_cast<size_t>(n) * 4));
-  if (a->need_slot_of_row) CRGPU_TRY(a->slot_of_row.ensure(static_cast<size_t>(n) * 4));
-  // BYTES key payload: reserve room for every key byte of the chunk
-  std::vector<unsigned long long> tails(kMaxKeyCols, 0);
+  // BYTES key payload / BYTES ANY_NOT_NULL values: reserve room for every byte of the chunk
   for (size_t k = 0; k < a->ks.size(); k++) {
     const DCol &c = cols[a->group_cols[k]];
     if (c.type != CRGPU_BYTES) continue;
@@ -961,10 +1140,10 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     CRGPU_HIP(hipMemcpyAsync(begins, c.offsets, 4, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipMemcpyAsync(ends, c.offsets + n, 4, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
+    const size_t before = a->ks[k].b_buf.cap;
     CRGPU_TRY(a->ks[k].b_buf.ensure(static_cast<size_t>(a->ks[k].tail + (ends[0] - begins[0]) + 16), true));
-    tails[k] = a->ks[k].tail;
+    if (a->ks[k].b_buf.cap != before) a->descriptors_dirty = true;
   }
-  std::vector<unsigned long long> any_tails(a->ops.size() ? a->ops.size() : 1, 0);
   for (size_t f = 0; f < a->ops.size(); f++) {
     AggOpHost &op = a->ops[f];
     if (op.kind != ACC_ANY_ROW || op.in_type != CRGPU_BYTES) continue;
@@ -974,110 +1153,150 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     CRGPU_HIP(hipMemcpyAsync(ends, c.offsets + n, 4, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     CRGPU_TRY(op.any_buf.ensure(static_cast<size_t>(op.any_tail + (ends[0] - begins[0]) + 16), true));
-    any_tails[f] = op.any_tail;
   }
-  CRGPU_TRY(a->tails_dev.ensure(kMaxKeyCols * 8));
-  CRGPU_HIP(hipMemcpyAsync(a->tails_dev.p, tails.data(), kMaxKeyCols * 8, hipMemcpyHostToDevice, st));
-  CRGPU_TRY(a->any_tails_dev.ensure(any_tails.size() * 8));
-  CRGPU_HIP(hipMemcpyAsync(a->any_tails_dev.p, any_tails.data(), any_tails.size() * 8, hipMemcpyHostToDevice, st));
-  CRGPU_HIP(hipStreamSynchronize(st));
+  CRGPU_TRY(upload_descriptors(a, &cols));  // the chunk's column pointers are part of the op descriptors
 
-  KeyCols keys;
-  keys.n = static_cast<int>(a->group_cols.size());
-  keys._pad = 0;
-  for (int k = 0; k < keys.n; k++) keys.c[k] = cols[a->group_cols[k]];
+  PassInput in;
+  in.cols = &cols;
+  in.keys.n = static_cast<int>(a->group_cols.size());
+  in.keys._pad = 0;
+  for (int k = 0; k < in.keys.n; k++) in.keys.c[k] = cols[a->group_cols[k]];
+  in.list = nullptr;
+  in.m = n;
 
-  bool only_deferred = false;
-  int64_t groups_before = a->ngroups;
-  for (int round = 0; round < 40; round++) {
-    CRGPU_TRY(upload_descriptors(a, &cols));
+  CRGPU_TRY(a->list_a.ensure(static_cast<size_t>(n) * 4));
+  uint32_t *cur_list = nullptr;                       // list backing `in.list`
+  uint32_t *next_list = a->list_a.as<uint32_t>();     // where the next pass's rows are collected
+  const int64_t groups_before = a->ngroups;
+
+  // steady state: one fused pass; only rows of groups that do not exist yet remain
+  const AccPlan fused_plan = plan_accumulate(a, a->ngroups, n);
+  const bool fused = !a->need_any_fix && a->ngroups > 0 && a->new_ratio < 0.5 && fused_plan.sweeps == 1;
+  if (fused) {
     CRGPU_HIP(hipMemsetAsync(a->counters.p, 0, 16, st));
-    AggArgs args;
-    std::memset(&args, 0, sizeof(args));
-    args.keys = keys;
-    args.store = a->store_dev.as<KeyStore>();
-    args.ops = a->ops_dev.as<AggOpDev>();
-    args.naggs = static_cast<int>(a->ops.size());
-    args.combine = a->ngroups <= 64 && (a->seq > 0 || only_deferred || n >= 4096) ? 1 : 0;
-    if (a->ngroups == 0 && a->seq == 0 && n > 4096) args.combine = 0;  // unknown cardinality: probe with a small first chunk
-    args.n = n;
-    args.seq_base = a->seq;
-    args.slots = a->slots.as<uint32_t>();
-    args.mask = a->cap - 1;
-    args.only_deferred = only_deferred ? 1 : 0;
-    args.hstore = a->hstore.as<uint32_t>();
-    args.deferred = a->deferred.as<uint8_t>();
-    args.counters = a->counters.as<unsigned int>();
-    args.rep_rows = a->rep_rows.as<uint32_t>();
-    args.rep_slots = a->rep_slots.as<uint32_t>();
-    args.slot_of_row = a->need_slot_of_row ? a->slot_of_row.as<uint32_t>() : nullptr;
-    {
-      ProfScope prof("agg");
-      hipLaunchKernelGGL(agg_consume_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, args);
-      CRGPU_HIP(hipGetLastError());
-    }
-    unsigned int counters[4] = {0, 0, 0, 0};
-    CRGPU_HIP(hipMemcpyAsync(counters, a->counters.p, 16, hipMemcpyDeviceToHost, st));
-    CRGPU_HIP(hipStreamSynchronize(st));
-    const unsigned int nrep = counters[0], ndef = counters[1];
-    if (nrep > 0) {
-      hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for(nrep, 256)), dim3(256), 0, st, keys,
-                         a->store_dev.as<KeyStore>(), nrep, a->rep_rows.as<uint32_t>(), a->rep_slots.as<uint32_t>(),
-                         a->slots.as<uint32_t>(), a->tails_dev.as<unsigned long long>());
-      CRGPU_HIP(hipGetLastError());
-      a->ngroups += nrep;
-    }
-    if (a->need_slot_of_row) {
-      // ANY_NOT_NULL over non-group columns: the rows that won the arrival-order atomicMin in THIS
-      // round store their values now (slot ids are only valid until the table is rebuilt)
-      const size_t nops = a->ops.size();
-      std::vector<void *> ptrs(nops * 3, nullptr);
-      for (size_t f = 0; f < nops; f++) {
-        ptrs[f] = a->ops[f].any_off.p;
-        ptrs[nops + f] = a->ops[f].any_len.p;
-        ptrs[2 * nops + f] = a->ops[f].any_buf.p;
-      }
-      CRGPU_TRY(a->any_ptrs_dev.ensure(ptrs.size() * 8));
-      CRGPU_HIP(hipMemcpyAsync(a->any_ptrs_dev.p, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, st));
-      AnyFixArgs fa;
-      std::memset(&fa, 0, sizeof(fa));
-      fa.ops = a->ops_dev.as<AggOpDev>();
-      fa.naggs = static_cast<int>(nops);
-      fa.n = n;
-      fa.seq_base = a->seq;
-      fa.slot_of_row = a->slot_of_row.as<uint32_t>();
-      fa.any_off = reinterpret_cast<uint64_t *const *>(a->any_ptrs_dev.as<void *>());
-      fa.any_len = reinterpret_cast<uint32_t *const *>(a->any_ptrs_dev.as<void *>() + nops);
-      fa.any_buf = reinterpret_cast<uint8_t *const *>(a->any_ptrs_dev.as<void *>() + 2 * nops);
-      fa.any_tails = a->any_tails_dev.as<unsigned long long>();
-      hipLaunchKernelGGL(agg_any_fixup_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, fa);
-      CRGPU_HIP(hipGetLastError());
-      CRGPU_HIP(hipStreamSynchronize(st));  // `ptrs` is a host temporary
-    }
-    if (ndef == 0) break;
-    // table too full for some rows: grow for the worst case and replay the deferred rows
-    CRGPU_HIP(hipStreamSynchronize(st));
-    uint64_t want = next_pow2((static_cast<uint64_t>(a->ngroups) + ndef) * 2);
-    if (want <= a->cap) want = static_cast<uint64_t>(a->cap) * 2;
-    if (want > 0x80000000ull) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^30 groups per GPU");
-    CRGPU_TRY(agg_grow(a, static_cast<uint32_t>(want)));
-    only_deferred = true;
-    if (round == 39) return fail(CRGPU_ERR_HIP, "crgpu_dev_agg_consume: deferred rows did not converge");
+    CRGPU_TRY(launch_accumulate(a, in, true, next_list, fused_plan));
+    unsigned int c[2];
+    CRGPU_TRY(read_counters(a, c));
+    in.m = c[1];
+    cur_list = next_list;
+    in.list = cur_list;
   }
-  (void)groups_before;
-  // read back the BYTES tails
-  if (!a->ks.empty()) {
-    CRGPU_HIP(hipMemcpyAsync(tails.data(), a->tails_dev.p, kMaxKeyCols * 8, hipMemcpyDeviceToHost, st));
+  for (int round = 0; in.m > 0; round++) {
+    if (round >= 40) return fail(CRGPU_ERR_HIP, "crgpu_dev_agg_consume: deferred rows did not converge");
+    // index capacity: at most half full after the expected (later rounds: worst-case) number of new groups
+    uint64_t est = static_cast<uint64_t>(in.m);
+    if (round == 0 && a->new_ratio < 1.0) {
+      const uint64_t guess = static_cast<uint64_t>(static_cast<double>(in.m) * a->new_ratio * 1.5) + 4096;
+      if (guess < est) est = guess;
+    }
+    const uint64_t want = next_pow2((static_cast<uint64_t>(a->ngroups) + est) * 2);
+    if (want > kMaxCap) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^29 groups per GPU");
+    if (want > a->cap) CRGPU_TRY(reindex(a, static_cast<uint32_t>(want)));
+
+    const size_t m = static_cast<size_t>(in.m);
+    CRGPU_TRY(a->out_gid.ensure(m * 4));
+    CRGPU_TRY(a->rep_pos.ensure(m * 4));
+    CRGPU_TRY(a->rep_slot.ensure(m * 4));
+    CRGPU_TRY(a->rep_word.ensure(m * 8));
+    if (cur_list == a->list_a.as<uint32_t>()) {
+      CRGPU_TRY(a->list_b.ensure(m * 4));
+      next_list = a->list_b.as<uint32_t>();
+    } else {
+      next_list = a->list_a.as<uint32_t>();
+    }
+    CRGPU_HIP(hipMemsetAsync(a->counters.p, 0, 16, st));
+    ResolveArgs r;
+    std::memset(&r, 0, sizeof(r));
+    r.keys = in.keys;
+    r.store = a->store_dev.as<KeyStore>();
+    r.m = in.m;
+    r.list = in.list;
+    r.meta = a->meta.as<unsigned long long>();
+    r.mask = a->cap - 1;
+    r.out_gid = a->out_gid.as<uint32_t>();
+    r.rep_pos = a->rep_pos.as<uint32_t>();
+    r.rep_slot = a->rep_slot.as<uint32_t>();
+    r.rep_word = a->rep_word.as<unsigned long long>();
+    r.next_list = next_list;
+    r.counters = a->counters.as<unsigned int>();
+    {
+      ProfScope prof("agg_resolve");
+      hipLaunchKernelGGL(agg_resolve_kernel, dim3(grid_for(in.m, 256)), dim3(256), 0, st, r);
+      CRGPU_HIP(hipGetLastError());
+    }
+    unsigned int c[2];
+    CRGPU_TRY(read_counters(a, c));
+    const unsigned int nnew = c[0], ndef = c[1];
+    if (nnew > 0) {
+      CRGPU_TRY(ensure_groups(a, static_cast<size_t>(a->ngroups) + nnew));
+      if (a->descriptors_dirty) CRGPU_TRY(upload_descriptors(a, &cols));
+      FixupArgs f;
+      std::memset(&f, 0, sizeof(f));
+      f.keys = in.keys;
+      f.store = a->store_dev.as<KeyStore>();
+      f.ops = a->ops_dev.as<AggOpDev>();
+      f.naggs = static_cast<int>(a->ops.size());
+      f.nnew = nnew;
+      f.g0 = static_cast<uint32_t>(a->ngroups);
+      f.list = in.list;
+      f.rep_pos = a->rep_pos.as<uint32_t>();
+      f.rep_slot = a->rep_slot.as<uint32_t>();
+      f.rep_word = a->rep_word.as<unsigned long long>();
+      f.meta = a->meta.as<unsigned long long>();
+      f.gword = a->gword.as<unsigned long long>();
+      f.b_tails = a->tails_dev.as<unsigned long long>();
+      const size_t nops = a->ops.size();
+      f.any_off = reinterpret_cast<uint64_t *const *>(a->any_ptrs_dev.as<void *>());
+      f.any_len = reinterpret_cast<uint32_t *const *>(a->any_ptrs_dev.as<void *>() + nops);
+      ProfScope prof("agg_fixup");
+      hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for(nnew, 256)), dim3(256), 0, st, f);
+      CRGPU_HIP(hipGetLastError());
+      a->ngroups += nnew;
+    }
+    if (static_cast<int64_t>(ndef) < in.m) {
+      const AccPlan plan = plan_accumulate(a, a->ngroups, in.m);
+      CRGPU_TRY(launch_accumulate(a, in, false, nullptr, plan));
+      if (a->need_any_fix) {
+        const size_t nops = a->ops.size();
+        AnyFixArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.ops = a->ops_dev.as<AggOpDev>();
+        fa.naggs = static_cast<int>(nops);
+        fa.m = in.m;
+        fa.list = in.list;
+        fa.out_gid = a->out_gid.as<uint32_t>();
+        fa.meta = a->meta.as<unsigned long long>();
+        fa.seq_base = a->seq;
+        fa.any_off = reinterpret_cast<uint64_t *const *>(a->any_ptrs_dev.as<void *>());
+        fa.any_len = reinterpret_cast<uint32_t *const *>(a->any_ptrs_dev.as<void *>() + nops);
+        fa.any_buf = reinterpret_cast<uint8_t *const *>(a->any_ptrs_dev.as<void *>() + 2 * nops);
+        fa.any_tails = a->any_tails_dev.as<unsigned long long>();
+        ProfScope prof("agg_any_fixup");
+        hipLaunchKernelGGL(agg_any_fixup_kernel, dim3(grid_for(in.m, 256)), dim3(256), 0, st, fa);
+        CRGPU_HIP(hipGetLastError());
+      }
+    }
+    CRGPU_HIP(hipStreamSynchronize(st));
+    cur_list = next_list;
+    in.list = cur_list;
+    in.m = ndef;
+  }
+  // the BYTES append positions live on the device; the host copy sizes the next reservation
+  if (a->bytes_keys) {
+    unsigned long long tails[kMaxKeyCols];
+    CRGPU_HIP(hipMemcpyAsync(tails, a->tails_dev.p, kMaxKeyCols * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     for (size_t k = 0; k < a->ks.size(); k++) a->ks[k].tail = tails[k];
   }
-  if (a->need_slot_of_row) {
+  if (a->need_any_fix) {
+    std::vector<unsigned long long> any_tails(a->ops.size(), 0);
     CRGPU_HIP(hipMemcpyAsync(any_tails.data(), a->any_tails_dev.p, any_tails.size() * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     for (size_t f = 0; f < a->ops.size(); f++)
       if (a->ops[f].kind == ACC_ANY_ROW && a->ops[f].in_type == CRGPU_BYTES) a->ops[f].any_tail = any_tails[f];
   }
-  CRGPU_HIP(hipStreamSynchronize(st));
+  CRGPU_HIP(hipStreamSynchronize(st));  // `cols` descriptors and host temporaries are done
+  a->new_ratio = static_cast<double>(a->ngroups - groups_before) / static_cast<double>(n);
   a->seq += static_cast<unsigned long long>(n);
   return CRGPU_OK;
 }
@@ -1119,14 +1338,7 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
 extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res) {
   if (a == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_finish: null argument");
   hipStream_t st = stream();
-  int64_t ng = 0;
-  CRGPU_TRY(a->flags.ensure(a->cap));
-  CRGPU_TRY(a->slot_list.ensure(static_cast<size_t>(a->cap) * 4));
-  hipLaunchKernelGGL(occupied_flags_kernel, dim3(grid_for(a->cap, 256)), dim3(256), 0, st, a->slots.as<uint32_t>(),
-                     a->cap, a->flags.as<uint8_t>());
-  CRGPU_HIP(hipGetLastError());
-  CRGPU_TRY(select_flagged(a->flags.as<uint8_t>(), a->cap, a->slot_list.as<int32_t>(), a->scratch, &ng));
-  if (ng != a->ngroups) return fail(CRGPU_ERR_HIP, "crgpu_dev_agg_finish: group count mismatch (internal error)");
+  const int64_t ng = a->ngroups;
   CRGPU_TRY(upload_descriptors(a, nullptr));
   CRGPU_HIP(hipMemsetAsync(a->err_dev.p, 0, 4, st));
   CRGPU_TRY(a->present_tmp.ensure(static_cast<size_t>(ng > 0 ? ng : 1)));
@@ -1151,9 +1363,8 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
       CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(ng + 1) * 4));
       uint64_t total = 0;
       if (ng > 0) {
-        hipLaunchKernelGGL(bytes_view_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, off, len, pres, any_row,
-                           op.w0.as<unsigned long long>(), a->slot_list.as<int32_t>(), ng, a->lens_tmp.as<uint32_t>(),
-                           a->present_tmp.as<uint8_t>());
+        hipLaunchKernelGGL(bytes_view_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, len, pres, any_row,
+                           op.w0.as<unsigned long long>(), ng, a->lens_tmp.as<uint32_t>(), a->present_tmp.as<uint8_t>());
         CRGPU_HIP(hipGetLastError());
       }
       CRGPU_TRY(exclusive_scan_u32(a->lens_tmp.as<uint32_t>(), ng, a->offs64_tmp.as<uint64_t>(), a->scratch, &total));
@@ -1162,8 +1373,8 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
                          ng + 1, o.offsets.as<uint32_t>());
       CRGPU_TRY(o.data.ensure(static_cast<size_t>(total ? total : 1)));
       if (ng > 0) {
-        hipLaunchKernelGGL(bytes_copy_slots_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, off, buf,
-                           a->slot_list.as<int32_t>(), ng, o.offsets.as<uint32_t>(), o.data.as<uint8_t>());
+        hipLaunchKernelGGL(bytes_copy_groups_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, off, buf, ng,
+                           o.offsets.as<uint32_t>(), o.data.as<uint8_t>());
         CRGPU_HIP(hipGetLastError());
       }
     } else {
@@ -1173,7 +1384,6 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
         std::memset(&fa, 0, sizeof(fa));
         fa.op = ops[f];
         fa.out_type = op.out_type;
-        fa.slot_list = a->slot_list.as<int32_t>();
         fa.ngroups = ng;
         fa.out_data = o.data.as<uint8_t>();
         fa.out_present = a->present_tmp.as<uint8_t>();

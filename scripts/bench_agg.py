@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Hash aggregation throughput (device API, inputs resident in HBM): Q1 shape (two 1-byte BYTES group columns,
+4 groups, 4 SUM + 3 AVG + COUNT_ROWS over float64), mid cardinality (int64 key, SUM_INT + COUNT_ROWS + MIN + MAX)
+and all-distinct keys (config G shape).  Prints one JSON line per case."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cockroach_amd import _lib, coldata as cd, device as dev  # noqa: E402
+
+
+def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, the library runs on its own
+    a = dev.Agg(types, group_cols, aggs)
+    a.consume(cols, n); res = a.finish(); ngroups = int(res.n); a.reset()
+    torch.cuda.synchronize()
+    dev.prof_enable(True); dev.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        a.consume(cols, n)
+        res = a.finish()
+        a.reset()
+    _lib.load().crgpu_dev_synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    if expect is not None and expect != ngroups:
+        raise SystemExit(f"{name}: {ngroups} groups, expected {expect}")
+    print(json.dumps({"case": name, "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt,
+                      "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12}), flush=True)
+    a.close()
+
+
+def main():
+    lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+    n = 1 << lg
+    _lib.check(_lib.load().crgpu_init(0))
+    dv = torch.device("cuda", 0)
+    g = torch.Generator(device=dv); g.manual_seed(1)
+    # Q1 shape
+    rf = torch.randint(0, 3, (n,), generator=g, device=dv, dtype=torch.uint8) + 65
+    ls = torch.randint(0, 2, (n,), generator=g, device=dv, dtype=torch.uint8) + 70
+    offs = torch.arange(n + 1, device=dv, dtype=torch.int32)
+    f = [torch.rand(n, generator=g, device=dv, dtype=torch.float64) for _ in range(4)]
+    cols = [dev.from_torch(cd.BYTES, rf, offsets=offs), dev.from_torch(cd.BYTES, ls, offsets=offs)] + \
+           [dev.from_torch(cd.FLOAT64, x) for x in f]
+    types = [cd.BYTES, cd.BYTES] + [cd.FLOAT64] * 4
+    aggs = [(0, 0, -1), (0, 1, -1), (10, 2, -1), (10, 3, -1), (10, 4, -1), (10, 5, -1), (1, 2, -1), (1, 3, -1), (1, 4, -1), (14, -1, -1)]
+    run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0)
+    del cols, f, rf, ls
+    for groups in (1 << 10, 1 << 16, 1 << 20, 1 << 24, n):
+        if groups > n:
+            continue
+        k = torch.randint(0, groups, (n,), generator=g, device=dv, dtype=torch.int64) if groups < n else \
+            torch.randperm(n, generator=g, device=dv, dtype=torch.int64)
+        x = torch.randint(-1000, 1000, (n,), generator=g, device=dv, dtype=torch.int64)
+        cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)]
+        aggs = [(0, 0, -1), (11, 1, -1), (14, -1, -1), (8, 1, -1), (7, 1, -1)]
+        run(f"int64 key, {groups} groups, SUM_INT + COUNT_ROWS + MIN + MAX", cols, [cd.INT64, cd.INT64], [0], aggs, n,
+            n * 16.0 + groups * 40.0, expect=int(torch.unique(k).numel()))
+        del cols, k, x
+
+
+if __name__ == "__main__":
+    main()

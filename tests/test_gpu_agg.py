@@ -120,3 +120,42 @@ def test_agg_all_distinct_keys_growth():
     order = np.argsort(out[1].data)
     assert np.array_equal(out[1].data[order], x) and np.array_equal(out[0].data[order], k)
     assert (out[2].data == 1).all()
+
+
+@pytest.mark.parametrize("ngroups", [6, 700, 2500, 20_000, 500_000])
+def test_agg_accumulation_paths_vs_oracle(oracle, ngroups):
+    """No ANY_NOT_NULL over value columns => the fused lookup+accumulate pass runs from the second chunk on.
+    The group counts select each accumulation strategy (replicated LDS tables, one large LDS table, gid sweeps,
+    HBM atomics); the key range widens chunk by chunk so fused passes keep meeting groups that do not exist yet."""
+    rng = np.random.default_rng(7 + ngroups)
+    n, chunks = 480_000, 4
+    hi = np.repeat((np.arange(chunks) + 1) * ngroups // chunks, n // chunks)
+    k = (rng.random(n) * hi).astype(np.int64)
+    x = rng.integers(-10**12, 10**12, size=n, dtype=np.int64)
+    f = rng.integers(-1000, 1000, size=n).astype(np.float64)  # integer-valued: float sums are exact in any order
+    b = rng.integers(0, 2, size=n).astype(np.uint8)
+    cols = [cd.Vec.from_numpy(cd.INT64, k, rng.random(n) > 0.01), cd.Vec.from_numpy(cd.INT64, x, rng.random(n) > 0.1),
+            cd.Vec.from_numpy(cd.FLOAT64, f, rng.random(n) > 0.1), cd.Vec.from_numpy(cd.BOOL, b, rng.random(n) > 0.2)]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["COUNT_ROWS"], -1, -1), (F["COUNT"], 1, -1), (F["SUM_INT"], 1, -1),
+            (F["MIN"], 1, -1), (F["MAX"], 1, -1), (F["SUM"], 2, -1), (F["AVG"], 2, -1), (F["MIN"], 2, -1), (F["MAX"], 2, -1),
+            (F["BOOL_AND"], 3, -1), (F["BOOL_OR"], 3, -1), (F["SUM_INT"], 1, 3)]
+    want = H.vecs_to_tuples(oracle.hash_agg(cols, [0], aggs))
+    got = H.vecs_to_tuples(G.gpu_agg(cols, [0], aggs, chunks=chunks))
+    H.assert_same_multiset(got, want)
+
+
+def test_agg_reset_reuses_handle(oracle):
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(5)
+    a = dev.Agg([cd.INT64, cd.INT64], [0], [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)])
+    for ngroups in (5000, 3, 100_000):
+        n = 200_000
+        cols = [cd.Vec.from_numpy(cd.INT64, rng.integers(0, ngroups, size=n, dtype=np.int64)),
+                cd.Vec.from_numpy(cd.INT64, rng.integers(-50, 50, size=n, dtype=np.int64))]
+        for s, e in ((0, n // 2), (n // 2, n)):
+            a.consume([dev.upload(v.slice(s, e)) for v in cols], e - s)
+        got = dev.result_to_vecs(a.finish())
+        want = oracle.hash_agg(cols, [0], [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)])
+        assert np.array_equal(_canon(got), _canon(want))
+        a.reset()
+    a.close()
