@@ -49,9 +49,11 @@ static constexpr uint32_t kGidDefer = 0xFFFFFFFFu;     // out_gid: row could not
 static constexpr uint32_t kGidSlotRef = 0x80000000u;   // out_gid: low 31 bits name an index slot whose gid the fixup assigns
 static constexpr uint32_t kMaxCap = 1u << 30;          // index entries (=> at most 2^29 groups per GPU)
 static constexpr uint32_t kIdxHashMask = kMaxCap - 1;
-static constexpr size_t kLdsSmall = 64 * 1024;         // two 512-thread workgroups per CU
-static constexpr size_t kLdsLarge = 152 * 1024;        // one 1024-thread workgroup per CU
+static constexpr size_t kLdsReplicated = 20 * 1024;    // replicate small partial tables up to this size (8 workgroups per CU)
+static constexpr size_t kLdsLarge = 152 * 1024;        // largest partial table: one 1024-thread workgroup per CU
+static constexpr uint32_t kMaxSweeps = 8;
 static constexpr int kMaxReplicas = 32;
+static constexpr int kAccRows = 8;                     // rows per thread and iteration in the accumulate kernels
 
 enum AccKind : int32_t {
   ACC_COUNT_ROWS = 0, ACC_COUNT, ACC_SUM_F64, ACC_AVG_F64, ACC_SUM_I128, ACC_MIN_I64, ACC_MAX_I64, ACC_MIN_F64,
@@ -84,6 +86,22 @@ struct KeyStore {
   int32_t _pad;
   KeyStoreCol c[kMaxKeyCols];
 };
+
+// Accumulate-kernel form of an aggregation: lives in the KERNEL ARGUMENTS (constant memory), so the
+// per-op fields are scalar loads that no store or atomic of the kernel can invalidate.  (As loads from
+// a device array they were re-fetched per lane after every atomic: 68 vector loads per row.)
+struct OpK {
+  int8_t kind, in_type, has_filter, _p0;
+  int8_t lw0, lw1, lseen, _p1;  // LDS partial table: word / seen-byte plane numbers (-1: none)
+  const void *data;             // input column
+  const uint8_t *valid;
+  const uint8_t *fdata;         // FILTER column (BOOL)
+  const uint8_t *fvalid;
+  unsigned long long *w0;       // HBM accumulators [gid]
+  unsigned long long *w1;
+  uint8_t *seen;
+};
+static constexpr int kMaxOpsPerLaunch = 32;  // 2 KiB of the 4 KiB kernel-argument budget
 
 // total-order map for float MIN/MAX: NaN is the smallest value
 // (hash_min_max_agg.eg.go:966-981) -> 0; everything else order-preserving and > 0.
@@ -201,43 +219,49 @@ __device__ __forceinline__ void add_i128(unsigned long long *lo, unsigned long l
   if (d != 0ull) atomicAdd(hi, d);
 }
 
-__device__ __forceinline__ void accum_row(const AggOpDev &op, int64_t row, unsigned long long seq, unsigned long long *w0,
-                                          unsigned long long *w1, uint8_t *seen) {
-  if (op.kind == ACC_ANY_KEY) return;
-  if (op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row))) return;  // aggregators_util.go:216-234
-  if (op.kind == ACC_COUNT_ROWS) {
-    atomicAdd(w0, 1ull);
-    return;
+// Accumulating one input row is split in two so that a thread can issue the loads of all its rows
+// before the first atomic: (1) does the row contribute to `op`, and with which 64-bit value
+// (float bits / sign-extended integer / bool); (2) the atomic update.
+__device__ __forceinline__ bool bit_valid(const uint8_t *valid, int64_t i) {
+  return valid == nullptr || ((valid[i >> 3] >> (i & 7)) & 1);  // coldata.Nulls: bit = 1 => present
+}
+__device__ __forceinline__ bool load_input(const OpK &op, int64_t row, unsigned long long &v) {
+  v = 0;
+  if (op.has_filter && (!bit_valid(op.fvalid, row) || op.fdata[row] == 0)) return false;  // aggregators_util.go:216-234
+  if (op.kind == ACC_COUNT_ROWS) return true;
+  if (!bit_valid(op.valid, row)) return false;  // aggregates skip NULL inputs
+  switch (op.in_type) {
+    case CRGPU_BOOL: v = reinterpret_cast<const uint8_t *>(op.data)[row] != 0; break;
+    case CRGPU_INT16: v = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int16_t *>(op.data)[row])); break;
+    case CRGPU_INT32: v = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int32_t *>(op.data)[row])); break;
+    case CRGPU_BYTES: break;  // COUNT / ANY_NOT_NULL: the payload is not needed here
+    default: v = reinterpret_cast<const unsigned long long *>(op.data)[row]; break;  // INT64 / FLOAT64 bits
   }
-  if (col_is_null(op.col, row)) return;  // aggregates skip NULL inputs
+  return true;
+}
+__device__ __forceinline__ void apply_input(const OpK &op, unsigned long long v, unsigned long long seq,
+                                            unsigned long long *w0, unsigned long long *w1, uint8_t *seen) {
   switch (op.kind) {
+    case ACC_COUNT_ROWS:
     case ACC_COUNT: atomicAdd(w0, 1ull); break;
     case ACC_SUM_F64:
-      unsafeAtomicAdd(reinterpret_cast<double *>(w0), col_get_f64(op.col, row));
+      unsafeAtomicAdd(reinterpret_cast<double *>(w0), __longlong_as_double(static_cast<long long>(v)));
       *seen = 1;
       break;
     case ACC_AVG_F64:
-      unsafeAtomicAdd(reinterpret_cast<double *>(w0), col_get_f64(op.col, row));
+      unsafeAtomicAdd(reinterpret_cast<double *>(w0), __longlong_as_double(static_cast<long long>(v)));
       atomicAdd(w1, 1ull);
       break;
-    case ACC_SUM_I128: {
-      const long long v = col_get_int(op.col, row);
-      add_i128(w0, w1, static_cast<unsigned long long>(v), v < 0 ? ~0ull : 0ull);
+    case ACC_SUM_I128:
+      add_i128(w0, w1, v, (v >> 63) ? ~0ull : 0ull);
       *seen = 1;
       break;
-    }
-    case ACC_MIN_I64:
-    case ACC_MAX_I64: {
-      const long long v = op.col.type == CRGPU_BOOL ? static_cast<long long>(col_get_bool(op.col, row)) : col_get_int(op.col, row);
-      if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(w0), v);
-      else atomicMax(reinterpret_cast<long long *>(w0), v);
-      *seen = 1;
-      break;
-    }
-    case ACC_MIN_F64: atomicMin(w0, f64_to_ordered(col_get_f64(op.col, row))); *seen = 1; break;
-    case ACC_MAX_F64: atomicMax(w0, f64_to_ordered(col_get_f64(op.col, row))); *seen = 1; break;
-    case ACC_BOOL_AND: if (!col_get_bool(op.col, row)) atomicAnd(w0, 0ull); *seen = 1; break;
-    case ACC_BOOL_OR: if (col_get_bool(op.col, row)) atomicOr(w0, 1ull); *seen = 1; break;
+    case ACC_MIN_I64: atomicMin(reinterpret_cast<long long *>(w0), static_cast<long long>(v)); *seen = 1; break;
+    case ACC_MAX_I64: atomicMax(reinterpret_cast<long long *>(w0), static_cast<long long>(v)); *seen = 1; break;
+    case ACC_MIN_F64: atomicMin(w0, f64_to_ordered(__longlong_as_double(static_cast<long long>(v)))); *seen = 1; break;
+    case ACC_MAX_F64: atomicMax(w0, f64_to_ordered(__longlong_as_double(static_cast<long long>(v)))); *seen = 1; break;
+    case ACC_BOOL_AND: if (!v) atomicAnd(w0, 0ull); *seen = 1; break;
+    case ACC_BOOL_OR: if (v) atomicOr(w0, 1ull); *seen = 1; break;
     case ACC_ANY_ROW: atomicMin(w0, seq); break;  // first non-NULL in arrival order
     default: break;
   }
@@ -255,7 +279,7 @@ __device__ __forceinline__ unsigned long long acc_init_w0(int kind) {
 }
 
 // merge the replicas of group g (LDS) into the HBM accumulators of group gid
-__device__ inline void lds_flush_op(const AggOpDev &op, const unsigned long long *ldsw, const uint8_t *ldss, uint32_t G,
+__device__ inline void lds_flush_op(const OpK &op, const unsigned long long *ldsw, const uint8_t *ldss, uint32_t G,
                                     uint32_t R, uint32_t g, uint32_t gid) {
   if (op.kind == ACC_ANY_KEY) return;
   const unsigned long long *p0 = ldsw + (static_cast<size_t>(op.lw0) * G + g) * R;
@@ -352,10 +376,10 @@ __device__ inline void lds_flush_op(const AggOpDev &op, const unsigned long long
 
 struct AccArgs {
   KeyCols keys;
-  const KeyStore *store;   // device copy
-  const AggOpDev *ops;     // device copy
-  int32_t naggs;
-  int32_t _pad;
+  KeyStore store;
+  OpK ops[kMaxOpsPerLaunch];
+  int32_t naggs;           // ops of this launch
+  int32_t record_misses;   // FUSED: list rows whose group does not exist (first launch of a pass only)
   int64_t m;               // rows of this pass (positions into `list`, or chunk rows when list == nullptr)
   const uint32_t *list;    // chunk row of each position, or nullptr for the identity
   const uint32_t *out_gid; // !FUSED: group of each position (resolve kernel)
@@ -376,11 +400,11 @@ template <bool FUSED, bool LDS>
 __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
   extern __shared__ unsigned long long lds_words[];
   uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * a.G * a.R);
-  const KeyStore &store = *a.store;
+  const KeyStore &store = a.store;
   if (LDS) {
     const uint32_t per = a.G * a.R;
     for (int f = 0; f < a.naggs; f++) {
-      const AggOpDev &op = a.ops[f];
+      const OpK &op = a.ops[f];
       if (op.lw0 >= 0) {
         const unsigned long long init = acc_init_w0(op.kind);
         for (uint32_t i = threadIdx.x; i < per; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * per + i] = init;
@@ -394,45 +418,59 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
   const uint32_t rep = threadIdx.x & (a.R - 1);
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const int64_t mround = (a.m + 63) & ~int64_t(63);  // whole waves stay in the loop (wave-level collectives below)
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < mround; i += stride) {
-    const bool active = i < a.m;
-    const int64_t row = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
-    uint32_t gid = kGidDefer;
-    if (active) {
+  // kAccRows rows per thread and iteration: their loads overlap, and each op descriptor is fetched once for all of them
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i0 < mround; i0 += stride * kAccRows) {
+    int64_t row[kAccRows];
+    uint32_t gid[kAccRows];
+#pragma unroll
+    for (int k = 0; k < kAccRows; k++) {
+      const int64_t i = i0 + k * stride;
+      const bool active = i < a.m;
+      row[k] = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
+      gid[k] = kGidDefer;
+      if (!FUSED && active) gid[k] = a.out_gid[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kAccRows; k++) {
+      const bool active = i0 + k * stride < a.m;
       if (FUSED) {
-        gid = index_lookup(a.keys, row, store, a.meta, a.mask);
-      } else {
-        gid = a.out_gid[i];
-        if (gid != kGidDefer && (gid & kGidSlotRef)) gid = static_cast<uint32_t>(a.meta[gid & ~kGidSlotRef]);
+        if (active) gid[k] = index_lookup(a.keys, row[k], store, a.meta, a.mask);
+        const bool miss = active && gid[k] == kGidDefer;
+        const uint64_t mm = a.record_misses ? __ballot(miss) : 0;
+        if (mm) {
+          const int lead = __ffsll(static_cast<long long>(mm)) - 1;
+          unsigned int base = 0;
+          if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(mm)));
+          base = __shfl(base, lead, 64);
+          if (miss) a.miss_list[base + rank_in_mask(mm)] = static_cast<uint32_t>(row[k]);
+        }
+      } else if (gid[k] != kGidDefer && (gid[k] & kGidSlotRef)) {
+        gid[k] = static_cast<uint32_t>(a.meta[gid[k] & ~kGidSlotRef]);
+      }
+      if (LDS && gid[k] != kGidDefer) {
+        gid[k] -= a.gid_lo;
+        if (gid[k] >= a.G) gid[k] = kGidDefer;  // another sweep's group (unsigned compare covers gid < gid_lo)
       }
     }
-    if (FUSED) {
-      const bool miss = active && gid == kGidDefer;
-      const uint64_t mm = __ballot(miss);
-      if (mm) {
-        const int lead = __ffsll(static_cast<long long>(mm)) - 1;
-        unsigned int base = 0;
-        if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(mm)));
-        base = __shfl(base, lead, 64);
-        if (miss) a.miss_list[base + rank_in_mask(mm)] = static_cast<uint32_t>(row);
-      }
-    }
-    if (gid == kGidDefer) continue;
-    const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row);
-    if (LDS) {
-      const uint32_t g = gid - a.gid_lo;
-      if (g >= a.G) continue;  // another sweep's group (unsigned compare covers gid < gid_lo)
-      for (int f = 0; f < a.naggs; f++) {
-        const AggOpDev &op = a.ops[f];
-        unsigned long long *w0 = lds_words + (static_cast<size_t>(op.lw0) * a.G + g) * a.R + rep;
-        unsigned long long *w1 = lds_words + (static_cast<size_t>(op.lw1) * a.G + g) * a.R + rep;
-        uint8_t *seen = lds_seen + (static_cast<size_t>(op.lseen) * a.G + g) * a.R + rep;
-        accum_row(op, row, seq, w0, w1, seen);
-      }
-    } else {
-      for (int f = 0; f < a.naggs; f++) {
-        const AggOpDev &op = a.ops[f];
-        accum_row(op, row, seq, op.w0 + gid, op.w1 + gid, op.seen + gid);
+    for (int f = 0; f < a.naggs; f++) {
+      const OpK &op = a.ops[f];
+      unsigned long long v[kAccRows];
+      bool take[kAccRows];
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) take[k] = gid[k] != kGidDefer && load_input(op, row[k], v[k]);
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) {
+        if (!take[k]) continue;
+        const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row[k]);
+        if (LDS) {
+          const uint32_t g = gid[k];
+          unsigned long long *w0 = lds_words + (static_cast<size_t>(op.lw0) * a.G + g) * a.R + rep;
+          unsigned long long *w1 = lds_words + (static_cast<size_t>(op.lw1) * a.G + g) * a.R + rep;
+          uint8_t *seen = lds_seen + (static_cast<size_t>(op.lseen) * a.G + g) * a.R + rep;
+          apply_input(op, v[k], seq, w0, w1, seen);
+        } else {
+          apply_input(op, v[k], seq, op.w0 + gid[k], op.w1 + gid[k], op.seen + gid[k]);
+        }
       }
     }
   }
@@ -449,7 +487,7 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
 // ------------------------------------------------------------------ find-or-insert (rows whose group may not exist yet)
 struct ResolveArgs {
   KeyCols keys;
-  const KeyStore *store;
+  KeyStore store;
   int64_t m;
   const uint32_t *list;
   unsigned long long *meta;
@@ -461,71 +499,166 @@ struct ResolveArgs {
   uint32_t *next_list;            // deferred chunk rows
   unsigned int *counters;         // [0] new groups, [1] deferred rows
 };
+static constexpr int kResolveRows = 4;  // rows per thread and tile: one pair of global counter updates per 1024 rows
 __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
-  const KeyStore &store = *a.store;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  const int64_t mround = (a.m + 63) & ~int64_t(63);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < mround; i += stride) {
-    const bool active = i < a.m;
-    const int64_t row = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
-    uint32_t res = kGidDefer, slot = 0;
-    bool is_new = false;
-    RowHash rh{0, 0};
-    if (active) {
-      rh = agg_hash(a.keys, row);
-      uint32_t idx = rh.idx & a.mask;
-      for (int probes = 0; probes < kMaxProbe; probes++) {
-        unsigned long long e = __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e == kMetaEmpty) {
-          const unsigned long long claim = (static_cast<unsigned long long>(rh.upper | kClaimBit) << 32) | static_cast<uint32_t>(i);
-          const unsigned long long old = atomicCAS(&a.meta[idx], kMetaEmpty, claim);
-          if (old == kMetaEmpty) {
-            is_new = true;
-            slot = idx;
-            res = kGidSlotRef | idx;
+  // Same-address HBM atomics serialise (~10 ns each), so new-group / deferred-row slots are
+  // reserved per workgroup tile: waves count in LDS, one thread reserves for the whole tile.
+  __shared__ unsigned int s_cnt[2], s_base[2];
+  const KeyStore &store = a.store;
+  const int64_t tile_rows = 256 * kResolveRows;
+  const int64_t ntiles = (a.m + tile_rows - 1) / tile_rows;
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t res[kResolveRows], slot[kResolveRows], loc[kResolveRows];
+    unsigned long long word[kResolveRows];
+    int64_t row[kResolveRows];
+    bool is_new[kResolveRows], deferred[kResolveRows];
+#pragma unroll
+    for (int k = 0; k < kResolveRows; k++) {
+      const int64_t i = tile * tile_rows + k * 256 + threadIdx.x;
+      const bool active = i < a.m;
+      row[k] = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
+      res[k] = kGidDefer;
+      slot[k] = 0;
+      word[k] = 0;
+      is_new[k] = false;
+      if (active) {
+        const RowHash rh = agg_hash(a.keys, row[k]);
+        word[k] = (static_cast<unsigned long long>(rh.upper) << 32) | rh.idx;
+        const unsigned long long claim = (static_cast<unsigned long long>(rh.upper | kClaimBit) << 32) | static_cast<uint32_t>(i);
+        uint32_t idx = rh.idx & a.mask;
+        for (int probes = 0; probes < kMaxProbe; probes++) {
+          // rows that reach this kernel mostly belong to groups that do not exist yet: try to claim first
+          const unsigned long long e = atomicCAS(&a.meta[idx], kMetaEmpty, claim);
+          if (e == kMetaEmpty) {
+            is_new[k] = true;
+            slot[k] = idx;
             break;
           }
-          e = old;
-        }
-        const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
-        if ((up & ~kClaimBit) == rh.upper) {
-          if (up & kClaimBit) {
-            const int64_t other = a.list != nullptr ? static_cast<int64_t>(a.list[lo]) : static_cast<int64_t>(lo);
-            if (keys_equal(a.keys, row, a.keys, other, true)) {
-              res = kGidSlotRef | idx;
+          const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
+          if ((up & ~kClaimBit) == rh.upper) {
+            if (up & kClaimBit) {
+              const int64_t other = a.list != nullptr ? static_cast<int64_t>(a.list[lo]) : static_cast<int64_t>(lo);
+              if (keys_equal(a.keys, row[k], a.keys, other, true)) {
+                res[k] = kGidSlotRef | idx;
+                break;
+              }
+            } else if (key_equals_store(a.keys, row[k], store, lo, rh.upper & 0xFFu)) {
+              res[k] = lo;
               break;
             }
-          } else if (key_equals_store(a.keys, row, store, lo, rh.upper & 0xFFu)) {
-            res = lo;
-            break;
           }
+          idx = (idx + 1) & a.mask;
         }
-        idx = (idx + 1) & a.mask;
+      }
+      deferred[k] = active && !is_new[k] && res[k] == kGidDefer;
+      // position inside the tile's reservation
+      const uint64_t m_new = __ballot(is_new[k]), m_def = __ballot(deferred[k]);
+      unsigned int wb = 0;
+      if (m_new) {
+        const int lead = __ffsll(static_cast<long long>(m_new)) - 1;
+        if (lane_id() == static_cast<uint32_t>(lead)) wb = atomicAdd(&s_cnt[0], static_cast<unsigned int>(popc64(m_new)));
+        wb = __shfl(wb, lead, 64);
+        if (is_new[k]) loc[k] = wb + rank_in_mask(m_new);
+      }
+      if (m_def) {
+        const int lead = __ffsll(static_cast<long long>(m_def)) - 1;
+        if (lane_id() == static_cast<uint32_t>(lead)) wb = atomicAdd(&s_cnt[1], static_cast<unsigned int>(popc64(m_def)));
+        wb = __shfl(wb, lead, 64);
+        if (deferred[k]) loc[k] = wb + rank_in_mask(m_def);
       }
     }
-    const uint64_t m_new = __ballot(is_new);
-    if (m_new) {
-      const int lead = __ffsll(static_cast<long long>(m_new)) - 1;
-      unsigned int base = 0;
-      if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[0], static_cast<unsigned int>(popc64(m_new)));
-      base = __shfl(base, lead, 64);
-      if (is_new) {
-        const unsigned int p = base + rank_in_mask(m_new);
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const unsigned int c = s_cnt[threadIdx.x];
+      s_base[threadIdx.x] = c ? atomicAdd(&a.counters[threadIdx.x], c) : 0;
+      s_cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const unsigned int base_new = s_base[0], base_def = s_base[1];
+#pragma unroll
+    for (int k = 0; k < kResolveRows; k++) {
+      const int64_t i = tile * tile_rows + k * 256 + threadIdx.x;
+      if (is_new[k]) {
+        const unsigned int p = base_new + loc[k];
         a.rep_pos[p] = static_cast<uint32_t>(i);
-        a.rep_slot[p] = slot;
-        a.rep_word[p] = (static_cast<unsigned long long>(rh.upper) << 32) | rh.idx;
+        a.rep_slot[p] = slot[k];
+        a.rep_word[p] = word[k];
       }
+      if (deferred[k]) a.next_list[base_def + loc[k]] = static_cast<uint32_t>(row[k]);
+      // claimants are accumulated by the fixup kernel, deferred rows by a later round
+      if (i < a.m) a.out_gid[i] = res[k];
     }
-    const bool deferred = active && res == kGidDefer;
-    const uint64_t m_def = __ballot(deferred);
-    if (m_def) {
-      const int lead = __ffsll(static_cast<long long>(m_def)) - 1;
-      unsigned int base = 0;
-      if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(m_def)));
-      base = __shfl(base, lead, 64);
-      if (deferred) a.next_list[base + rank_in_mask(m_def)] = static_cast<uint32_t>(row);
+    __syncthreads();  // s_base is rewritten by the next tile
+  }
+}
+
+// ANY_NOT_NULL over a non-group column: store the value of `row` as group gid's value
+// (fixed-width: w1 word; BYTES: per-op append buffer)
+__device__ inline void any_store_value(const AggOpDev &op, int f, int64_t row, uint32_t gid, uint64_t *const *any_off,
+                                       uint32_t *const *any_len, uint8_t *const *any_buf, unsigned long long *any_tails) {
+  switch (op.col.type) {
+    case CRGPU_BOOL: op.w1[gid] = col_get_bool(op.col, row); break;
+    case CRGPU_FLOAT64: op.w1[gid] = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); break;
+    case CRGPU_BYTES: {
+      uint32_t a0 = op.col.offsets[row], len = op.col.offsets[row + 1] - a0;
+      unsigned long long off = len ? atomicAdd(&any_tails[f], static_cast<unsigned long long>(len)) : 0ull;
+      any_off[f][gid] = off;
+      any_len[f][gid] = len;
+      const uint8_t *src = reinterpret_cast<const uint8_t *>(op.col.data) + a0;
+      for (uint32_t t = 0; t < len; t++) any_buf[f][off + t] = src[t];
+      break;
     }
-    if (active) a.out_gid[i] = res;
+    default: op.w1[gid] = static_cast<unsigned long long>(col_get_int(op.col, row)); break;
+  }
+}
+
+// A new group's accumulators after its first row (the claimant), written with plain stores:
+// nobody else touches the group before the fixup kernel has finished.
+__device__ inline void first_row_store(const AggOpDev &op, int f, int64_t row, unsigned long long seq, uint32_t gid,
+                                       uint64_t *const *any_off, uint32_t *const *any_len, uint8_t *const *any_buf,
+                                       unsigned long long *any_tails) {
+  if (op.kind == ACC_ANY_KEY) return;
+  unsigned long long w0 = acc_init_w0(op.kind), w1 = 0;
+  uint8_t seen = 0;
+  bool take = !(op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row)));
+  if (take && op.kind != ACC_COUNT_ROWS && col_is_null(op.col, row)) take = false;
+  if (take) {
+    switch (op.kind) {
+      case ACC_COUNT_ROWS:
+      case ACC_COUNT: w0 = 1; break;
+      case ACC_SUM_F64: w0 = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); seen = 1; break;
+      case ACC_AVG_F64: w0 = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); w1 = 1; break;
+      case ACC_SUM_I128: {
+        const long long v = col_get_int(op.col, row);
+        w0 = static_cast<unsigned long long>(v);
+        w1 = v < 0 ? ~0ull : 0ull;
+        seen = 1;
+        break;
+      }
+      case ACC_MIN_I64:
+      case ACC_MAX_I64:
+        w0 = static_cast<unsigned long long>(op.col.type == CRGPU_BOOL ? static_cast<long long>(col_get_bool(op.col, row)) : col_get_int(op.col, row));
+        seen = 1;
+        break;
+      case ACC_MIN_F64:
+      case ACC_MAX_F64: w0 = f64_to_ordered(col_get_f64(op.col, row)); seen = 1; break;
+      case ACC_BOOL_AND:
+      case ACC_BOOL_OR: w0 = col_get_bool(op.col, row) ? 1ull : 0ull; seen = 1; break;
+      case ACC_ANY_ROW: w0 = seq; break;
+      default: break;
+    }
+  }
+  op.w0[gid] = w0;
+  if (op.w1 != nullptr) op.w1[gid] = w1;
+  if (op.seen != nullptr) op.seen[gid] = seen;
+  if (op.kind == ACC_ANY_ROW) {
+    if (any_off[f] != nullptr) {
+      any_off[f][gid] = 0;
+      any_len[f][gid] = 0;
+    }
+    if (take) any_store_value(op, f, row, gid, any_off, any_len, any_buf, any_tails);
   }
 }
 
@@ -533,7 +666,7 @@ __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
 // accumulators, publish the gid in the index entry
 struct FixupArgs {
   KeyCols keys;
-  const KeyStore *store;
+  KeyStore store;
   const AggOpDev *ops;
   int32_t naggs;
   uint32_t nnew;
@@ -547,9 +680,12 @@ struct FixupArgs {
   unsigned long long *b_tails;
   uint64_t *const *any_off;  // [naggs] BYTES ANY_NOT_NULL value store (or nullptr entries)
   uint32_t *const *any_len;
+  uint8_t *const *any_buf;
+  unsigned long long *any_tails;
+  unsigned long long seq_base;
 };
 __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
-  const KeyStore &st = *a.store;
+  const KeyStore &st = a.store;
   const unsigned int stride = gridDim.x * blockDim.x;
   for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.nnew; p += stride) {
     const uint32_t gid = a.g0 + p;
@@ -578,16 +714,9 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
         default: break;
       }
     }
-    for (int f = 0; f < a.naggs; f++) {
-      const AggOpDev &op = a.ops[f];
-      if (op.w0 != nullptr) op.w0[gid] = acc_init_w0(op.kind);
-      if (op.w1 != nullptr) op.w1[gid] = 0ull;
-      if (op.seen != nullptr) op.seen[gid] = 0;
-      if (a.any_off[f] != nullptr) {
-        a.any_off[f][gid] = 0;
-        a.any_len[f][gid] = 0;
-      }
-    }
+    const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row);
+    for (int f = 0; f < a.naggs; f++)
+      first_row_store(a.ops[f], f, row, seq, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
     const unsigned long long w = a.rep_word[p];
     a.gword[gid] = w;
     a.meta[a.rep_slot[p]] = (w & 0xFFFFFFFF00000000ull) | gid;
@@ -633,20 +762,7 @@ __global__ __launch_bounds__(256) void agg_any_fixup_kernel(AnyFixArgs a) {
       const AggOpDev &op = a.ops[f];
       if (op.kind != ACC_ANY_ROW) continue;
       if (op.w0[gid] != a.seq_base + static_cast<unsigned long long>(row)) continue;
-      switch (op.col.type) {
-        case CRGPU_BOOL: op.w1[gid] = col_get_bool(op.col, row); break;
-        case CRGPU_FLOAT64: op.w1[gid] = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); break;
-        case CRGPU_BYTES: {
-          uint32_t a0 = op.col.offsets[row], len = op.col.offsets[row + 1] - a0;
-          unsigned long long off = len ? atomicAdd(&a.any_tails[f], static_cast<unsigned long long>(len)) : 0ull;
-          a.any_off[f][gid] = off;
-          a.any_len[f][gid] = len;
-          const uint8_t *src = reinterpret_cast<const uint8_t *>(op.col.data) + a0;
-          for (uint32_t t = 0; t < len; t++) a.any_buf[f][off + t] = src[t];
-          break;
-        }
-        default: op.w1[gid] = static_cast<unsigned long long>(col_get_int(op.col, row)); break;
-      }
+      any_store_value(op, f, row, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
     }
   }
 }
@@ -796,7 +912,8 @@ struct crgpu_agg {
   double new_ratio = 1.0;  // new groups per input row in the previous chunk (1: unknown)
   bool descriptors_dirty = true;
 
-  DevBuf store_dev, ops_dev, tails_dev, any_tails_dev, any_ptrs_dev;
+  KeyStore store_host;
+  DevBuf ops_dev, tails_dev, any_tails_dev, any_ptrs_dev;
   DevBuf counters, out_gid, list_a, list_b, rep_pos, rep_slot, rep_word, scratch, err_dev;
   DevBuf lens_tmp, offs64_tmp, present_tmp;
   std::vector<OutCol> out;
@@ -829,7 +946,7 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
   CRGPU_TRY(a->ops_dev.ensure(sizeof(AggOpDev) * (ops.size() ? ops.size() : 1)));
   if (!ops.empty())
     CRGPU_HIP(hipMemcpyAsync(a->ops_dev.p, ops.data(), sizeof(AggOpDev) * ops.size(), hipMemcpyHostToDevice, stream()));
-  KeyStore st;
+  KeyStore &st = a->store_host;
   std::memset(&st, 0, sizeof(st));
   st.n = static_cast<int>(a->ks.size());
   for (size_t k = 0; k < a->ks.size(); k++) {
@@ -840,8 +957,6 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
     st.c[k].b_len = a->ks[k].b_len.as<uint32_t>();
     st.c[k].b_buf = a->ks[k].b_buf.as<uint8_t>();
   }
-  CRGPU_TRY(a->store_dev.ensure(sizeof(KeyStore)));
-  CRGPU_HIP(hipMemcpyAsync(a->store_dev.p, &st, sizeof(KeyStore), hipMemcpyHostToDevice, stream()));
   // pointer table of the BYTES ANY_NOT_NULL value stores: [off | len | buf] x naggs
   const size_t nops = a->ops.size();
   std::vector<void *> ptrs(nops * 3, nullptr);
@@ -1030,37 +1145,41 @@ struct AccPlan {
   bool lds = false;
   uint32_t G = 0, R = 1, sweeps = 1;
   int block = 256;
+  int wgs_per_cu = 8;
   size_t lds_bytes = 0;
 };
-// How to accumulate `m` rows into `ngroups` groups: LDS partial tables (one sweep, or several
-// gid ranges while 4 bytes/row/sweep stays cheaper than `acc_words` HBM atomics per row), else HBM atomics.
+// How to accumulate `m` rows into `ngroups` groups: LDS partial tables (one sweep, or a few gid
+// ranges while that stays cheaper than `acc_words` HBM atomics per row), else HBM atomics.
 static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m) {
   AccPlan p;
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0 || ngroups <= 0) return p;
   const size_t total = bpg * static_cast<size_t>(ngroups);
-  if (total <= kLdsSmall) {
+  if (total <= kLdsLarge) {
     p.lds = true;
     p.G = static_cast<uint32_t>(ngroups);
-    uint32_t r = 1;
-    while (r < kMaxReplicas && total * (r * 2) <= kLdsSmall) r *= 2;
+    uint32_t r = 1;  // replicas: spread the lanes of a wave that hit one group, while 8 workgroups still fit a CU
+    while (r < kMaxReplicas && total * (r * 2) <= kLdsReplicated) r *= 2;
     p.R = r;
-    p.block = 512;
     p.lds_bytes = total * r;
+    const size_t fit = (160 * 1024) / (p.lds_bytes ? p.lds_bytes : 1);
+    p.wgs_per_cu = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
+    p.block = p.wgs_per_cu == 8 ? 256 : p.wgs_per_cu == 4 ? 512 : 1024;
     return p;
   }
   const uint32_t per_sweep = static_cast<uint32_t>(kLdsLarge / bpg);
   const uint32_t sweeps = static_cast<uint32_t>((static_cast<uint64_t>(ngroups) + per_sweep - 1) / per_sweep);
-  // cost model (measured rates): a sweep streams 4 B/row at ~4 TB/s plus its share of the value columns;
-  // an HBM atomic costs 1/24 ns.  8 B/row/sweep covers the partial value re-reads.
-  const double sweep_cost = static_cast<double>(sweeps) * 8.0 / 4e12;
+  // every sweep walks all rows again (4-byte gid + the op loop for waves with a row in range): measured ~1 ms
+  // per 2^27 rows and sweep, against acc_words / 24 G/s for HBM atomics
+  const double sweep_cost = static_cast<double>(sweeps) * 1.0e-3 / 134217728.0;
   const double atomic_cost = static_cast<double>(a->acc_words > 0 ? a->acc_words : 1) / 24e9;
-  if (m >= 65536 && sweep_cost < atomic_cost) {
+  if (m >= 65536 && sweeps <= kMaxSweeps && sweep_cost < atomic_cost) {
     p.lds = true;
-    p.G = sweeps == 1 ? static_cast<uint32_t>(ngroups) : per_sweep;
+    p.G = per_sweep;
     p.R = 1;
     p.sweeps = sweeps;
     p.block = 1024;
+    p.wgs_per_cu = 1;
     p.lds_bytes = bpg * p.G;
   }
   return p;
@@ -1077,9 +1196,7 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
   AccArgs args;
   std::memset(&args, 0, sizeof(args));
   args.keys = in.keys;
-  args.store = a->store_dev.as<KeyStore>();
-  args.ops = a->ops_dev.as<AggOpDev>();
-  args.naggs = static_cast<int>(a->ops.size());
+  args.store = a->store_host;
   args.m = in.m;
   args.list = in.list;
   args.out_gid = a->out_gid.as<uint32_t>();
@@ -1089,34 +1206,74 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
   args.seq_base = a->seq;
   args.miss_list = miss_list;
   args.counters = a->counters.as<unsigned int>();
+  args.record_misses = fused ? 1 : 0;
   hipStream_t st = stream();
+  dim3 grid, block;
+  size_t lds = 0;
   if (!plan.lds) {
-    ProfScope prof(fused ? "agg_fused_hbm" : "agg_accum_hbm");
-    const dim3 grid(grid_for(in.m, 256)), block(256);
-    if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false>), grid, block, 0, st, args);
-    else hipLaunchKernelGGL((agg_accum_kernel<false, false>), grid, block, 0, st, args);
-    CRGPU_HIP(hipGetLastError());
-    return CRGPU_OK;
+    grid = dim3(grid_for((in.m + kAccRows - 1) / kAccRows, 256));
+    block = dim3(256);
+  } else {
+    args.R = plan.R;
+    args.nwords = static_cast<uint32_t>(a->lds_words);
+    args.nseen = static_cast<uint32_t>(a->lds_seen);
+    // persistent workgroups: every one initialises and merges a whole partial table
+    const int64_t per_wg = static_cast<int64_t>(plan.block) * kAccRows * 2;
+    int64_t want = (in.m + per_wg - 1) / per_wg;
+    if (want < 1) want = 1;
+    const int64_t max_grid = static_cast<int64_t>(num_cus()) * plan.wgs_per_cu;
+    grid = dim3(static_cast<unsigned int>(want < max_grid ? want : max_grid));
+    block = dim3(plan.block);
+    lds = (plan.lds_bytes + 15) & ~size_t(15);
   }
-  args.R = plan.R;
-  args.nwords = static_cast<uint32_t>(a->lds_words);
-  args.nseen = static_cast<uint32_t>(a->lds_seen);
-  // persistent workgroups: every one initialises and merges a whole partial table
-  const int per_cu = plan.block == 512 ? 2 : 1;
-  int64_t want = (in.m + plan.block * 8 - 1) / (plan.block * 8);
-  if (want < 1) want = 1;
-  const int64_t max_grid = static_cast<int64_t>(num_cus()) * per_cu;
-  const dim3 grid(static_cast<unsigned int>(want < max_grid ? want : max_grid)), block(plan.block);
-  const size_t lds = (plan.lds_bytes + 15) & ~size_t(15);
-  for (uint32_t s = 0; s < plan.sweeps; s++) {
-    args.gid_lo = s * plan.G;
-    const int64_t left = a->ngroups - static_cast<int64_t>(args.gid_lo);
-    args.G = static_cast<uint32_t>(left < static_cast<int64_t>(plan.G) ? left : plan.G);
-    if (plan.sweeps == 1) args.G = plan.G;
-    ProfScope prof(fused ? "agg_fused_lds" : "agg_accum_lds");
-    if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, true>), grid, block, lds, st, args);
-    else hipLaunchKernelGGL((agg_accum_kernel<false, true>), grid, block, lds, st, args);
-    CRGPU_HIP(hipGetLastError());
+  // the op descriptors travel in the kernel arguments, kMaxOpsPerLaunch at a time (one launch in practice)
+  std::vector<OpK> ops;
+  for (const AggOpHost &h : a->ops) {
+    if (h.kind == ACC_ANY_KEY) continue;
+    OpK k;
+    std::memset(&k, 0, sizeof(k));
+    k.kind = static_cast<int8_t>(h.kind);
+    k.in_type = static_cast<int8_t>(h.in_type);
+    k.has_filter = h.filter_col >= 0;
+    k.lw0 = static_cast<int8_t>(h.lw0);
+    k.lw1 = static_cast<int8_t>(h.lw1);
+    k.lseen = static_cast<int8_t>(h.lseen);
+    if (h.col >= 0) {
+      k.data = (*in.cols)[h.col].data;
+      k.valid = (*in.cols)[h.col].valid;
+    }
+    if (h.filter_col >= 0) {
+      k.fdata = static_cast<const uint8_t *>((*in.cols)[h.filter_col].data);
+      k.fvalid = (*in.cols)[h.filter_col].valid;
+    }
+    k.w0 = h.w0.as<unsigned long long>();
+    k.w1 = h.w1.as<unsigned long long>();
+    k.seen = h.seen.as<uint8_t>();
+    ops.push_back(k);
+  }
+  const size_t nbatches = ops.empty() ? 1 : (ops.size() + kMaxOpsPerLaunch - 1) / kMaxOpsPerLaunch;
+  for (size_t b = 0; b < nbatches; b++) {
+    const size_t o0 = b * kMaxOpsPerLaunch;
+    const size_t cnt = ops.size() - o0 < static_cast<size_t>(kMaxOpsPerLaunch) ? ops.size() - o0 : kMaxOpsPerLaunch;
+    args.naggs = static_cast<int32_t>(ops.empty() ? 0 : cnt);
+    if (args.naggs > 0) std::memcpy(args.ops, ops.data() + o0, sizeof(OpK) * cnt);
+    for (uint32_t s = 0; s < plan.sweeps; s++) {
+      if (plan.lds) {
+        args.gid_lo = s * plan.G;
+        const int64_t left = a->ngroups - static_cast<int64_t>(args.gid_lo);
+        args.G = plan.sweeps == 1 ? plan.G : static_cast<uint32_t>(left < static_cast<int64_t>(plan.G) ? left : plan.G);
+      }
+      ProfScope prof(plan.lds ? (fused ? "agg_fused_lds" : "agg_accum_lds") : (fused ? "agg_fused_hbm" : "agg_accum_hbm"));
+      if (plan.lds) {
+        if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, true>), grid, block, lds, st, args);
+        else hipLaunchKernelGGL((agg_accum_kernel<false, true>), grid, block, lds, st, args);
+      } else {
+        if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false>), grid, block, 0, st, args);
+        else hipLaunchKernelGGL((agg_accum_kernel<false, false>), grid, block, 0, st, args);
+      }
+      CRGPU_HIP(hipGetLastError());
+    }
+    args.record_misses = 0;
   }
   return CRGPU_OK;
 }
@@ -1208,7 +1365,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     ResolveArgs r;
     std::memset(&r, 0, sizeof(r));
     r.keys = in.keys;
-    r.store = a->store_dev.as<KeyStore>();
+    r.store = a->store_host;
     r.m = in.m;
     r.list = in.list;
     r.meta = a->meta.as<unsigned long long>();
@@ -1221,7 +1378,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     r.counters = a->counters.as<unsigned int>();
     {
       ProfScope prof("agg_resolve");
-      hipLaunchKernelGGL(agg_resolve_kernel, dim3(grid_for(in.m, 256)), dim3(256), 0, st, r);
+      hipLaunchKernelGGL(agg_resolve_kernel, dim3(grid_for((in.m + kResolveRows - 1) / kResolveRows, 256)), dim3(256), 0, st, r);
       CRGPU_HIP(hipGetLastError());
     }
     unsigned int c[2];
@@ -1233,7 +1390,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
       FixupArgs f;
       std::memset(&f, 0, sizeof(f));
       f.keys = in.keys;
-      f.store = a->store_dev.as<KeyStore>();
+      f.store = a->store_host;
       f.ops = a->ops_dev.as<AggOpDev>();
       f.naggs = static_cast<int>(a->ops.size());
       f.nnew = nnew;
@@ -1248,12 +1405,15 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
       const size_t nops = a->ops.size();
       f.any_off = reinterpret_cast<uint64_t *const *>(a->any_ptrs_dev.as<void *>());
       f.any_len = reinterpret_cast<uint32_t *const *>(a->any_ptrs_dev.as<void *>() + nops);
+      f.any_buf = reinterpret_cast<uint8_t *const *>(a->any_ptrs_dev.as<void *>() + 2 * nops);
+      f.any_tails = a->any_tails_dev.as<unsigned long long>();
+      f.seq_base = a->seq;
       ProfScope prof("agg_fixup");
       hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for(nnew, 256)), dim3(256), 0, st, f);
       CRGPU_HIP(hipGetLastError());
       a->ngroups += nnew;
     }
-    if (static_cast<int64_t>(ndef) < in.m) {
+    if (static_cast<int64_t>(ndef) + static_cast<int64_t>(nnew) < in.m) {  // rows besides claimants (fixup) and deferred ones
       const AccPlan plan = plan_accumulate(a, a->ngroups, in.m);
       CRGPU_TRY(launch_accumulate(a, in, false, nullptr, plan));
       if (a->need_any_fix) {

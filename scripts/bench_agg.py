@@ -30,13 +30,21 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
     dt = (time.perf_counter() - t0) / reps
     if expect is not None and expect != ngroups:
         raise SystemExit(f"{name}: {ngroups} groups, expected {expect}")
+    kern = {}
+    for k in ("agg_fused_lds", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
+              "agg_any_fixup"):
+        ms, cnt = dev.prof_get(k)
+        if cnt:
+            kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
     print(json.dumps({"case": name, "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt,
-                      "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12}), flush=True)
+                      "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12, "kernels": kern}), flush=True)
     a.close()
 
 
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # e.g. "q1,1024,65536"
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     n = 1 << lg
     _lib.check(_lib.load().crgpu_init(0))
     dv = torch.device("cuda", 0)
@@ -50,10 +58,11 @@ def main():
            [dev.from_torch(cd.FLOAT64, x) for x in f]
     types = [cd.BYTES, cd.BYTES] + [cd.FLOAT64] * 4
     aggs = [(0, 0, -1), (0, 1, -1), (10, 2, -1), (10, 3, -1), (10, 4, -1), (10, 5, -1), (1, 2, -1), (1, 3, -1), (1, 4, -1), (14, -1, -1)]
-    run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0)
+    if only is None or "q1" in only:
+        run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0, reps=reps)
     del cols, f, rf, ls
     for groups in (1 << 10, 1 << 16, 1 << 20, 1 << 24, n):
-        if groups > n:
+        if groups > n or (only is not None and str(groups) not in only):
             continue
         k = torch.randint(0, groups, (n,), generator=g, device=dv, dtype=torch.int64) if groups < n else \
             torch.randperm(n, generator=g, device=dv, dtype=torch.int64)
@@ -61,7 +70,7 @@ def main():
         cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)]
         aggs = [(0, 0, -1), (11, 1, -1), (14, -1, -1), (8, 1, -1), (7, 1, -1)]
         run(f"int64 key, {groups} groups, SUM_INT + COUNT_ROWS + MIN + MAX", cols, [cd.INT64, cd.INT64], [0], aggs, n,
-            n * 16.0 + groups * 40.0, expect=int(torch.unique(k).numel()))
+            n * 16.0 + groups * 40.0, expect=int(torch.unique(k).numel()), reps=reps)
         del cols, k, x
 
 
