@@ -52,6 +52,7 @@ static constexpr uint32_t kIdxHashMask = kMaxCap - 1;
 static constexpr size_t kLdsReplicated = 20 * 1024;    // replicate small partial tables up to this size (8 workgroups per CU)
 static constexpr size_t kLdsLarge = 152 * 1024;        // largest partial table: one 1024-thread workgroup per CU
 static constexpr uint32_t kMaxSweeps = 8;
+static constexpr size_t kLdsMax = 160 * 1024;
 static constexpr int kMaxReplicas = 32;
 static constexpr int kAccRows = 8;                     // rows per thread and iteration in the accumulate kernels
 
@@ -194,6 +195,143 @@ __device__ inline bool key_equals_store(const KeyCols &k, int64_t row, const Key
   return true;
 }
 
+// ------------------------------------------------------------------ packed keys (LDS key table of the fused pass)
+// When the group columns fit 128 bits, a row's key packs injectively into two words:
+// fixed-width columns by value (floats canonical), BYTES as {length:4, up to 7 bytes}, plus one NULL
+// bit per column when there is room.  Rows that do not fit (longer BYTES, or a NULL without a NULL
+// bit) are "unpackable": they and their groups use the HBM index instead.
+struct PackCol {
+  int8_t word, shift;            // where the value field starts
+  int8_t null_word, null_shift;  // where the NULL bit lives (null_word < 0: none)
+  int8_t bbytes;                 // BYTES: longest packable value
+  int8_t _pad[3];
+};
+struct PackSpec {
+  int32_t enabled;
+  int32_t two_words;
+  PackCol c[kMaxKeyCols];
+};
+__device__ __forceinline__ bool pack_row(const KeyCols &k, const PackSpec &ps, int64_t row, unsigned long long &k0,
+                                         unsigned long long &k1) {
+  k0 = 0;
+  k1 = 0;
+  for (int c = 0; c < k.n; c++) {
+    const DCol &x = k.c[c];
+    const PackCol &pc = ps.c[c];
+    unsigned long long v;
+    int word = pc.word, shift = pc.shift;
+    if (col_is_null(x, row)) {
+      if (pc.null_word < 0) return false;
+      v = 1;
+      word = pc.null_word;
+      shift = pc.null_shift;
+    } else if (x.type == CRGPU_BYTES) {
+      const uint32_t a0 = x.offsets[row], len = x.offsets[row + 1] - a0;
+      if (len > static_cast<uint32_t>(pc.bbytes)) return false;
+      const uint8_t *p = reinterpret_cast<const uint8_t *>(x.data) + a0;
+      v = len;
+      for (uint32_t j = 0; j < len; j++) v |= static_cast<unsigned long long>(p[j]) << (4 + 8 * j);
+    } else {
+      v = pack_key(x, row);
+      if (x.type == CRGPU_INT16) v &= 0xFFFFull;
+      if (x.type == CRGPU_INT32) v &= 0xFFFFFFFFull;
+    }
+    if (word) k1 |= v << shift;
+    else k0 |= v << shift;
+  }
+  return true;
+}
+// pack_row for the kAccRows rows of a thread, column-wise (see load_inputs): fixed-width columns load
+// branch-free; BYTES columns keep a per-row branch for their variable length.
+template <int K>
+__device__ __forceinline__ void pack_rows(const KeyCols &keys, const PackSpec &ps, const int64_t (&row)[K], bool (&ok)[K],
+                                          unsigned long long (&k0)[K], unsigned long long (&k1)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    k0[k] = 0;
+    k1[k] = 0;
+  }
+  for (int c = 0; c < keys.n; c++) {
+    const DCol &x = keys.c[c];
+    const PackCol &pc = ps.c[c];
+    bool isnull[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) isnull[k] = false;
+    if (x.valid != nullptr) {
+      uint8_t vb[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) vb[k] = x.valid[row[k] >> 3];
+#pragma unroll
+      for (int k = 0; k < K; k++) isnull[k] = !((vb[k] >> (row[k] & 7)) & 1);
+    }
+    unsigned long long v[K];
+    if (x.type == CRGPU_BYTES) {
+      uint32_t a0[K], a1[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        a0[k] = x.offsets[row[k]];
+        a1[k] = x.offsets[row[k] + 1];
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const uint32_t len = a1[k] - a0[k];
+        v[k] = len;
+        if (isnull[k] || !ok[k]) continue;
+        if (len > static_cast<uint32_t>(pc.bbytes)) {
+          ok[k] = false;
+          continue;
+        }
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(x.data) + a0[k];
+        for (uint32_t j = 0; j < len; j++) v[k] |= static_cast<unsigned long long>(p[j]) << (4 + 8 * j);
+      }
+    } else {
+      switch (x.type) {
+        case CRGPU_BOOL:
+#pragma unroll
+          for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const uint8_t *>(x.data)[row[k]] != 0;
+          break;
+        case CRGPU_INT16:
+#pragma unroll
+          for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const uint16_t *>(x.data)[row[k]];
+          break;
+        case CRGPU_INT32:
+#pragma unroll
+          for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const uint32_t *>(x.data)[row[k]];
+          break;
+        case CRGPU_FLOAT64:
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            const double f = reinterpret_cast<const double *>(x.data)[row[k]];
+            v[k] = f != f ? 0x7FF8000000000000ull : (f == 0 ? 0ull : static_cast<unsigned long long>(__double_as_longlong(f)));
+          }
+          break;
+        default:
+#pragma unroll
+          for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const unsigned long long *>(x.data)[row[k]];
+          break;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      unsigned long long f0 = 0, f1 = 0;
+      if (isnull[k]) {
+        if (pc.null_word < 0) ok[k] = false;
+        else if (pc.null_word) f1 = 1ull << pc.null_shift;
+        else f0 = 1ull << pc.null_shift;
+      } else if (pc.word) {
+        f1 = v[k] << pc.shift;
+      } else {
+        f0 = v[k] << pc.shift;
+      }
+      k0[k] |= f0;
+      k1[k] |= f1;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t pk_hash(unsigned long long k0, unsigned long long k1) {
+  return static_cast<uint32_t>(fmix64(k0 ^ (k1 * 0x9FB21C651E98DF25ull)) >> 20);
+}
+
 // read-only index lookup: gid of the row's group or kGidDefer when it does not exist (yet)
 __device__ inline uint32_t index_lookup(const KeyCols &keys, int64_t row, const KeyStore &store,
                                         const unsigned long long *__restrict__ meta, uint32_t mask) {
@@ -264,6 +402,57 @@ __device__ __forceinline__ void apply_input(const OpK &op, unsigned long long v,
     case ACC_BOOL_OR: if (v) atomicOr(w0, 1ull); *seen = 1; break;
     case ACC_ANY_ROW: atomicMin(w0, seq); break;  // first non-NULL in arrival order
     default: break;
+  }
+}
+
+// The same test-and-load for the kAccRows rows of a thread, written column-wise: every branch is on a
+// per-op (wave-uniform) property and every loop body is a plain load, so the compiler issues the loads of
+// all rows back to back and waits once (row-wise code waited after every single load).
+template <int K>
+__device__ __forceinline__ void load_inputs(const OpK &op, const int64_t (&row)[K], bool (&take)[K],
+                                            unsigned long long (&v)[K]) {
+  if (op.has_filter) {  // aggregators_util.go:216-234
+    uint8_t fb[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) fb[k] = op.fdata[row[k]];
+    if (op.fvalid != nullptr) {
+      uint8_t fv[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) fv[k] = op.fvalid[row[k] >> 3];
+#pragma unroll
+      for (int k = 0; k < K; k++) take[k] = take[k] && ((fv[k] >> (row[k] & 7)) & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) take[k] = take[k] && fb[k] != 0;
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = 0;
+  if (op.kind == ACC_COUNT_ROWS) return;
+  if (op.valid != nullptr) {  // aggregates skip NULL inputs
+    uint8_t vb[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) vb[k] = op.valid[row[k] >> 3];
+#pragma unroll
+    for (int k = 0; k < K; k++) take[k] = take[k] && ((vb[k] >> (row[k] & 7)) & 1);
+  }
+  switch (op.in_type) {
+    case CRGPU_BOOL:
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const uint8_t *>(op.data)[row[k]] != 0;
+      break;
+    case CRGPU_INT16:
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int16_t *>(op.data)[row[k]]));
+      break;
+    case CRGPU_INT32:
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int32_t *>(op.data)[row[k]]));
+      break;
+    case CRGPU_BYTES: break;  // COUNT / ANY_NOT_NULL: the payload is not needed here
+    default:
+#pragma unroll
+      for (int k = 0; k < K; k++) v[k] = reinterpret_cast<const unsigned long long *>(op.data)[row[k]];  // INT64 / FLOAT64 bits
+      break;
   }
 }
 
@@ -392,15 +581,40 @@ struct AccArgs {
   unsigned long long seq_base;  // global arrival number of row 0 of this chunk
   uint32_t *miss_list;     // FUSED: chunk rows whose group does not exist yet
   unsigned int *counters;  // [0] new groups, [1] deferred / missed rows
+  // PK: LDS key table over the packed keys of all groups
+  PackSpec pack;
+  const unsigned long long *gpk0, *gpk1;  // [gid] packed key words
+  const uint8_t *gpackable;               // [gid]
+  uint32_t C;                             // key table entries (power of two, >= 2 G)
+  uint32_t _pad2;
 };
 
 // FUSED: hash -> index lookup -> accumulate (misses are listed);  !FUSED: the group comes from out_gid.
 // LDS: accumulate into the workgroup's partial table and merge it at the end;  !LDS: HBM atomics.
-template <bool FUSED, bool LDS>
-__global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
+// PK (with FUSED and LDS): the lookup runs against an LDS table of the groups' packed keys; the HBM index
+// only serves unpackable rows and rows whose group does not exist yet.
+template <bool FUSED, bool LDS, bool PK>
+__global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
   extern __shared__ unsigned long long lds_words[];
   uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * a.G * a.R);
+  // key table: k0[C] | k1[C] (two-word keys) | gid[C]
+  unsigned long long *t_k0 = reinterpret_cast<unsigned long long *>(
+      lds_seen + ((static_cast<size_t>(a.nseen) * a.G * a.R + 7) & ~size_t(7)));
+  unsigned long long *t_k1 = t_k0 + a.C;
+  uint32_t *t_gid = reinterpret_cast<uint32_t *>(a.pack.two_words ? t_k1 + a.C : t_k1);
   const KeyStore &store = a.store;
+  if (PK) {
+    for (uint32_t i = threadIdx.x; i < a.C; i += blockDim.x) t_gid[i] = kGidDefer;
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < a.G; g += blockDim.x) {
+      if (!a.gpackable[g]) continue;
+      const unsigned long long k0 = a.gpk0[g], k1 = a.pack.two_words ? a.gpk1[g] : 0ull;
+      uint32_t idx = pk_hash(k0, k1) & (a.C - 1);
+      while (atomicCAS(&t_gid[idx], kGidDefer, g) != kGidDefer) idx = (idx + 1) & (a.C - 1);  // groups are distinct keys
+      t_k0[idx] = k0;
+      if (a.pack.two_words) t_k1[idx] = k1;
+    }
+  }
   if (LDS) {
     const uint32_t per = a.G * a.R;
     for (int f = 0; f < a.naggs; f++) {
@@ -430,11 +644,32 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
       gid[k] = kGidDefer;
       if (!FUSED && active) gid[k] = a.out_gid[i];
     }
+    if (PK) {
+      bool ok[kAccRows];
+      unsigned long long k0[kAccRows], k1[kAccRows];
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) ok[k] = i0 + k * stride < a.m;
+      pack_rows<kAccRows>(a.keys, a.pack, row, ok, k0, k1);
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) {
+        if (!ok[k]) continue;
+        uint32_t idx = pk_hash(k0[k], k1[k]) & (a.C - 1);
+        for (;;) {
+          const uint32_t g = t_gid[idx];
+          if (g == kGidDefer) break;
+          if (t_k0[idx] == k0[k] && (!a.pack.two_words || t_k1[idx] == k1[k])) {
+            gid[k] = g;
+            break;
+          }
+          idx = (idx + 1) & (a.C - 1);
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kAccRows; k++) {
       const bool active = i0 + k * stride < a.m;
       if (FUSED) {
-        if (active) gid[k] = index_lookup(a.keys, row[k], store, a.meta, a.mask);
+        if (active && gid[k] == kGidDefer) gid[k] = index_lookup(a.keys, row[k], store, a.meta, a.mask);
         const bool miss = active && gid[k] == kGidDefer;
         const uint64_t mm = a.record_misses ? __ballot(miss) : 0;
         if (mm) {
@@ -457,7 +692,8 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
       unsigned long long v[kAccRows];
       bool take[kAccRows];
 #pragma unroll
-      for (int k = 0; k < kAccRows; k++) take[k] = gid[k] != kGidDefer && load_input(op, row[k], v[k]);
+      for (int k = 0; k < kAccRows; k++) take[k] = gid[k] != kGidDefer;
+      load_inputs<kAccRows>(op, row, take, v);
 #pragma unroll
       for (int k = 0; k < kAccRows; k++) {
         if (!take[k]) continue;
@@ -683,6 +919,9 @@ struct FixupArgs {
   uint8_t *const *any_buf;
   unsigned long long *any_tails;
   unsigned long long seq_base;
+  PackSpec pack;
+  unsigned long long *gpk0, *gpk1;
+  uint8_t *gpackable;
 };
 __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
   const KeyStore &st = a.store;
@@ -717,6 +956,13 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
     const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row);
     for (int f = 0; f < a.naggs; f++)
       first_row_store(a.ops[f], f, row, seq, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
+    if (a.pack.enabled) {
+      unsigned long long k0, k1;
+      const bool ok = pack_row(a.keys, a.pack, row, k0, k1);
+      a.gpackable[gid] = ok ? 1 : 0;
+      a.gpk0[gid] = k0;
+      if (a.pack.two_words) a.gpk1[gid] = k1;
+    }
     const unsigned long long w = a.rep_word[p];
     a.gword[gid] = w;
     a.meta[a.rep_slot[p]] = (w & 0xFFFFFFFF00000000ull) | gid;
@@ -905,6 +1151,8 @@ struct crgpu_agg {
   int64_t ngroups = 0;
   size_t gcap = 0;
   DevBuf gword;
+  PackSpec pack;                    // packed-key layout (enabled = 0: keys do not fit 128 bits)
+  DevBuf gpk0, gpk1, gpackable;     // [gid] packed key of each group
   struct KS { DevBuf data, present, b_off, b_len, b_buf; uint64_t tail = 0; };
   std::vector<KS> ks;
 
@@ -978,6 +1226,11 @@ static crgpu_status ensure_groups(crgpu_agg *a, size_t need) {
   size_t ncap = a->gcap ? a->gcap : 1024;
   while (ncap < need) ncap *= 2;
   CRGPU_TRY(a->gword.ensure(ncap * 8, true));
+  if (a->pack.enabled) {
+    CRGPU_TRY(a->gpk0.ensure(ncap * 8, true));
+    if (a->pack.two_words) CRGPU_TRY(a->gpk1.ensure(ncap * 8, true));
+    CRGPU_TRY(a->gpackable.ensure(ncap, true));
+  }
   for (auto &op : a->ops) {
     if (op.has_w0) CRGPU_TRY(op.w0.ensure(ncap * 8, true));
     if (op.has_w1) CRGPU_TRY(op.w1.ensure(ncap * 8, true));
@@ -1021,6 +1274,52 @@ static crgpu_status reindex(crgpu_agg *a, uint32_t new_cap) {
   return CRGPU_OK;
 }
 
+// Packed-key layout: first-fit the value fields (and, when they fit too, one NULL bit per column)
+// into two 64-bit words.  BYTES columns get {length:4, B bytes}, B as large as fits (at most 7).
+static PackSpec plan_pack(const std::vector<int> &types, const std::vector<int> &group_cols) {
+  PackSpec best;
+  std::memset(&best, 0, sizeof(best));
+  const int n = static_cast<int>(group_cols.size());
+  if (n == 0) return best;
+  for (int with_nulls = 1; with_nulls >= 0; with_nulls--) {
+    for (int bbytes = 7; bbytes >= 1; bbytes--) {
+      PackSpec ps;
+      std::memset(&ps, 0, sizeof(ps));
+      int used[2] = {0, 0};
+      bool ok = true, any_bytes = false;
+      auto place = [&](int bits, int8_t &word, int8_t &shift) {
+        for (int w = 0; w < 2; w++)
+          if (used[w] + bits <= 64) {
+            word = static_cast<int8_t>(w);
+            shift = static_cast<int8_t>(used[w]);
+            used[w] += bits;
+            return true;
+          }
+        return false;
+      };
+      for (int c = 0; c < n && ok; c++) {
+        const int t = types[group_cols[c]];
+        int bits = 64;
+        if (t == CRGPU_BOOL) bits = 1;
+        else if (t == CRGPU_INT16) bits = 16;
+        else if (t == CRGPU_INT32) bits = 32;
+        else if (t == CRGPU_BYTES) { bits = 4 + 8 * bbytes; any_bytes = true; }
+        ps.c[c].bbytes = static_cast<int8_t>(t == CRGPU_BYTES ? bbytes : 0);
+        ps.c[c].null_word = -1;
+        ok = place(bits, ps.c[c].word, ps.c[c].shift);
+      }
+      for (int c = 0; c < n && ok && with_nulls; c++) ok = place(1, ps.c[c].null_word, ps.c[c].null_shift);
+      if (ok) {
+        ps.enabled = 1;
+        ps.two_words = used[1] > 0;
+        return ps;
+      }
+      if (!any_bytes) break;  // the BYTES budget is the only thing the inner loop varies
+    }
+  }
+  return best;
+}
+
 extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_agg **out) {
   CRGPU_TRY(ensure_init());
   if (spec == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: null argument");
@@ -1038,6 +1337,7 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
     if (a->types[spec->group_cols[i]] == CRGPU_BYTES) a->bytes_keys = true;
   }
   a->ks = std::vector<crgpu_agg::KS>(spec->n_group);
+  a->pack = plan_pack(a->types, a->group_cols);
   a->ops = std::vector<AggOpHost>(spec->n_aggs);
   for (int f = 0; f < spec->n_aggs; f++) {
     const crgpu_agg_desc &d = spec->aggs[f];
@@ -1111,10 +1411,12 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
   CRGPU_TRY(reindex(a.get(), 256));  // hashAggregator starts with 256 buckets too (hash_aggregator.go:217)
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
-    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsLarge)));
-    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsLarge)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     lds_attr_set = true;
   }
   *out = a.release();
@@ -1147,10 +1449,12 @@ struct AccPlan {
   int block = 256;
   int wgs_per_cu = 8;
   size_t lds_bytes = 0;
+  bool pk = false;   // fused pass: LDS key table over the packed keys
+  uint32_t C = 0;    // its capacity
 };
 // How to accumulate `m` rows into `ngroups` groups: LDS partial tables (one sweep, or a few gid
 // ranges while that stays cheaper than `acc_words` HBM atomics per row), else HBM atomics.
-static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m) {
+static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, bool fused) {
   AccPlan p;
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0 || ngroups <= 0) return p;
@@ -1158,13 +1462,23 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m) {
   if (total <= kLdsLarge) {
     p.lds = true;
     p.G = static_cast<uint32_t>(ngroups);
+    size_t table = 0;
+    if (fused && a->pack.enabled) {
+      const uint32_t C = static_cast<uint32_t>(next_pow2(static_cast<uint64_t>(ngroups) * 2 < 16 ? 16 : static_cast<uint64_t>(ngroups) * 2));
+      const size_t bytes = static_cast<size_t>(C) * (a->pack.two_words ? 20 : 12) + 8;
+      if (total + bytes <= kLdsMax - 1024) {
+        p.pk = true;
+        p.C = C;
+        table = bytes;
+      }
+    }
     uint32_t r = 1;  // replicas: spread the lanes of a wave that hit one group, while 8 workgroups still fit a CU
-    while (r < kMaxReplicas && total * (r * 2) <= kLdsReplicated) r *= 2;
+    while (r < kMaxReplicas && total * (r * 2) + table <= kLdsReplicated) r *= 2;
     p.R = r;
-    p.lds_bytes = total * r;
+    p.lds_bytes = total * r + table;
     const size_t fit = (160 * 1024) / (p.lds_bytes ? p.lds_bytes : 1);
     p.wgs_per_cu = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
-    p.block = p.wgs_per_cu == 8 ? 256 : p.wgs_per_cu == 4 ? 512 : 1024;
+    p.block = p.wgs_per_cu == 8 ? 256 : 512;
     return p;
   }
   const uint32_t per_sweep = static_cast<uint32_t>(kLdsLarge / bpg);
@@ -1178,7 +1492,7 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m) {
     p.G = per_sweep;
     p.R = 1;
     p.sweeps = sweeps;
-    p.block = 1024;
+    p.block = 512;
     p.wgs_per_cu = 1;
     p.lds_bytes = bpg * p.G;
   }
@@ -1207,6 +1521,11 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
   args.miss_list = miss_list;
   args.counters = a->counters.as<unsigned int>();
   args.record_misses = fused ? 1 : 0;
+  args.pack = a->pack;
+  args.gpk0 = a->gpk0.as<unsigned long long>();
+  args.gpk1 = a->gpk1.as<unsigned long long>();
+  args.gpackable = a->gpackable.as<uint8_t>();
+  args.C = plan.pk ? plan.C : 0;
   hipStream_t st = stream();
   dim3 grid, block;
   size_t lds = 0;
@@ -1265,11 +1584,12 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
       }
       ProfScope prof(plan.lds ? (fused ? "agg_fused_lds" : "agg_accum_lds") : (fused ? "agg_fused_hbm" : "agg_accum_hbm"));
       if (plan.lds) {
-        if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, true>), grid, block, lds, st, args);
-        else hipLaunchKernelGGL((agg_accum_kernel<false, true>), grid, block, lds, st, args);
+        if (fused && plan.pk) hipLaunchKernelGGL((agg_accum_kernel<true, true, true>), grid, block, lds, st, args);
+        else if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, true, false>), grid, block, lds, st, args);
+        else hipLaunchKernelGGL((agg_accum_kernel<false, true, false>), grid, block, lds, st, args);
       } else {
-        if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false>), grid, block, 0, st, args);
-        else hipLaunchKernelGGL((agg_accum_kernel<false, false>), grid, block, 0, st, args);
+        if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false, false>), grid, block, 0, st, args);
+        else hipLaunchKernelGGL((agg_accum_kernel<false, false, false>), grid, block, 0, st, args);
       }
       CRGPU_HIP(hipGetLastError());
     }
@@ -1327,7 +1647,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
   const int64_t groups_before = a->ngroups;
 
   // steady state: one fused pass; only rows of groups that do not exist yet remain
-  const AccPlan fused_plan = plan_accumulate(a, a->ngroups, n);
+  const AccPlan fused_plan = plan_accumulate(a, a->ngroups, n, true);
   const bool fused = !a->need_any_fix && a->ngroups > 0 && a->new_ratio < 0.5 && fused_plan.sweeps == 1;
   if (fused) {
     CRGPU_HIP(hipMemsetAsync(a->counters.p, 0, 16, st));
@@ -1408,13 +1728,17 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
       f.any_buf = reinterpret_cast<uint8_t *const *>(a->any_ptrs_dev.as<void *>() + 2 * nops);
       f.any_tails = a->any_tails_dev.as<unsigned long long>();
       f.seq_base = a->seq;
+      f.pack = a->pack;
+      f.gpk0 = a->gpk0.as<unsigned long long>();
+      f.gpk1 = a->gpk1.as<unsigned long long>();
+      f.gpackable = a->gpackable.as<uint8_t>();
       ProfScope prof("agg_fixup");
       hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for(nnew, 256)), dim3(256), 0, st, f);
       CRGPU_HIP(hipGetLastError());
       a->ngroups += nnew;
     }
     if (static_cast<int64_t>(ndef) + static_cast<int64_t>(nnew) < in.m) {  // rows besides claimants (fixup) and deferred ones
-      const AccPlan plan = plan_accumulate(a, a->ngroups, in.m);
+      const AccPlan plan = plan_accumulate(a, a->ngroups, in.m, false);
       CRGPU_TRY(launch_accumulate(a, in, false, nullptr, plan));
       if (a->need_any_fix) {
         const size_t nops = a->ops.size();
@@ -1474,10 +1798,12 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
     if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null data pointer");
     in.push_back(to_dcol(cols[c]));
   }
-  // chunking: a small first chunk discovers the cardinality regime, then 16M-row chunks
-  const int64_t kChunk = int64_t(1) << 24;
+  // chunking: a small first chunk discovers the cardinality regime, then 16M-row chunks (the per-row
+  // temporaries of find-or-insert are sized by the chunk); once hardly any new group appears the fused
+  // pass needs none of them and larger chunks mean fewer merges of the LDS partial tables
   int64_t pos = 0;
   while (pos < n) {
+    const int64_t kChunk = (a->seq > 0 && a->new_ratio < 0.01 && !a->need_any_fix) ? int64_t(1) << 28 : int64_t(1) << 24;
     int64_t len = n - pos < kChunk ? n - pos : kChunk;
     if (a->seq == 0 && len > 65536) len = 65536;
     std::vector<DCol> chunk = in;
