@@ -34,6 +34,7 @@
 //    tolerance rel 1e-9).
 //
 // Roofline: HBM-bound (streaming input; LDS atomics are far from their limit).
+#include <algorithm>
 #include <cstring>
 #include <memory>
 
@@ -51,7 +52,6 @@ static constexpr uint32_t kMaxCap = 1u << 30;          // index entries (=> at m
 static constexpr uint32_t kIdxHashMask = kMaxCap - 1;
 static constexpr size_t kLdsReplicated = 20 * 1024;    // replicate small partial tables up to this size (8 workgroups per CU)
 static constexpr size_t kLdsLarge = 152 * 1024;        // largest partial table: one 1024-thread workgroup per CU
-static constexpr uint32_t kMaxSweeps = 8;
 static constexpr size_t kLdsMax = 160 * 1024;
 static constexpr int kMaxReplicas = 32;
 static constexpr int kAccRows = 8;                     // rows per thread and iteration in the accumulate kernels
@@ -211,36 +211,48 @@ struct PackSpec {
   int32_t two_words;
   PackCol c[kMaxKeyCols];
 };
-__device__ __forceinline__ bool pack_row(const KeyCols &k, const PackSpec &ps, int64_t row, unsigned long long &k0,
-                                         unsigned long long &k1) {
+// packed key of the stored key of group gid (false: the group's key is unpackable)
+__device__ inline bool pack_group(const KeyStore &st, const PackSpec &ps, uint32_t gid, unsigned long long &k0,
+                                  unsigned long long &k1) {
   k0 = 0;
   k1 = 0;
-  for (int c = 0; c < k.n; c++) {
-    const DCol &x = k.c[c];
+  for (int c = 0; c < st.n; c++) {
+    const KeyStoreCol &s = st.c[c];
     const PackCol &pc = ps.c[c];
     unsigned long long v;
     int word = pc.word, shift = pc.shift;
-    if (col_is_null(x, row)) {
+    if (s.present[gid] == 0) {
       if (pc.null_word < 0) return false;
       v = 1;
       word = pc.null_word;
       shift = pc.null_shift;
-    } else if (x.type == CRGPU_BYTES) {
-      const uint32_t a0 = x.offsets[row], len = x.offsets[row + 1] - a0;
-      if (len > static_cast<uint32_t>(pc.bbytes)) return false;
-      const uint8_t *p = reinterpret_cast<const uint8_t *>(x.data) + a0;
-      v = len;
-      for (uint32_t j = 0; j < len; j++) v |= static_cast<unsigned long long>(p[j]) << (4 + 8 * j);
     } else {
-      v = pack_key(x, row);
-      if (x.type == CRGPU_INT16) v &= 0xFFFFull;
-      if (x.type == CRGPU_INT32) v &= 0xFFFFFFFFull;
+      switch (s.type) {
+        case CRGPU_BYTES: {
+          const uint32_t len = s.b_len[gid];
+          if (len > static_cast<uint32_t>(pc.bbytes)) return false;
+          const uint8_t *p = s.b_buf + s.b_off[gid];
+          v = len;
+          for (uint32_t j = 0; j < len; j++) v |= static_cast<unsigned long long>(p[j]) << (4 + 8 * j);
+          break;
+        }
+        case CRGPU_BOOL: v = s.data[gid] != 0; break;
+        case CRGPU_INT16: v = reinterpret_cast<const uint16_t *>(s.data)[gid]; break;
+        case CRGPU_INT32: v = reinterpret_cast<const uint32_t *>(s.data)[gid]; break;
+        case CRGPU_FLOAT64: {
+          const double f = reinterpret_cast<const double *>(s.data)[gid];
+          v = f != f ? 0x7FF8000000000000ull : (f == 0 ? 0ull : static_cast<unsigned long long>(__double_as_longlong(f)));
+          break;
+        }
+        default: v = reinterpret_cast<const unsigned long long *>(s.data)[gid]; break;
+      }
     }
     if (word) k1 |= v << shift;
     else k0 |= v << shift;
   }
   return true;
 }
+
 // pack_row for the kAccRows rows of a thread, column-wise (see load_inputs): fixed-width columns load
 // branch-free; BYTES columns keep a per-row branch for their variable length.
 template <int K>
@@ -362,20 +374,6 @@ __device__ __forceinline__ void add_i128(unsigned long long *lo, unsigned long l
 // (float bits / sign-extended integer / bool); (2) the atomic update.
 __device__ __forceinline__ bool bit_valid(const uint8_t *valid, int64_t i) {
   return valid == nullptr || ((valid[i >> 3] >> (i & 7)) & 1);  // coldata.Nulls: bit = 1 => present
-}
-__device__ __forceinline__ bool load_input(const OpK &op, int64_t row, unsigned long long &v) {
-  v = 0;
-  if (op.has_filter && (!bit_valid(op.fvalid, row) || op.fdata[row] == 0)) return false;  // aggregators_util.go:216-234
-  if (op.kind == ACC_COUNT_ROWS) return true;
-  if (!bit_valid(op.valid, row)) return false;  // aggregates skip NULL inputs
-  switch (op.in_type) {
-    case CRGPU_BOOL: v = reinterpret_cast<const uint8_t *>(op.data)[row] != 0; break;
-    case CRGPU_INT16: v = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int16_t *>(op.data)[row])); break;
-    case CRGPU_INT32: v = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int32_t *>(op.data)[row])); break;
-    case CRGPU_BYTES: break;  // COUNT / ANY_NOT_NULL: the payload is not needed here
-    default: v = reinterpret_cast<const unsigned long long *>(op.data)[row]; break;  // INT64 / FLOAT64 bits
-  }
-  return true;
 }
 __device__ __forceinline__ void apply_input(const OpK &op, unsigned long long v, unsigned long long seq,
                                             unsigned long long *w0, unsigned long long *w1, uint8_t *seen) {
@@ -583,8 +581,6 @@ struct AccArgs {
   unsigned int *counters;  // [0] new groups, [1] deferred / missed rows
   // PK: LDS key table over the packed keys of all groups
   PackSpec pack;
-  const unsigned long long *gpk0, *gpk1;  // [gid] packed key words
-  const uint8_t *gpackable;               // [gid]
   uint32_t C;                             // key table entries (power of two, >= 2 G)
   uint32_t _pad2;
 };
@@ -607,8 +603,8 @@ __global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
     for (uint32_t i = threadIdx.x; i < a.C; i += blockDim.x) t_gid[i] = kGidDefer;
     __syncthreads();
     for (uint32_t g = threadIdx.x; g < a.G; g += blockDim.x) {
-      if (!a.gpackable[g]) continue;
-      const unsigned long long k0 = a.gpk0[g], k1 = a.pack.two_words ? a.gpk1[g] : 0ull;
+      unsigned long long k0, k1;
+      if (!pack_group(store, a.pack, g, k0, k1)) continue;
       uint32_t idx = pk_hash(k0, k1) & (a.C - 1);
       while (atomicCAS(&t_gid[idx], kGidDefer, g) != kGidDefer) idx = (idx + 1) & (a.C - 1);  // groups are distinct keys
       t_k0[idx] = k0;
@@ -720,6 +716,233 @@ __global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ gid-partitioned accumulation
+// Too many groups for one LDS partial table, and HBM atomics run at ~24 G/s however they are laid out:
+// so the rows are first regrouped by gid RANGE (partition p = gids [p << shift, (p + 1) << shift)), together
+// with everything accumulation needs -- the gid, one "takes this row" bit per aggregation (FILTER and NULL
+// tests evaluated here, once) and the input values widened to 64 bits, each as a dense column.  Every
+// partition is then accumulated by a few workgroups in an LDS partial table exactly like the small case.
+static constexpr int kPartTile = 16384;       // rows per tile: 256 threads x 64 (long runs per partition: the stores combine in L2)
+static constexpr int kPartRows = 8;           // rows per thread and step (two steps per tile)
+static constexpr int kMaxPartCols = 12;
+static constexpr uint32_t kMaxParts = 1024;
+
+struct PartArgs {
+  int64_t m;
+  const uint32_t *list;
+  const uint32_t *out_gid;
+  const unsigned long long *meta;
+  uint32_t shift, P, ntiles;
+  int32_t naggs, ncols, _pad;
+  uint32_t *gid_res;          // [m] resolved gid (kGidDefer: row is not part of this pass)
+  uint32_t *tile_hist;        // [P][ntiles]
+  const uint64_t *offsets;    // exclusive scan of tile_hist
+  uint32_t *gid_out;          // [rows of the pass] partition-ordered
+  uint32_t *flags_out;
+  const void *src[kMaxPartCols];
+  unsigned long long *dst[kMaxPartCols];
+  int8_t src_type[kMaxPartCols];
+  int32_t _pad2;
+  OpK ops[kMaxOpsPerLaunch];  // FILTER / validity pointers of each aggregation
+};
+
+__global__ __launch_bounds__(256) void agg_part_hist_kernel(PartArgs a) {
+  __shared__ uint32_t cnt[kMaxParts];
+  for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < a.P; p += 256) cnt[p] = 0;
+    __syncthreads();
+    const int64_t base = static_cast<int64_t>(tile) * kPartTile;
+#pragma unroll
+    for (int r = 0; r < kPartTile / 256; r++) {
+      const int64_t i = base + r * 256 + threadIdx.x;
+      if (i < a.m) {
+        uint32_t g = a.out_gid[i];
+        if (g != kGidDefer && (g & kGidSlotRef)) g = static_cast<uint32_t>(a.meta[g & ~kGidSlotRef]);
+        a.gid_res[i] = g;
+        if (g != kGidDefer) atomicAdd(&cnt[g >> a.shift], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < a.P; p += 256) a.tile_hist[static_cast<size_t>(p) * a.ntiles + tile] = cnt[p];
+    __syncthreads();
+  }
+}
+
+// bit f of the result: aggregation f accumulates this row (FILTER true and, except COUNT_ROWS, input not NULL)
+template <int K>
+__device__ __forceinline__ void take_bits(const OpK *ops, int naggs, const int64_t (&row)[K], uint32_t (&bits)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; k++) bits[k] = 0;
+  for (int f = 0; f < naggs; f++) {
+    const OpK &op = ops[f];
+    bool take[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) take[k] = true;
+    if (op.has_filter) {
+      uint8_t fb[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) fb[k] = op.fdata[row[k]];
+      if (op.fvalid != nullptr) {
+        uint8_t fv[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) fv[k] = op.fvalid[row[k] >> 3];
+#pragma unroll
+        for (int k = 0; k < K; k++) take[k] = take[k] && ((fv[k] >> (row[k] & 7)) & 1);
+      }
+#pragma unroll
+      for (int k = 0; k < K; k++) take[k] = take[k] && fb[k] != 0;
+    }
+    if (op.kind != ACC_COUNT_ROWS && op.valid != nullptr) {
+      uint8_t vb[K];
+#pragma unroll
+      for (int k = 0; k < K; k++) vb[k] = op.valid[row[k] >> 3];
+#pragma unroll
+      for (int k = 0; k < K; k++) take[k] = take[k] && ((vb[k] >> (row[k] & 7)) & 1);
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) bits[k] |= (take[k] ? 1u : 0u) << f;
+  }
+}
+
+__global__ __launch_bounds__(256) void agg_part_scatter_kernel(PartArgs a) {
+  __shared__ uint32_t cnt[kMaxParts], start[kMaxParts];
+  for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (uint32_t p = threadIdx.x; p < a.P; p += 256) {
+      cnt[p] = 0;
+      start[p] = static_cast<uint32_t>(a.offsets[static_cast<size_t>(p) * a.ntiles + tile]);
+    }
+    __syncthreads();
+    const int64_t base = static_cast<int64_t>(tile) * kPartTile;
+    for (int step = 0; step < kPartTile / 256 / kPartRows; step++) {
+      int64_t row[kPartRows];
+      uint32_t g[kPartRows], dest[kPartRows], bits[kPartRows];
+#pragma unroll
+      for (int k = 0; k < kPartRows; k++) {
+        const int64_t i = base + (step * kPartRows + k) * 256 + threadIdx.x;
+        const bool active = i < a.m;
+        g[k] = active ? a.gid_res[i] : kGidDefer;
+        row[k] = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPartRows; k++) {
+        dest[k] = 0;
+        if (g[k] != kGidDefer) {
+          const uint32_t p = g[k] >> a.shift;
+          dest[k] = start[p] + atomicAdd(&cnt[p], 1u);
+        }
+      }
+      take_bits<kPartRows>(a.ops, a.naggs, row, bits);
+#pragma unroll
+      for (int k = 0; k < kPartRows; k++) {
+        if (g[k] == kGidDefer) continue;
+        a.gid_out[dest[k]] = g[k];
+        a.flags_out[dest[k]] = bits[k];
+      }
+      for (int c = 0; c < a.ncols; c++) {
+        unsigned long long v[kPartRows];
+        switch (a.src_type[c]) {
+          case CRGPU_BOOL:
+#pragma unroll
+            for (int k = 0; k < kPartRows; k++) v[k] = reinterpret_cast<const uint8_t *>(a.src[c])[row[k]] != 0;
+            break;
+          case CRGPU_INT16:
+#pragma unroll
+            for (int k = 0; k < kPartRows; k++) v[k] = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int16_t *>(a.src[c])[row[k]]));
+            break;
+          case CRGPU_INT32:
+#pragma unroll
+            for (int k = 0; k < kPartRows; k++) v[k] = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int32_t *>(a.src[c])[row[k]]));
+            break;
+          default:
+#pragma unroll
+            for (int k = 0; k < kPartRows; k++) v[k] = reinterpret_cast<const unsigned long long *>(a.src[c])[row[k]];
+            break;
+        }
+#pragma unroll
+        for (int k = 0; k < kPartRows; k++)
+          if (g[k] != kGidDefer) a.dst[c][dest[k]] = v[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void agg_part_starts_kernel(const uint64_t *__restrict__ offsets, uint32_t P, uint32_t ntiles,
+                                                              uint64_t *__restrict__ starts) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p <= P) starts[p] = offsets[static_cast<size_t>(p) * ntiles];  // p == P: the grand total
+}
+
+struct PartWg {  // one workgroup of the partitioned accumulate: rows [begin, end) of partition `part`
+  uint32_t part, _pad;
+  uint64_t begin, end;
+};
+struct PartAccArgs {
+  OpK ops[kMaxOpsPerLaunch];  // data: the partition-ordered 64-bit value column of the op's input
+  int32_t naggs;
+  uint32_t shift;
+  uint32_t nwords, nseen;
+  int64_t ngroups;
+  const uint32_t *gid;
+  const uint32_t *flags;
+  const PartWg *wgs;
+};
+__global__ __launch_bounds__(512) void agg_part_accum_kernel(PartAccArgs a) {
+  extern __shared__ unsigned long long lds_words[];
+  const PartWg d = a.wgs[blockIdx.x];
+  const uint32_t gid_lo = d.part << a.shift;
+  const int64_t left = a.ngroups - static_cast<int64_t>(gid_lo);
+  const uint32_t G = static_cast<uint32_t>(left < (int64_t(1) << a.shift) ? left : (int64_t(1) << a.shift));
+  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * G);
+  for (int f = 0; f < a.naggs; f++) {
+    const OpK &op = a.ops[f];
+    if (op.lw0 >= 0) {
+      const unsigned long long init = acc_init_w0(op.kind);
+      for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * G + i] = init;
+    }
+    if (op.lw1 >= 0)
+      for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * G + i] = 0ull;
+  }
+  for (uint32_t i = threadIdx.x; i < a.nseen * G; i += blockDim.x) lds_seen[i] = 0;
+  __syncthreads();
+  for (uint64_t j0 = d.begin + threadIdx.x; j0 < d.end; j0 += static_cast<uint64_t>(blockDim.x) * kAccRows) {
+    uint64_t j[kAccRows];
+    uint32_t g[kAccRows], fl[kAccRows];
+#pragma unroll
+    for (int k = 0; k < kAccRows; k++) {
+      const uint64_t jj = j0 + static_cast<uint64_t>(k) * blockDim.x;
+      j[k] = jj < d.end ? jj : d.end - 1;  // clamped: the loads below stay unconditional
+      g[k] = a.gid[j[k]] - gid_lo;
+      fl[k] = jj < d.end ? a.flags[j[k]] : 0u;
+    }
+    for (int f = 0; f < a.naggs; f++) {
+      const OpK &op = a.ops[f];
+      unsigned long long v[kAccRows];
+      if (op.data != nullptr) {
+#pragma unroll
+        for (int k = 0; k < kAccRows; k++) v[k] = reinterpret_cast<const unsigned long long *>(op.data)[j[k]];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kAccRows; k++) v[k] = 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) {
+        if (!((fl[k] >> f) & 1u)) continue;
+        unsigned long long *w0 = lds_words + static_cast<size_t>(op.lw0) * G + g[k];
+        unsigned long long *w1 = lds_words + static_cast<size_t>(op.lw1) * G + g[k];
+        uint8_t *seen = lds_seen + static_cast<size_t>(op.lseen) * G + g[k];
+        apply_input(op, v[k], 0ull, w0, w1, seen);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t pairs = G * static_cast<uint32_t>(a.naggs);
+  for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
+    const uint32_t f = t / G, g = t - f * G;
+    lds_flush_op(a.ops[f], lds_words, lds_seen, G, 1, g, gid_lo + g);
+  }
+}
+
 // ------------------------------------------------------------------ find-or-insert (rows whose group may not exist yet)
 struct ResolveArgs {
   KeyCols keys;
@@ -728,7 +951,7 @@ struct ResolveArgs {
   const uint32_t *list;
   unsigned long long *meta;
   uint32_t mask;
-  uint32_t _pad;
+  uint32_t cas_first;             // most rows belong to groups that do not exist yet: claim without looking first
   uint32_t *out_gid;              // [m]
   uint32_t *rep_pos, *rep_slot;   // [new groups]: claimant position / index slot
   unsigned long long *rep_word;   // [new groups]: {upper:32 | idx hash:32}
@@ -765,8 +988,9 @@ __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
         const unsigned long long claim = (static_cast<unsigned long long>(rh.upper | kClaimBit) << 32) | static_cast<uint32_t>(i);
         uint32_t idx = rh.idx & a.mask;
         for (int probes = 0; probes < kMaxProbe; probes++) {
-          // rows that reach this kernel mostly belong to groups that do not exist yet: try to claim first
-          const unsigned long long e = atomicCAS(&a.meta[idx], kMetaEmpty, claim);
+          // A failed CAS still costs an HBM atomic (~24 G/s), a load does not: look first unless most rows are new groups
+          unsigned long long e = a.cas_first ? kMetaEmpty : __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (e == kMetaEmpty) e = atomicCAS(&a.meta[idx], kMetaEmpty, claim);
           if (e == kMetaEmpty) {
             is_new[k] = true;
             slot[k] = idx;
@@ -919,9 +1143,6 @@ struct FixupArgs {
   uint8_t *const *any_buf;
   unsigned long long *any_tails;
   unsigned long long seq_base;
-  PackSpec pack;
-  unsigned long long *gpk0, *gpk1;
-  uint8_t *gpackable;
 };
 __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
   const KeyStore &st = a.store;
@@ -956,13 +1177,6 @@ __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
     const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row);
     for (int f = 0; f < a.naggs; f++)
       first_row_store(a.ops[f], f, row, seq, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
-    if (a.pack.enabled) {
-      unsigned long long k0, k1;
-      const bool ok = pack_row(a.keys, a.pack, row, k0, k1);
-      a.gpackable[gid] = ok ? 1 : 0;
-      a.gpk0[gid] = k0;
-      if (a.pack.two_words) a.gpk1[gid] = k1;
-    }
     const unsigned long long w = a.rep_word[p];
     a.gword[gid] = w;
     a.meta[a.rep_slot[p]] = (w & 0xFFFFFFFF00000000ull) | gid;
@@ -1152,7 +1366,6 @@ struct crgpu_agg {
   size_t gcap = 0;
   DevBuf gword;
   PackSpec pack;                    // packed-key layout (enabled = 0: keys do not fit 128 bits)
-  DevBuf gpk0, gpk1, gpackable;     // [gid] packed key of each group
   struct KS { DevBuf data, present, b_off, b_len, b_buf; uint64_t tail = 0; };
   std::vector<KS> ks;
 
@@ -1164,6 +1377,9 @@ struct crgpu_agg {
   DevBuf ops_dev, tails_dev, any_tails_dev, any_ptrs_dev;
   DevBuf counters, out_gid, list_a, list_b, rep_pos, rep_slot, rep_word, scratch, err_dev;
   DevBuf lens_tmp, offs64_tmp, present_tmp;
+  // gid-partitioned accumulation
+  DevBuf p_gid_res, p_hist, p_offsets, p_gid, p_flags, p_wgs, p_starts;
+  DevBuf p_cols[kMaxPartCols];
   std::vector<OutCol> out;
   std::vector<crgpu_dcol> views;
 };
@@ -1226,11 +1442,6 @@ static crgpu_status ensure_groups(crgpu_agg *a, size_t need) {
   size_t ncap = a->gcap ? a->gcap : 1024;
   while (ncap < need) ncap *= 2;
   CRGPU_TRY(a->gword.ensure(ncap * 8, true));
-  if (a->pack.enabled) {
-    CRGPU_TRY(a->gpk0.ensure(ncap * 8, true));
-    if (a->pack.two_words) CRGPU_TRY(a->gpk1.ensure(ncap * 8, true));
-    CRGPU_TRY(a->gpackable.ensure(ncap, true));
-  }
   for (auto &op : a->ops) {
     if (op.has_w0) CRGPU_TRY(op.w0.ensure(ncap * 8, true));
     if (op.has_w1) CRGPU_TRY(op.w1.ensure(ncap * 8, true));
@@ -1417,6 +1628,8 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_part_accum_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     lds_attr_set = true;
   }
   *out = a.release();
@@ -1451,10 +1664,12 @@ struct AccPlan {
   size_t lds_bytes = 0;
   bool pk = false;   // fused pass: LDS key table over the packed keys
   uint32_t C = 0;    // its capacity
+  bool part = false; // regroup the rows by gid range first, then LDS partial tables per range
+  uint32_t shift = 0, P = 0;
 };
 // How to accumulate `m` rows into `ngroups` groups: LDS partial tables (one sweep, or a few gid
 // ranges while that stays cheaper than `acc_words` HBM atomics per row), else HBM atomics.
-static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, bool fused) {
+static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, bool fused, bool fused_only_lds = false) {
   AccPlan p;
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0 || ngroups <= 0) return p;
@@ -1481,20 +1696,30 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, b
     p.block = p.wgs_per_cu == 8 ? 256 : 512;
     return p;
   }
-  const uint32_t per_sweep = static_cast<uint32_t>(kLdsLarge / bpg);
-  const uint32_t sweeps = static_cast<uint32_t>((static_cast<uint64_t>(ngroups) + per_sweep - 1) / per_sweep);
-  // every sweep walks all rows again (4-byte gid + the op loop for waves with a row in range): measured ~1 ms
-  // per 2^27 rows and sweep, against acc_words / 24 G/s for HBM atomics
-  const double sweep_cost = static_cast<double>(sweeps) * 1.0e-3 / 134217728.0;
-  const double atomic_cost = static_cast<double>(a->acc_words > 0 ? a->acc_words : 1) / 24e9;
-  if (m >= 65536 && sweeps <= kMaxSweeps && sweep_cost < atomic_cost) {
-    p.lds = true;
-    p.G = per_sweep;
-    p.R = 1;
-    p.sweeps = sweeps;
-    p.block = 512;
-    p.wgs_per_cu = 1;
-    p.lds_bytes = bpg * p.G;
+  // gid-partitioned: ranges of 2^shift groups, each with a partial table of at most kLdsLarge bytes
+  {
+    uint32_t shift = 0;
+    while ((bpg << (shift + 1)) <= kLdsLarge) shift++;
+    const uint64_t P = (static_cast<uint64_t>(ngroups) + (1ull << shift) - 1) >> shift;
+    int nops = 0;
+    std::vector<int> cols;
+    for (const AggOpHost &h : a->ops) {
+      if (h.kind == ACC_ANY_KEY) continue;
+      nops++;
+      if (h.kind != ACC_COUNT_ROWS && h.in_type != CRGPU_BYTES && std::find(cols.begin(), cols.end(), h.col) == cols.end())
+        cols.push_back(h.col);
+    }
+    // moving a row costs ~(8 + 8 per value column) bytes written and read again; an HBM atomic costs 1/24 ns
+    const double move_cost = (16.0 + 16.0 * static_cast<double>(cols.size())) / 3e12;
+    const double atomic_cost = static_cast<double>(a->acc_words > 0 ? a->acc_words : 1) / 24e9;
+    if (!fused_only_lds && !a->need_any_fix && m >= (int64_t(1) << 18) && P <= kMaxParts && nops <= kMaxOpsPerLaunch &&
+        static_cast<int>(cols.size()) <= kMaxPartCols && move_cost < atomic_cost) {
+      p.part = true;
+      p.shift = shift;
+      p.P = static_cast<uint32_t>(P);
+      p.block = 512;
+      p.lds_bytes = bpg << shift;
+    }
   }
   return p;
 }
@@ -1522,9 +1747,6 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
   args.counters = a->counters.as<unsigned int>();
   args.record_misses = fused ? 1 : 0;
   args.pack = a->pack;
-  args.gpk0 = a->gpk0.as<unsigned long long>();
-  args.gpk1 = a->gpk1.as<unsigned long long>();
-  args.gpackable = a->gpackable.as<uint8_t>();
   args.C = plan.pk ? plan.C : 0;
   hipStream_t st = stream();
   dim3 grid, block;
@@ -1598,6 +1820,139 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
   return CRGPU_OK;
 }
 
+// Regroup the rows of the pass by gid range and accumulate every range in LDS (see the kernels above).
+static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const AccPlan &plan) {
+  hipStream_t st = stream();
+  const uint32_t P = plan.P;
+  const uint32_t ntiles = static_cast<uint32_t>((in.m + kPartTile - 1) / kPartTile);
+  const size_t m = static_cast<size_t>(in.m);
+  // aggregation descriptors + the distinct value columns they read
+  std::vector<OpK> ops;
+  std::vector<int> cols, op_slot;
+  for (const AggOpHost &h : a->ops) {
+    if (h.kind == ACC_ANY_KEY) continue;
+    OpK k;
+    std::memset(&k, 0, sizeof(k));
+    k.kind = static_cast<int8_t>(h.kind);
+    k.in_type = static_cast<int8_t>(h.in_type);
+    k.has_filter = h.filter_col >= 0;
+    k.lw0 = static_cast<int8_t>(h.lw0);
+    k.lw1 = static_cast<int8_t>(h.lw1);
+    k.lseen = static_cast<int8_t>(h.lseen);
+    if (h.col >= 0) k.valid = (*in.cols)[h.col].valid;
+    if (h.filter_col >= 0) {
+      k.fdata = static_cast<const uint8_t *>((*in.cols)[h.filter_col].data);
+      k.fvalid = (*in.cols)[h.filter_col].valid;
+    }
+    k.w0 = h.w0.as<unsigned long long>();
+    k.w1 = h.w1.as<unsigned long long>();
+    k.seen = h.seen.as<uint8_t>();
+    int slot = -1;
+    if (h.kind != ACC_COUNT_ROWS && h.in_type != CRGPU_BYTES) {
+      auto it = std::find(cols.begin(), cols.end(), h.col);
+      slot = static_cast<int>(it - cols.begin());
+      if (it == cols.end()) cols.push_back(h.col);
+    }
+    ops.push_back(k);
+    op_slot.push_back(slot);
+  }
+  CRGPU_TRY(a->p_gid_res.ensure(m * 4));
+  CRGPU_TRY(a->p_hist.ensure(static_cast<size_t>(P) * ntiles * 4));
+  CRGPU_TRY(a->p_offsets.ensure((static_cast<size_t>(P) * ntiles + 1) * 8));
+  CRGPU_TRY(a->p_gid.ensure(m * 4));
+  CRGPU_TRY(a->p_flags.ensure(m * 4));
+  for (size_t c = 0; c < cols.size(); c++) CRGPU_TRY(a->p_cols[c].ensure(m * 8));
+
+  PartArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.m = in.m;
+  pa.list = in.list;
+  pa.out_gid = a->out_gid.as<uint32_t>();
+  pa.meta = a->meta.as<unsigned long long>();
+  pa.shift = plan.shift;
+  pa.P = P;
+  pa.ntiles = ntiles;
+  pa.naggs = static_cast<int32_t>(ops.size());
+  pa.ncols = static_cast<int32_t>(cols.size());
+  pa.gid_res = a->p_gid_res.as<uint32_t>();
+  pa.tile_hist = a->p_hist.as<uint32_t>();
+  pa.offsets = a->p_offsets.as<uint64_t>();
+  pa.gid_out = a->p_gid.as<uint32_t>();
+  pa.flags_out = a->p_flags.as<uint32_t>();
+  for (size_t c = 0; c < cols.size(); c++) {
+    pa.src[c] = (*in.cols)[cols[c]].data;
+    pa.src_type[c] = static_cast<int8_t>((*in.cols)[cols[c]].type);
+    pa.dst[c] = a->p_cols[c].as<unsigned long long>();
+  }
+  if (!ops.empty()) std::memcpy(pa.ops, ops.data(), sizeof(OpK) * ops.size());
+  const dim3 grid(static_cast<unsigned int>(ntiles < static_cast<uint32_t>(num_cus()) * 8 ? ntiles : num_cus() * 8));
+  uint64_t total = 0;
+  {
+    ProfScope prof("agg_part_hist");
+    hipLaunchKernelGGL(agg_part_hist_kernel, grid, dim3(256), 0, st, pa);
+    CRGPU_HIP(hipGetLastError());
+  }
+  CRGPU_TRY(exclusive_scan_u32(a->p_hist.as<uint32_t>(), static_cast<int64_t>(P) * ntiles, a->p_offsets.as<uint64_t>(),
+                               a->scratch, &total));
+  {
+    ProfScope prof("agg_part_scatter");
+    hipLaunchKernelGGL(agg_part_scatter_kernel, grid, dim3(256), 0, st, pa);
+    CRGPU_HIP(hipGetLastError());
+  }
+  // partition boundaries: offsets[p * ntiles] for every p, then `total`
+  std::vector<uint64_t> starts(static_cast<size_t>(P) + 1, 0);
+  CRGPU_TRY(a->p_starts.ensure((static_cast<size_t>(P) + 1) * 8));
+  hipLaunchKernelGGL(agg_part_starts_kernel, dim3((P + 256) / 256), dim3(256), 0, st, a->p_offsets.as<uint64_t>(), P, ntiles,
+                     a->p_starts.as<uint64_t>());
+  CRGPU_HIP(hipGetLastError());
+  CRGPU_HIP(hipMemcpyAsync(starts.data(), a->p_starts.p, (static_cast<size_t>(P) + 1) * 8, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  // a few fat workgroups per partition: every one merges a whole partial table at the end
+  const uint64_t target_wgs = static_cast<uint64_t>(num_cus()) * 2;
+  uint64_t rows_per_wg = (total + target_wgs - 1) / target_wgs;
+  if (rows_per_wg < 8192) rows_per_wg = 8192;
+  std::vector<PartWg> wgs;
+  for (uint32_t q = 0; q < P; q++) {
+    const uint64_t b = starts[q], e = starts[q + 1];
+    if (e <= b) continue;
+    const uint64_t nw = (e - b + rows_per_wg - 1) / rows_per_wg;
+    const uint64_t per = (e - b + nw - 1) / nw;
+    for (uint64_t w = 0; w < nw; w++) {
+      PartWg d;
+      d.part = q;
+      d._pad = 0;
+      d.begin = b + w * per;
+      d.end = d.begin + per < e ? d.begin + per : e;
+      if (d.begin < d.end) wgs.push_back(d);
+    }
+  }
+  if (wgs.empty()) return CRGPU_OK;
+  CRGPU_TRY(a->p_wgs.ensure(wgs.size() * sizeof(PartWg)));
+  CRGPU_HIP(hipMemcpyAsync(a->p_wgs.p, wgs.data(), wgs.size() * sizeof(PartWg), hipMemcpyHostToDevice, st));
+  PartAccArgs aa;
+  std::memset(&aa, 0, sizeof(aa));
+  for (size_t f = 0; f < ops.size(); f++) {
+    aa.ops[f] = ops[f];
+    aa.ops[f].data = op_slot[f] >= 0 ? a->p_cols[op_slot[f]].p : nullptr;
+  }
+  aa.naggs = static_cast<int32_t>(ops.size());
+  aa.shift = plan.shift;
+  aa.nwords = static_cast<uint32_t>(a->lds_words);
+  aa.nseen = static_cast<uint32_t>(a->lds_seen);
+  aa.ngroups = a->ngroups;
+  aa.gid = a->p_gid.as<uint32_t>();
+  aa.flags = a->p_flags.as<uint32_t>();
+  aa.wgs = a->p_wgs.as<PartWg>();
+  {
+    ProfScope prof("agg_part_accum");
+    hipLaunchKernelGGL(agg_part_accum_kernel, dim3(static_cast<unsigned int>(wgs.size())), dim3(512),
+                       (plan.lds_bytes + 15) & ~size_t(15), st, aa);
+    CRGPU_HIP(hipGetLastError());
+  }
+  CRGPU_HIP(hipStreamSynchronize(st));  // `wgs` is a host temporary
+  return CRGPU_OK;
+}
+
 static crgpu_status read_counters(crgpu_agg *a, unsigned int *out2) {
   unsigned int c[4] = {0, 0, 0, 0};
   CRGPU_HIP(hipMemcpyAsync(c, a->counters.p, 16, hipMemcpyDeviceToHost, stream()));
@@ -1648,7 +2003,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
 
   // steady state: one fused pass; only rows of groups that do not exist yet remain
   const AccPlan fused_plan = plan_accumulate(a, a->ngroups, n, true);
-  const bool fused = !a->need_any_fix && a->ngroups > 0 && a->new_ratio < 0.5 && fused_plan.sweeps == 1;
+  const bool fused = !a->need_any_fix && a->ngroups > 0 && a->new_ratio < 0.5 && fused_plan.sweeps == 1 && !fused_plan.part;
   if (fused) {
     CRGPU_HIP(hipMemsetAsync(a->counters.p, 0, 16, st));
     CRGPU_TRY(launch_accumulate(a, in, true, next_list, fused_plan));
@@ -1690,6 +2045,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     r.list = in.list;
     r.meta = a->meta.as<unsigned long long>();
     r.mask = a->cap - 1;
+    r.cas_first = (cur_list != nullptr || a->new_ratio >= 0.5) ? 1u : 0u;  // misses of a fused pass, or mostly new groups
     r.out_gid = a->out_gid.as<uint32_t>();
     r.rep_pos = a->rep_pos.as<uint32_t>();
     r.rep_slot = a->rep_slot.as<uint32_t>();
@@ -1728,10 +2084,6 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
       f.any_buf = reinterpret_cast<uint8_t *const *>(a->any_ptrs_dev.as<void *>() + 2 * nops);
       f.any_tails = a->any_tails_dev.as<unsigned long long>();
       f.seq_base = a->seq;
-      f.pack = a->pack;
-      f.gpk0 = a->gpk0.as<unsigned long long>();
-      f.gpk1 = a->gpk1.as<unsigned long long>();
-      f.gpackable = a->gpackable.as<uint8_t>();
       ProfScope prof("agg_fixup");
       hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for(nnew, 256)), dim3(256), 0, st, f);
       CRGPU_HIP(hipGetLastError());
@@ -1739,7 +2091,8 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     }
     if (static_cast<int64_t>(ndef) + static_cast<int64_t>(nnew) < in.m) {  // rows besides claimants (fixup) and deferred ones
       const AccPlan plan = plan_accumulate(a, a->ngroups, in.m, false);
-      CRGPU_TRY(launch_accumulate(a, in, false, nullptr, plan));
+      if (plan.part) CRGPU_TRY(launch_partitioned(a, in, plan));
+      else CRGPU_TRY(launch_accumulate(a, in, false, nullptr, plan));
       if (a->need_any_fix) {
         const size_t nops = a->ops.size();
         AnyFixArgs fa;
