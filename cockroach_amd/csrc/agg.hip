@@ -1962,7 +1962,7 @@ static crgpu_status read_counters(crgpu_agg *a, unsigned int *out2) {
   return CRGPU_OK;
 }
 
-static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n) {
+static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, int64_t remaining) {
   hipStream_t st = stream();
   // BYTES key payload / BYTES ANY_NOT_NULL values: reserve room for every byte of the chunk
   for (size_t k = 0; k < a->ks.size(); k++) {
@@ -2020,6 +2020,11 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     if (round == 0 && a->new_ratio < 1.0) {
       const uint64_t guess = static_cast<uint64_t>(static_cast<double>(in.m) * a->new_ratio * 1.5) + 4096;
       if (guess < est) est = guess;
+    }
+    if (round == 0 && a->seq > 0 && a->new_ratio >= 0.25 && remaining > in.m) {
+      // high-cardinality input: size the index once for the rest of this call instead of rebuilding it chunk by chunk
+      const uint64_t rest = static_cast<uint64_t>(static_cast<double>(remaining) * (a->new_ratio < 1.0 ? a->new_ratio : 1.0));
+      if (rest > est) est = rest;
     }
     const uint64_t want = next_pow2((static_cast<uint64_t>(a->ngroups) + est) * 2);
     if (want > kMaxCap) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^29 groups per GPU");
@@ -2168,7 +2173,7 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
       else d.data = static_cast<const uint8_t *>(d.data) + pos * type_width(d.type);
       if (d.valid != nullptr) d.valid += pos >> 3;
     }
-    CRGPU_TRY(consume_chunk(a, chunk, len));
+    CRGPU_TRY(consume_chunk(a, chunk, len, n - pos));
     pos += len;
   }
   return CRGPU_OK;
