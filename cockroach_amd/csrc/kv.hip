@@ -9,8 +9,13 @@
 // (encoding.go:374-403,569-591,788-824,2617-2673,3032-3060,3420-3486; float.go:61-98).
 //
 // Record boundaries form a dependent chain inside one batch response (each record's
-// length is in its own header), so one wavefront walks each batch through an LDS window;
-// batches (<= 10 MiB each in production, rowinfra/base.go:53) are walked concurrently.
+// length is in its own header; batches are <= 10 MiB in production, rowinfra/base.go:53).
+// One wavefront following one chain reads ~1 GB/s, so every batch is cut into 32 KiB
+// segments that are walked concurrently: a segment's first record is SPECULATED (the first
+// offset from which six consecutive headers are plausible: lengths in range, the batch's
+// table/index key prefix, an MVCC timestamp-length byte) and then VERIFIED -- the walk of
+// segment s must end exactly where segment s+1 started; any mismatch re-walks that segment
+// from the proven offset, so the result never depends on the guess.
 // Everything after that is row-parallel: one lane per KV, byte-serial parsing of ~170 B
 // that neighbouring lanes share cache lines of.  BYTES outputs take two passes
 // (lengths -> scan -> copy).  Bound: HBM stream of the input bytes (read three times:
@@ -204,71 +209,157 @@ __device__ __forceinline__ int64_t peek_value_len(const uint8_t *b, int64_t len,
 }
 
 // ------------------------------------------------------------------ record boundaries
-// One wavefront per batch response.  The batch is pulled through an 8 KiB LDS window with
-// coalesced 16-byte loads; lane 0 follows the chain of {valLen u32, keyLen u32} headers inside it.
-template <bool WRITE>
-__global__ __launch_bounds__(64) void kv_walk_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ batch_offs,
-                                                     const int64_t *__restrict__ row_base, int64_t *__restrict__ counts,
-                                                     int64_t *__restrict__ rec_off, KvError *__restrict__ err) {
+static constexpr int64_t kSegBytes = 32 * 1024;
+static constexpr int kSpecDepth = 6;
+struct KvSeg {
+  int64_t lo, hi;      // the batch response this segment belongs to
+  int64_t begin, end;  // records that START in [begin, end) belong to the segment
+  int32_t batch;
+  int32_t first;       // 1: begin == lo, the first record is known
+};
+
+__device__ __forceinline__ uint32_t ld_u32_bytes(const uint8_t *p) {
+  return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
+}
+// Could a record start at c?  kSpecDepth consecutive headers must stay inside the batch, carry the
+// batch's key prefix and end their MVCC key with a timestamp-length byte (decode.go:26-49: 0, 9, 13 or 14).
+__device__ inline bool kv_plausible(const uint8_t *__restrict__ repr, int64_t c, int64_t hi, unsigned long long prefix,
+                                    int plen) {
+  int64_t pos = c;
+  for (int d = 0; d < kSpecDepth; d++) {
+    if (pos == hi) return true;
+    if (pos + 8 > hi) return false;
+    const uint32_t vl = ld_u32_bytes(repr + pos), kl = ld_u32_bytes(repr + pos + 4);
+    if (kl < static_cast<uint32_t>(plen) + 1u || kl > (1u << 20)) return false;
+    const int64_t next = pos + 8 + static_cast<int64_t>(kl) + vl;
+    if (next > hi) return false;
+    for (int i = 0; i < plen; i++)
+      if (repr[pos + 8 + i] != static_cast<uint8_t>(prefix >> (8 * i))) return false;
+    const uint8_t last = repr[pos + 8 + kl - 1];
+    if (!(last == 0 || last == 9 || last == 13 || last == 14)) return false;
+    pos = next;
+  }
+  return true;
+}
+
+// One wavefront per segment.  MODE 0: speculate the first record (unless the segment opens its batch) and
+// count; MODE 1: count again from start[] (segments flagged by the verification only); MODE 2: write the
+// record offsets.  The segment is pulled through an 8 KiB LDS window with coalesced 16-byte loads; lane 0
+// follows the chain of {valLen u32, keyLen u32} headers inside it.
+template <int MODE>
+__global__ __launch_bounds__(64) void kv_seg_walk_kernel(const uint8_t *__restrict__ repr, const KvSeg *__restrict__ segs,
+                                                         int64_t nseg, int plen, int64_t *__restrict__ start,
+                                                         int64_t *__restrict__ stop, uint32_t *__restrict__ count,
+                                                         int32_t *__restrict__ errc, const uint8_t *__restrict__ flag,
+                                                         const uint64_t *__restrict__ row_base, int64_t *__restrict__ rec_off) {
   __shared__ __align__(16) uint8_t win[kWalkWindow + 16];
   __shared__ int64_t s_pos;
   __shared__ int s_stop;
-  const int b = blockIdx.x;
-  const int64_t lo = batch_offs[b], hi = batch_offs[b + 1];
-  int64_t pos = lo, nrec = 0;
-  const int64_t out_base = WRITE ? row_base[b] : 0;
-  while (pos < hi) {
-    // window starts at the 16-byte aligned address at or below pos
-    const int64_t wbase = pos & ~int64_t(15);
-    for (int i = threadIdx.x * 16; i < kWalkWindow; i += 64 * 16) {
-      const int64_t g = wbase + i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (g + 16 <= hi) {
-        v = *reinterpret_cast<const uint4 *>(repr + g);
-      } else if (g < hi) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 16; k++)
-          if (g + k < hi) w[k >> 2] |= static_cast<uint32_t>(repr[g + k]) << (8 * (k & 3));
-        v = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-      *reinterpret_cast<uint4 *>(win + i) = v;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int stop = 0;
-      const int64_t wend = wbase + kWalkWindow < hi ? wbase + kWalkWindow : hi;
-      while (pos < hi) {
-        if (pos + 8 > wend) {
-          if (pos + 8 > hi) stop = KV_TRUNCATED;  // "unexpected batch EOF" (decode.go:109-111)
-          break;                                   // otherwise: header not in this window, reload
+  for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    if (MODE == 1 && !flag[s]) continue;
+    const KvSeg sg = segs[s];
+    const int64_t hi = sg.hi;
+    int64_t pos;
+    if (MODE == 0) {
+      pos = sg.first ? sg.lo : -1;
+      if (!sg.first && sg.lo + 8 + plen <= hi) {
+        unsigned long long prefix = 0;
+        for (int i = 0; i < plen; i++) prefix |= static_cast<unsigned long long>(repr[sg.lo + 8 + i]) << (8 * i);
+        for (int64_t base = sg.begin; base < sg.end; base += 64) {
+          const int64_t c = base + threadIdx.x;
+          const bool ok = c < sg.end && c < hi && kv_plausible(repr, c, hi, prefix, plen);
+          const uint64_t m = __ballot(ok);
+          if (m) {
+            pos = base + (__ffsll(static_cast<long long>(m)) - 1);
+            break;
+          }
         }
-        const uint8_t *h = win + (pos - wbase);
-        const uint32_t vl = h[0] | (h[1] << 8) | (h[2] << 16) | (static_cast<uint32_t>(h[3]) << 24);
-        const uint32_t kl = h[4] | (h[5] << 8) | (h[6] << 16) | (static_cast<uint32_t>(h[7]) << 24);
-        const int64_t next = pos + 8 + static_cast<int64_t>(kl) + vl;
-        if (next > hi) {
-          stop = KV_TRUNCATED;
-          break;
-        }
-        if (WRITE) rec_off[out_base + nrec] = pos;
-        nrec++;
-        pos = next;
       }
-      s_pos = pos;
-      s_stop = stop;
+      if (threadIdx.x == 0) start[s] = pos;
+    } else {
+      pos = start[s];
     }
-    __syncthreads();
-    pos = s_pos;
-    if (s_stop) {
+    int64_t nrec = 0;
+    int stopc = 0;
+    const int64_t out_base = MODE == 2 ? static_cast<int64_t>(row_base[s]) : 0;
+    while (pos >= 0 && pos < sg.end && pos < hi) {
+      // window starts at the 16-byte aligned address at or below pos
+      const int64_t wbase = pos & ~int64_t(15);
+      for (int i = threadIdx.x * 16; i < kWalkWindow; i += 64 * 16) {
+        const int64_t g = wbase + i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g + 16 <= hi) {
+          v = *reinterpret_cast<const uint4 *>(repr + g);
+        } else if (g < hi) {
+          uint32_t w[4] = {0, 0, 0, 0};
+          for (int k = 0; k < 16; k++)
+            if (g + k < hi) w[k >> 2] |= static_cast<uint32_t>(repr[g + k]) << (8 * (k & 3));
+          v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4 *>(win + i) = v;
+      }
+      __syncthreads();
       if (threadIdx.x == 0) {
-        atomicMin(&err->first_row, static_cast<unsigned long long>(b));
-        err->code = s_stop;
+        int stop_code = 0;
+        const int64_t wend = wbase + kWalkWindow < hi ? wbase + kWalkWindow : hi;
+        while (pos < sg.end && pos < hi) {
+          if (pos + 8 > wend) {
+            if (pos + 8 > hi) stop_code = KV_TRUNCATED;  // "unexpected batch EOF" (decode.go:109-111)
+            break;                                        // otherwise: header not in this window, reload
+          }
+          const uint8_t *h = win + (pos - wbase);
+          const uint32_t vl = ld_u32_bytes(h), kl = ld_u32_bytes(h + 4);
+          const int64_t next = pos + 8 + static_cast<int64_t>(kl) + vl;
+          if (next > hi) {
+            stop_code = KV_TRUNCATED;
+            break;
+          }
+          if (MODE == 2) rec_off[out_base + nrec] = pos;
+          nrec++;
+          pos = next;
+        }
+        s_pos = pos;
+        s_stop = stop_code;
       }
-      break;
+      __syncthreads();
+      pos = s_pos;
+      stopc = s_stop;
+      __syncthreads();
+      if (stopc) break;
     }
-    __syncthreads();
+    if (MODE != 2 && threadIdx.x == 0) {
+      count[s] = static_cast<uint32_t>(nrec);
+      stop[s] = pos;
+      errc[s] = stopc;
+    }
   }
-  if (!WRITE && threadIdx.x == 0) counts[b] = nrec;
+}
+
+// the walk of segment s-1 proves where segment s starts; a speculated start that differs is replaced and flagged
+__global__ __launch_bounds__(256) void kv_seg_verify_kernel(const KvSeg *__restrict__ segs, int64_t nseg,
+                                                            int64_t *__restrict__ start, const int64_t *__restrict__ stop,
+                                                            const int32_t *__restrict__ errc, uint8_t *__restrict__ flag,
+                                                            unsigned int *__restrict__ nbad) {
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  uint8_t f = 0;
+  if (!segs[s].first) {
+    // a truncated predecessor ends the batch: nothing after it is decoded (the error is reported)
+    const int64_t expected = errc[s - 1] ? segs[s].hi : stop[s - 1];
+    if (expected >= 0 && start[s] != expected) {
+      start[s] = expected;
+      f = 1;
+    }
+  }
+  flag[s] = f;
+  if (f) atomicAdd(nbad, 1u);
+}
+__global__ __launch_bounds__(256) void kv_seg_errors_kernel(const KvSeg *__restrict__ segs, int64_t nseg,
+                                                            const int32_t *__restrict__ errc, KvError *__restrict__ err) {
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= nseg || errc[s] == 0) return;
+  atomicMin(&err->first_row, static_cast<unsigned long long>(segs[s].batch));
+  err->code = errc[s];
 }
 
 // ------------------------------------------------------------------ row decode
@@ -509,7 +600,7 @@ using namespace crgpu;
 
 struct crgpu_decoder {
   FetchSpec spec;
-  DevBuf batch_offs, row_base, counts, rec_off, err, scratch, offs64;
+  DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
   std::vector<OutCol> out;
   std::vector<DevBuf> valid_bytes, lens;
   std::vector<crgpu_dcol> views;
@@ -600,34 +691,79 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
   CRGPU_HIP(hipMemsetAsync(d->err.p, 0xFF, 8, st));
   CRGPU_HIP(hipMemsetAsync(d->err.as<uint8_t>() + 8, 0, 8, st));
   if (n_batches > 0) {
-    CRGPU_TRY(d->batch_offs.ensure(static_cast<size_t>(n_batches + 1) * 8));
-    CRGPU_TRY(d->row_base.ensure(static_cast<size_t>(n_batches + 1) * 8));
-    CRGPU_TRY(d->counts.ensure(static_cast<size_t>(n_batches) * 8));
-    CRGPU_HIP(hipMemcpyAsync(d->batch_offs.p, batch_offsets_host, static_cast<size_t>(n_batches + 1) * 8, hipMemcpyHostToDevice, st));
+    // cut the batches into segments
+    std::vector<KvSeg> segs;
+    for (int64_t b = 0; b < n_batches; b++) {
+      const int64_t lo = batch_offsets_host[b], hi = batch_offsets_host[b + 1];
+      for (int64_t p = lo; p < hi || p == lo; p += kSegBytes) {
+        KvSeg sg;
+        sg.lo = lo;
+        sg.hi = hi;
+        sg.begin = p;
+        sg.end = p + kSegBytes < hi ? p + kSegBytes : hi;
+        sg.batch = static_cast<int32_t>(b);
+        sg.first = p == lo;
+        segs.push_back(sg);
+        if (hi == lo) break;
+      }
+    }
+    const int64_t nseg = static_cast<int64_t>(segs.size());
+    const size_t ns = static_cast<size_t>(nseg);
+    CRGPU_TRY(d->segs.ensure(ns * sizeof(KvSeg)));
+    CRGPU_TRY(d->seg_start.ensure(ns * 8));
+    CRGPU_TRY(d->seg_stop.ensure(ns * 8));
+    CRGPU_TRY(d->seg_count.ensure(ns * 4));
+    CRGPU_TRY(d->seg_err.ensure(ns * 4));
+    CRGPU_TRY(d->seg_flag.ensure(ns));
+    CRGPU_TRY(d->seg_base.ensure((ns + 1) * 8));
+    CRGPU_TRY(d->nbad.ensure(4));
+    CRGPU_HIP(hipMemcpyAsync(d->segs.p, segs.data(), ns * sizeof(KvSeg), hipMemcpyHostToDevice, st));
+    const int plen = f.key_prefix_len < 8 ? f.key_prefix_len : 8;
+    const unsigned wgrid = static_cast<unsigned>(nseg < static_cast<int64_t>(num_cus()) * 32 ? nseg : num_cus() * 32);
+    const unsigned vgrid = static_cast<unsigned>((nseg + 255) / 256);
     {
       ProfScope prof("kv_walk");
-      hipLaunchKernelGGL(kv_walk_kernel<false>, dim3(static_cast<unsigned>(n_batches)), dim3(64), 0, st, repr_dev,
-                         d->batch_offs.as<int64_t>(), static_cast<const int64_t *>(nullptr), d->counts.as<int64_t>(),
-                         static_cast<int64_t *>(nullptr), d->err.as<KvError>());
+      hipLaunchKernelGGL(kv_seg_walk_kernel<0>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
+                         d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
+                         d->seg_err.as<int32_t>(), static_cast<const uint8_t *>(nullptr), static_cast<const uint64_t *>(nullptr),
+                         static_cast<int64_t *>(nullptr));
       CRGPU_HIP(hipGetLastError());
     }
-    std::vector<int64_t> counts(static_cast<size_t>(n_batches)), base(static_cast<size_t>(n_batches) + 1);
-    CRGPU_HIP(hipMemcpyAsync(counts.data(), d->counts.p, static_cast<size_t>(n_batches) * 8, hipMemcpyDeviceToHost, st));
+    for (int64_t iter = 0;; iter++) {
+      if (iter > nseg) return fail(CRGPU_ERR_HIP, "crgpu_dev_decode_kv: record boundaries did not converge (internal error)");
+      CRGPU_HIP(hipMemsetAsync(d->nbad.p, 0, 4, st));
+      hipLaunchKernelGGL(kv_seg_verify_kernel, dim3(vgrid), dim3(256), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_start.as<int64_t>(),
+                         d->seg_stop.as<int64_t>(), d->seg_err.as<int32_t>(), d->seg_flag.as<uint8_t>(), d->nbad.as<unsigned int>());
+      CRGPU_HIP(hipGetLastError());
+      unsigned int nbad = 0;
+      CRGPU_HIP(hipMemcpyAsync(&nbad, d->nbad.p, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipStreamSynchronize(st));
+      if (nbad == 0) break;
+      ProfScope prof("kv_walk");
+      hipLaunchKernelGGL(kv_seg_walk_kernel<1>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
+                         d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
+                         d->seg_err.as<int32_t>(), d->seg_flag.as<uint8_t>(), static_cast<const uint64_t *>(nullptr),
+                         static_cast<int64_t *>(nullptr));
+      CRGPU_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(kv_seg_errors_kernel, dim3(vgrid), dim3(256), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_err.as<int32_t>(),
+                       d->err.as<KvError>());
+    CRGPU_HIP(hipGetLastError());
     CRGPU_TRY(kv_check_error(d, "batch"));
-    base[0] = 0;
-    for (int64_t b = 0; b < n_batches; b++) base[b + 1] = base[b] + counts[b];
-    n = base[n_batches];
+    uint64_t total = 0;
+    CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, &total));
+    n = static_cast<int64_t>(total);
     if (n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: more than 2^31 rows in one call");
     if (n > 0) {
       CRGPU_TRY(d->rec_off.ensure(static_cast<size_t>(n) * 8));
-      CRGPU_HIP(hipMemcpyAsync(d->row_base.p, base.data(), static_cast<size_t>(n_batches + 1) * 8, hipMemcpyHostToDevice, st));
       ProfScope prof("kv_walk");
-      hipLaunchKernelGGL(kv_walk_kernel<true>, dim3(static_cast<unsigned>(n_batches)), dim3(64), 0, st, repr_dev,
-                         d->batch_offs.as<int64_t>(), d->row_base.as<int64_t>(), static_cast<int64_t *>(nullptr),
-                         d->rec_off.as<int64_t>(), d->err.as<KvError>());
+      hipLaunchKernelGGL(kv_seg_walk_kernel<2>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
+                         d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
+                         d->seg_err.as<int32_t>(), static_cast<const uint8_t *>(nullptr), d->seg_base.as<uint64_t>(),
+                         d->rec_off.as<int64_t>());
       CRGPU_HIP(hipGetLastError());
-      CRGPU_HIP(hipStreamSynchronize(st));  // `base` is read by the copy above
     }
+    CRGPU_HIP(hipStreamSynchronize(st));  // `segs` is a host temporary
   }
   const int64_t cap = n > 0 ? n : 1;
   FetchOut o;

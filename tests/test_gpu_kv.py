@@ -110,3 +110,59 @@ def test_decode_errors_and_empty(oracle):
     assert "TUPLE" in str(e.value) and "row 0" in str(e.value)
     with pytest.raises(_lib.CrgpuError):  # value column ids must increase
         dev.Decoder(2, [cd.INT64], [0], [0], [5, 3], [cd.INT64, cd.INT64], [1, 2], [cd.INT64] * 3)
+
+
+def test_decode_segmented_walk_misleading_values(oracle):
+    """Batches are walked in 32 KiB segments whose first record is speculated and then verified.  Here many
+    values are byte-for-byte copies of encoded records of the SAME table (same key prefix, plausible lengths
+    and timestamps): a segment that begins inside such a value finds a convincing but wrong first record, and
+    only the verification against the previous segment's walk puts it right."""
+    rng = np.random.default_rng(11)
+    kt, kd, vt, ids = [cd.INT64], [0], [cd.INT64, cd.BYTES], [2, 3]
+    t = oracle.KvTable(77, 1, kt, kd, ids, vt)
+    n0 = 600
+    k0 = cd.Vec.from_numpy(cd.INT64, np.arange(n0, dtype=np.int64))
+    inner, _ = oracle.kv_encode(t, [k0], [k0, cd.Vec.from_values(cd.BYTES, [b"x" * int(rng.integers(0, 40)) for _ in range(n0)])])
+    blob = bytes(inner)
+    assert len(blob) > 20_000
+    n = 300
+    payload = []
+    for i in range(n):
+        r = rng.random()
+        if r < 0.4:
+            a = int(rng.integers(0, len(blob) // 2))
+            payload.append(blob[a:a + int(rng.integers(9_000, 70_000))])  # tens of fake records, often across a segment boundary
+        elif r < 0.5:
+            payload.append(None)
+        else:
+            payload.append(bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8)))
+    keys = [cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64) * 3 - 100)]
+    vals = [cd.Vec.from_numpy(cd.INT64, rng.integers(-5, 5, size=n, dtype=np.int64)), cd.Vec.from_values(cd.BYTES, payload)]
+    for batch_bytes in (1 << 20, 64 << 20):
+        data, offs = oracle.kv_encode(t, keys, vals, max_batch_bytes=batch_bytes)
+        assert len(data) > 40 * 32 * 1024 // 10
+        spec = (t.prefix_len(), kt, kd, [0], ids, vt, [1, 2], kt + vt)
+        dev.prof_enable(True)
+        dev.prof_reset()
+        got = gpu_decode(*spec, data, offs)
+        walks = dev.prof_get("kv_walk")[1]
+        dev.prof_enable(False)
+        assert walks > 2, "expected at least one segment to be re-walked after a wrong speculation"
+        H.assert_vecs_equal(got, oracle.kv_decode(*spec, data, offs), "misleading values")
+        H.assert_vecs_equal(got, [keys[0], vals[0], vals[1]], "misleading values vs source rows")
+    # truncation inside a later segment of a large batch is still reported
+    with pytest.raises(_lib.CrgpuError) as e:
+        gpu_decode(*spec, data[:-5], [0, len(data) - 5])
+    assert "truncated" in str(e.value)
+
+
+def test_decode_one_large_batch_many_segments(oracle):
+    rng = np.random.default_rng(12)
+    n = 150_000
+    kt, kd, vt, ids = [cd.INT64, cd.BYTES], [0, 1], [cd.FLOAT64, cd.BYTES, cd.INT32], [4, 8, 9]
+    keys, vals = H.kv_random_rows(rng, n, kt, vt)
+    t = oracle.KvTable(300, 2, kt, kd, ids, vt)
+    data, offs = oracle.kv_encode(t, keys, vals, max_batch_bytes=1 << 30)
+    assert len(offs) == 2 and len(data) > 100 * 32 * 1024
+    spec = (t.prefix_len(), kt, kd, [0, 1], ids, vt, [2, 3, 4], kt + vt)
+    H.assert_vecs_equal(gpu_decode(*spec, data, offs), oracle.kv_decode(*spec, data, offs), "one batch, many segments")
