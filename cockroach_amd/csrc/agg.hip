@@ -54,7 +54,14 @@ static constexpr size_t kLdsReplicated = 20 * 1024;    // replicate small partia
 static constexpr size_t kLdsLarge = 152 * 1024;        // largest partial table: one 1024-thread workgroup per CU
 static constexpr size_t kLdsMax = 160 * 1024;
 static constexpr int kMaxReplicas = 32;
-static constexpr int kAccRows = 8;                     // rows per thread and iteration in the accumulate kernels
+#ifndef CRGPU_OP_GROUP
+#define CRGPU_OP_GROUP 2
+#endif
+#ifndef CRGPU_ACC_ROWS
+#define CRGPU_ACC_ROWS 4
+#endif
+static constexpr int kOpGroup = CRGPU_OP_GROUP;                     // aggregations whose input loads are in flight together
+static constexpr int kAccRows = CRGPU_ACC_ROWS;                     // rows per thread and iteration in the accumulate kernels
 
 enum AccKind : int32_t {
   ACC_COUNT_ROWS = 0, ACC_COUNT, ACC_SUM_F64, ACC_AVG_F64, ACC_SUM_I128, ACC_MIN_I64, ACC_MAX_I64, ACC_MIN_F64,
@@ -278,23 +285,42 @@ __device__ __forceinline__ void pack_rows(const KeyCols &keys, const PackSpec &p
     }
     unsigned long long v[K];
     if (x.type == CRGPU_BYTES) {
-      uint32_t a0[K], a1[K];
+      uint32_t a0[K], len[K];
 #pragma unroll
       for (int k = 0; k < K; k++) {
         a0[k] = x.offsets[row[k]];
-        a1[k] = x.offsets[row[k] + 1];
+        len[k] = x.offsets[row[k] + 1];
       }
+      uint32_t mx = 0;
 #pragma unroll
       for (int k = 0; k < K; k++) {
-        const uint32_t len = a1[k] - a0[k];
-        v[k] = len;
-        if (isnull[k] || !ok[k]) continue;
-        if (len > static_cast<uint32_t>(pc.bbytes)) {
-          ok[k] = false;
-          continue;
+        len[k] -= a0[k];
+        if (len[k] > static_cast<uint32_t>(pc.bbytes)) {
+          if (!isnull[k]) ok[k] = false;
+          len[k] = 0;
         }
-        const uint8_t *p = reinterpret_cast<const uint8_t *>(x.data) + a0[k];
-        for (uint32_t j = 0; j < len; j++) v[k] |= static_cast<unsigned long long>(p[j]) << (4 + 8 * j);
+        if (isnull[k] || !ok[k]) len[k] = 0;
+        v[k] = len[k];
+        mx = len[k] > mx ? len[k] : mx;
+      }
+      // longest packable value in the wave (wave-uniform loop bound); byte j of every row is one unconditional
+      // load: rows shorter than j + 1 read a byte that is certainly mapped (their own last byte, or the offsets array)
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(mx, d, 64);
+        mx = o > mx ? o : mx;
+      }
+      for (uint32_t j = 0; j < mx; j++) {
+        uint8_t b[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          const uint8_t *src = len[k] ? reinterpret_cast<const uint8_t *>(x.data) + a0[k] + (j < len[k] ? j : len[k] - 1)
+                                      : reinterpret_cast<const uint8_t *>(x.offsets);
+          b[k] = *src;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++)
+          if (j < len[k]) v[k] |= static_cast<unsigned long long>(b[k]) << (4 + 8 * j);
       }
     } else {
       switch (x.type) {
@@ -341,7 +367,18 @@ __device__ __forceinline__ void pack_rows(const KeyCols &keys, const PackSpec &p
   }
 }
 __device__ __forceinline__ uint32_t pk_hash(unsigned long long k0, unsigned long long k1) {
+#ifdef CRGPU_PK_HASH_FMIX
   return static_cast<uint32_t>(fmix64(k0 ^ (k1 * 0x9FB21C651E98DF25ull)) >> 20);
+#endif
+  // 32-bit mixing with two multiplies ("lowbias32"): the table is at most half full and only has to spread the keys
+  uint32_t h = static_cast<uint32_t>(k0) ^ (static_cast<uint32_t>(k0 >> 32) * 0x9E3779B1u) ^
+               (static_cast<uint32_t>(k1) * 0x85EBCA77u) ^ (static_cast<uint32_t>(k1 >> 32) * 0xC2B2AE3Du);
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return h;
 }
 
 // read-only index lookup: gid of the row's group or kGidDefer when it does not exist (yet)
@@ -399,6 +436,89 @@ __device__ __forceinline__ void apply_input(const OpK &op, unsigned long long v,
     case ACC_BOOL_AND: if (!v) atomicAnd(w0, 0ull); *seen = 1; break;
     case ACC_BOOL_OR: if (v) atomicOr(w0, 1ull); *seen = 1; break;
     case ACC_ANY_ROW: atomicMin(w0, seq); break;  // first non-NULL in arrival order
+    default: break;
+  }
+}
+
+// LDS form of apply_input for the kAccRows rows of a thread: the switch on the aggregation runs once, and
+// rows that do not contribute are not branched around -- they update a trash group (index G of every plane)
+// instead, so the whole update is straight-line code (a divergent branch per (aggregation, row) cost more
+// scalar instructions than the atomics themselves: 313 SALU instructions per row in the first profile).
+template <int K>
+__device__ __forceinline__ void apply_rows_lds(const OpK &op, const unsigned long long (&v)[K], uint32_t takem,
+                                               const uint32_t (&gr)[K], uint32_t trash, uint32_t plane,
+                                               unsigned long long *lds_words, uint8_t *lds_seen, const int64_t (&row)[K],
+                                               unsigned long long seq_base) {
+  uint32_t idx[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) idx[k] = ((takem >> k) & 1u) ? gr[k] : trash;
+  unsigned long long *p0 = lds_words + static_cast<size_t>(op.lw0) * plane;
+  unsigned long long *p1 = lds_words + static_cast<size_t>(op.lw1) * plane;
+  uint8_t *ps = lds_seen + static_cast<size_t>(op.lseen) * plane;
+  switch (op.kind) {
+    case ACC_COUNT_ROWS:
+    case ACC_COUNT:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicAdd(p0 + idx[k], 1ull);
+      break;
+    case ACC_SUM_F64:
+#pragma unroll
+      for (int k = 0; k < K; k++) unsafeAtomicAdd(reinterpret_cast<double *>(p0 + idx[k]), __longlong_as_double(static_cast<long long>(v[k])));
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_AVG_F64:
+#pragma unroll
+      for (int k = 0; k < K; k++) unsafeAtomicAdd(reinterpret_cast<double *>(p0 + idx[k]), __longlong_as_double(static_cast<long long>(v[k])));
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicAdd(p1 + idx[k], 1ull);
+      break;
+    case ACC_SUM_I128:
+#pragma unroll
+      for (int k = 0; k < K; k++) add_i128(p0 + idx[k], p1 + idx[k], v[k], (v[k] >> 63) ? ~0ull : 0ull);
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_MIN_I64:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicMin(reinterpret_cast<long long *>(p0 + idx[k]), static_cast<long long>(v[k]));
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_MAX_I64:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicMax(reinterpret_cast<long long *>(p0 + idx[k]), static_cast<long long>(v[k]));
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_MIN_F64:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicMin(p0 + idx[k], f64_to_ordered(__longlong_as_double(static_cast<long long>(v[k]))));
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_MAX_F64:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicMax(p0 + idx[k], f64_to_ordered(__longlong_as_double(static_cast<long long>(v[k]))));
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_BOOL_AND:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicAnd(p0 + idx[k], v[k] ? 1ull : 0ull);
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_BOOL_OR:
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicOr(p0 + idx[k], v[k] ? 1ull : 0ull);
+#pragma unroll
+      for (int k = 0; k < K; k++) ps[idx[k]] = 1;
+      break;
+    case ACC_ANY_ROW:  // first non-NULL in arrival order
+#pragma unroll
+      for (int k = 0; k < K; k++) atomicMin(p0 + idx[k], seq_base + static_cast<unsigned long long>(row[k]));
+      break;
     default: break;
   }
 }
@@ -590,12 +710,13 @@ struct AccArgs {
 // PK (with FUSED and LDS): the lookup runs against an LDS table of the groups' packed keys; the HBM index
 // only serves unpackable rows and rows whose group does not exist yet.
 template <bool FUSED, bool LDS, bool PK>
-__global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
+__global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
   extern __shared__ unsigned long long lds_words[];
-  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * a.G * a.R);
+  const uint32_t plane = (a.G + 1) * a.R;  // one plane per accumulator word: G groups + the trash group, R replicas each
+  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
   // key table: k0[C] | k1[C] (two-word keys) | gid[C]
   unsigned long long *t_k0 = reinterpret_cast<unsigned long long *>(
-      lds_seen + ((static_cast<size_t>(a.nseen) * a.G * a.R + 7) & ~size_t(7)));
+      lds_seen + ((static_cast<size_t>(a.nseen) * plane + 7) & ~size_t(7)));
   unsigned long long *t_k1 = t_k0 + a.C;
   uint32_t *t_gid = reinterpret_cast<uint32_t *>(a.pack.two_words ? t_k1 + a.C : t_k1);
   const KeyStore &store = a.store;
@@ -612,7 +733,7 @@ __global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
     }
   }
   if (LDS) {
-    const uint32_t per = a.G * a.R;
+    const uint32_t per = plane;
     for (int f = 0; f < a.naggs; f++) {
       const OpK &op = a.ops[f];
       if (op.lw0 >= 0) {
@@ -683,25 +804,38 @@ __global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
         if (gid[k] >= a.G) gid[k] = kGidDefer;  // another sweep's group (unsigned compare covers gid < gid_lo)
       }
     }
-    for (int f = 0; f < a.naggs; f++) {
-      const OpK &op = a.ops[f];
-      unsigned long long v[kAccRows];
-      bool take[kAccRows];
+    uint32_t gr[kAccRows];  // LDS: position of the row's group inside a plane
 #pragma unroll
-      for (int k = 0; k < kAccRows; k++) take[k] = gid[k] != kGidDefer;
-      load_inputs<kAccRows>(op, row, take, v);
+    for (int k = 0; k < kAccRows; k++) gr[k] = LDS && gid[k] != kGidDefer ? gid[k] * a.R + rep : 0;
+    // kOpGroup aggregations at a time: all their input loads are issued before the first atomic
+    for (int f0 = 0; f0 < a.naggs; f0 += kOpGroup) {
+      unsigned long long v[kOpGroup][kAccRows];
+      uint32_t takem[kOpGroup];
 #pragma unroll
-      for (int k = 0; k < kAccRows; k++) {
-        if (!take[k]) continue;
-        const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row[k]);
+      for (int u = 0; u < kOpGroup; u++) {
+        takem[u] = 0;
+        if (f0 + u < a.naggs) {
+          bool take[kAccRows];
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) take[k] = gid[k] != kGidDefer;
+          load_inputs<kAccRows>(a.ops[f0 + u], row, take, v[u]);
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) takem[u] |= (take[k] ? 1u : 0u) << k;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kOpGroup; u++) {
+        if (f0 + u >= a.naggs) break;
+        const OpK &op = a.ops[f0 + u];
         if (LDS) {
-          const uint32_t g = gid[k];
-          unsigned long long *w0 = lds_words + (static_cast<size_t>(op.lw0) * a.G + g) * a.R + rep;
-          unsigned long long *w1 = lds_words + (static_cast<size_t>(op.lw1) * a.G + g) * a.R + rep;
-          uint8_t *seen = lds_seen + (static_cast<size_t>(op.lseen) * a.G + g) * a.R + rep;
-          apply_input(op, v[k], seq, w0, w1, seen);
+          apply_rows_lds<kAccRows>(op, v[u], takem[u], gr, a.G * a.R + rep, plane, lds_words, lds_seen, row, a.seq_base);
         } else {
-          apply_input(op, v[k], seq, op.w0 + gid[k], op.w1 + gid[k], op.seen + gid[k]);
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) {
+            if (!((takem[u] >> k) & 1u)) continue;
+            const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row[k]);
+            apply_input(op, v[u][k], seq, op.w0 + gid[k], op.w1 + gid[k], op.seen + gid[k]);
+          }
         }
       }
     }
@@ -711,7 +845,7 @@ __global__ __launch_bounds__(512) void agg_accum_kernel(AccArgs a) {
     const uint32_t pairs = a.G * static_cast<uint32_t>(a.naggs);
     for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
       const uint32_t f = t / a.G, g = t - f * a.G;
-      lds_flush_op(a.ops[f], lds_words, lds_seen, a.G, a.R, g, a.gid_lo + g);
+      lds_flush_op(a.ops[f], lds_words, lds_seen, a.G + 1, a.R, g, a.gid_lo + g);
     }
   }
 }
@@ -1673,7 +1807,7 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, b
   AccPlan p;
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0 || ngroups <= 0) return p;
-  const size_t total = bpg * static_cast<size_t>(ngroups);
+  const size_t total = bpg * static_cast<size_t>(ngroups + 1);  // + the trash group rows that do not contribute update
   if (total <= kLdsLarge) {
     p.lds = true;
     p.G = static_cast<uint32_t>(ngroups);
@@ -1693,7 +1827,7 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, b
     p.lds_bytes = total * r + table;
     const size_t fit = (160 * 1024) / (p.lds_bytes ? p.lds_bytes : 1);
     p.wgs_per_cu = fit >= 8 ? 8 : fit >= 4 ? 4 : fit >= 2 ? 2 : 1;
-    p.block = p.wgs_per_cu == 8 ? 256 : 512;
+    p.block = p.wgs_per_cu == 8 ? 256 : p.wgs_per_cu == 1 ? 1024 : 512;  // 16 waves per CU whenever LDS allows
     return p;
   }
   // gid-partitioned: ranges of 2^shift groups, each with a partial table of at most kLdsLarge bytes
