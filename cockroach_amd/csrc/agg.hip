@@ -1027,25 +1027,26 @@ __global__ __launch_bounds__(512) void agg_part_accum_kernel(PartAccArgs a) {
   const uint32_t gid_lo = d.part << a.shift;
   const int64_t left = a.ngroups - static_cast<int64_t>(gid_lo);
   const uint32_t G = static_cast<uint32_t>(left < (int64_t(1) << a.shift) ? left : (int64_t(1) << a.shift));
-  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * G);
+  const uint32_t plane = G + 1;  // + the trash group (see apply_rows_lds)
+  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
   for (int f = 0; f < a.naggs; f++) {
     const OpK &op = a.ops[f];
     if (op.lw0 >= 0) {
       const unsigned long long init = acc_init_w0(op.kind);
-      for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * G + i] = init;
+      for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * plane + i] = init;
     }
     if (op.lw1 >= 0)
-      for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * G + i] = 0ull;
+      for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * plane + i] = 0ull;
   }
-  for (uint32_t i = threadIdx.x; i < a.nseen * G; i += blockDim.x) lds_seen[i] = 0;
+  for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
   __syncthreads();
   for (uint64_t j0 = d.begin + threadIdx.x; j0 < d.end; j0 += static_cast<uint64_t>(blockDim.x) * kAccRows) {
-    uint64_t j[kAccRows];
+    int64_t j[kAccRows];
     uint32_t g[kAccRows], fl[kAccRows];
 #pragma unroll
     for (int k = 0; k < kAccRows; k++) {
       const uint64_t jj = j0 + static_cast<uint64_t>(k) * blockDim.x;
-      j[k] = jj < d.end ? jj : d.end - 1;  // clamped: the loads below stay unconditional
+      j[k] = static_cast<int64_t>(jj < d.end ? jj : d.end - 1);  // clamped: the loads below stay unconditional
       g[k] = a.gid[j[k]] - gid_lo;
       fl[k] = jj < d.end ? a.flags[j[k]] : 0u;
     }
@@ -1059,21 +1060,17 @@ __global__ __launch_bounds__(512) void agg_part_accum_kernel(PartAccArgs a) {
 #pragma unroll
         for (int k = 0; k < kAccRows; k++) v[k] = 0;
       }
+      uint32_t takem = 0;
 #pragma unroll
-      for (int k = 0; k < kAccRows; k++) {
-        if (!((fl[k] >> f) & 1u)) continue;
-        unsigned long long *w0 = lds_words + static_cast<size_t>(op.lw0) * G + g[k];
-        unsigned long long *w1 = lds_words + static_cast<size_t>(op.lw1) * G + g[k];
-        uint8_t *seen = lds_seen + static_cast<size_t>(op.lseen) * G + g[k];
-        apply_input(op, v[k], 0ull, w0, w1, seen);
-      }
+      for (int k = 0; k < kAccRows; k++) takem |= ((fl[k] >> f) & 1u) << k;
+      apply_rows_lds<kAccRows>(op, v, takem, g, G, plane, lds_words, lds_seen, j, 0ull);
     }
   }
   __syncthreads();
   const uint32_t pairs = G * static_cast<uint32_t>(a.naggs);
   for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
     const uint32_t f = t / G, g = t - f * G;
-    lds_flush_op(a.ops[f], lds_words, lds_seen, G, 1, g, gid_lo + g);
+    lds_flush_op(a.ops[f], lds_words, lds_seen, plane, 1, g, gid_lo + g);
   }
 }
 
@@ -1852,7 +1849,7 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, b
       p.shift = shift;
       p.P = static_cast<uint32_t>(P);
       p.block = 512;
-      p.lds_bytes = bpg << shift;
+      p.lds_bytes = bpg * ((size_t(1) << shift) + 1);
     }
   }
   return p;
