@@ -15,6 +15,30 @@ sys.path.insert(0, ROOT)
 from cockroach_amd import _lib, coldata as cd, device as dev  # noqa: E402
 
 
+CPU_SAMPLE = 1 << 22  # rows the single-threaded oracle port aggregates for the cpu_baseline figure
+
+
+def to_host_vec(c, n):
+    """First n rows of a device column built by dev.from_torch, as a host Vec (CPU baseline input)."""
+    data, valid, offsets = c.keep
+    if c.type == cd.BYTES:
+        offs = offsets[:n + 1].cpu().numpy().astype(np.uint32)
+        return cd.Vec(cd.BYTES, data[:int(offs[-1])].cpu().numpy(), None, offs)
+    return cd.Vec.from_numpy(c.type, data[:n].cpu().numpy())
+
+
+def cpu_baseline(cols, group_cols, aggs, n):
+    from oracle import oracle as O  # test infrastructure: only the reported CPU baseline uses it
+    m = min(n, CPU_SAMPLE)
+    host = [to_host_vec(c, m) for c in cols]
+    t0 = time.perf_counter()
+    out = O.hash_agg(host, group_cols, aggs)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} rows of the same input (oracle/crdb_oracle.c hashAggregator restatement, 1 thread)",
+            "groups_in_sample": len(out[0])}
+
+
 def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
     torch.cuda.synchronize()  # inputs are produced on torch's stream, the library runs on its own
     a = dev.Agg(types, group_cols, aggs)
@@ -37,7 +61,8 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
         if cnt:
             kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
     print(json.dumps({"case": name, "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt,
-                      "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12, "kernels": kern}), flush=True)
+                      "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12, "kernels": kern,
+                      "cpu_baseline": cpu_baseline(cols, group_cols, aggs, n) if CPU_SAMPLE else None}), flush=True)
     a.close()
 
 
@@ -45,6 +70,9 @@ def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # e.g. "q1,1024,65536"
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    global CPU_SAMPLE
+    if len(sys.argv) > 4:
+        CPU_SAMPLE = int(sys.argv[4])  # 0: skip the CPU baseline (profiling runs)
     n = 1 << lg
     _lib.check(_lib.load().crgpu_init(0))
     dv = torch.device("cuda", 0)

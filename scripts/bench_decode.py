@@ -76,12 +76,21 @@ def main():
     walk_ms, _ = dev.prof_get("kv_walk")
     dec_ms, _ = dev.prof_get("kv_decode")
     in_bytes = one * reps
+    # CPU baseline: the oracle's cFetcher restatement (single thread) on one replica of the same batches
+    spec = (t.prefix_len(), kt, kd, [-1, -1], [ids[i] for i in sel], [vt[i] for i in sel], list(range(7)), [vt[i] for i in sel])
+    one_data = data[:one]
+    c0 = time.perf_counter()
+    cpu_out = O.kv_decode(*spec, one_data, offs)
+    cdt = time.perf_counter() - c0
+    cpu = {"value": len(cpu_out[0]) / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"one replica ({one} bytes, {len(cpu_out[0])} rows) of the same batches (oracle/crdb_kv.c, 1 thread)"}
     out_bytes = rows * (4 * 8 + 2 * (1 + 4) + 8)
     print(json.dumps({"rows": rows, "input_bytes": in_bytes, "bytes_per_row": in_bytes / rows, "batches_per_call": len(offs) - 1,
                       "wall_ms": dt * 1e3, "kv_walk_ms": walk_ms, "kv_decode_ms": dec_ms,
                       "rows_per_s": rows / dt, "input_GBps_wall": in_bytes / dt / 1e9,
                       "decode_kernel_GBps": (in_bytes + out_bytes) / (dec_ms / 1e3) / 1e9 if dec_ms else None,
-                      "walk_kernel_GBps": 2 * in_bytes / (walk_ms / 1e3) / 1e9 if walk_ms else None}))
+                      "walk_kernel_GBps": 2 * in_bytes / (walk_ms / 1e3) / 1e9 if walk_ms else None,
+                      "cpu_baseline": cpu}))
 
 
 if __name__ == "__main__":
