@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2-build", type=int, default=25)
     ap.add_argument("--cpu-log2-probe", type=int, default=27)
+    ap.add_argument("--no-other-paths", action="store_true", help="skip the aggregation / decode side measurements")
     return ap.parse_args()
 
 
@@ -241,13 +242,43 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2_build, args.cpu_log2_probe)
-        print(json.dumps(line), flush=True)
     join.close()
+    if rank == 0:
+        if world == 1 and not args.no_other_paths:
+            # the other rows of the hot path, measured in the same run (not part of `value`): DESIGN.md 4.3 / 4.4
+            line["other_paths"] = other_paths(local_rank)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         sys.exit(3)
+
+
+def other_paths(device_index):
+    """Hash aggregation (Q1 shape, 1024 groups, all-distinct = config G shape; 2^27 rows) and KV fetch decode
+    (lineitem-shaped rows, 10 MiB batch responses), inputs resident in HBM, each with the single-threaded CPU port
+    timed on a bounded sample.  scripts/bench_agg.py and scripts/bench_decode.py are the standalone forms."""
+    import importlib.util
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "scripts", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    out = {}
+    try:
+        agg = load("bench_agg")
+        out["hash_aggregation"] = [
+            {k: r[k] for k in ("case", "rows", "groups", "ms", "rows_per_s", "frac_of_8TBps", "cpu_baseline")}
+            for r in agg.measure(27, ["q1", "1024", str(1 << 27)], reps=3, cpu_sample=1 << 21, device_index=device_index)]
+        dec = load("bench_decode").measure(1 << 21, 4, 10 << 20, device_index)
+        out["kv_fetch_decode"] = {k: dec[k] for k in ("rows", "input_bytes", "wall_ms", "kv_walk_ms", "kv_decode_ms", "rows_per_s",
+                                                      "input_GBps_wall", "cpu_baseline")}
+    except Exception as e:  # the join line must not be lost to a failure in the side measurements
+        out["error"] = repr(e)
+    return out
 
 
 def _wrap(torch, ptr, n, device):

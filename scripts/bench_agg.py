@@ -60,22 +60,20 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
         ms, cnt = dev.prof_get(k)
         if cnt:
             kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
-    print(json.dumps({"case": name, "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt,
-                      "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12, "kernels": kern,
-                      "cpu_baseline": cpu_baseline(cols, group_cols, aggs, n) if CPU_SAMPLE else None}), flush=True)
     a.close()
+    return {"case": name, "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt,
+            "alg_GBps": alg_bytes / dt / 1e9, "frac_of_8TBps": alg_bytes / dt / 8e12, "kernels": kern,
+            "cpu_baseline": cpu_baseline(cols, group_cols, aggs, n) if CPU_SAMPLE else None}
 
 
-def main():
-    lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
-    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # e.g. "q1,1024,65536"
-    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
+    """Yields one result dict per case (bench.py reports a few of them beside the join line)."""
     global CPU_SAMPLE
-    if len(sys.argv) > 4:
-        CPU_SAMPLE = int(sys.argv[4])  # 0: skip the CPU baseline (profiling runs)
+    if cpu_sample is not None:
+        CPU_SAMPLE = cpu_sample
     n = 1 << lg
-    _lib.check(_lib.load().crgpu_init(0))
-    dv = torch.device("cuda", 0)
+    _lib.check(_lib.load().crgpu_init(device_index))
+    dv = torch.device("cuda", device_index)
     g = torch.Generator(device=dv); g.manual_seed(1)
     # Q1 shape
     rf = torch.randint(0, 3, (n,), generator=g, device=dv, dtype=torch.uint8) + 65
@@ -87,7 +85,7 @@ def main():
     types = [cd.BYTES, cd.BYTES] + [cd.FLOAT64] * 4
     aggs = [(0, 0, -1), (0, 1, -1), (10, 2, -1), (10, 3, -1), (10, 4, -1), (10, 5, -1), (1, 2, -1), (1, 3, -1), (1, 4, -1), (14, -1, -1)]
     if only is None or "q1" in only:
-        run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0, reps=reps)
+        yield run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0, reps=reps)
     del cols, f, rf, ls
     for groups in (1 << 10, 1 << 16, 1 << 20, 1 << 24, n):
         if groups > n or (only is not None and str(groups) not in only):
@@ -97,9 +95,18 @@ def main():
         x = torch.randint(-1000, 1000, (n,), generator=g, device=dv, dtype=torch.int64)
         cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)]
         aggs = [(0, 0, -1), (11, 1, -1), (14, -1, -1), (8, 1, -1), (7, 1, -1)]
-        run(f"int64 key, {groups} groups, SUM_INT + COUNT_ROWS + MIN + MAX", cols, [cd.INT64, cd.INT64], [0], aggs, n,
-            n * 16.0 + groups * 40.0, expect=int(torch.unique(k).numel()), reps=reps)
+        yield run(f"int64 key, {groups} groups, SUM_INT + COUNT_ROWS + MIN + MAX", cols, [cd.INT64, cd.INT64], [0], aggs, n,
+                  n * 16.0 + groups * 40.0, expect=int(torch.unique(k).numel()), reps=reps)
         del cols, k, x
+
+
+def main():
+    lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # e.g. "q1,1024,65536"
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    cpu_sample = int(sys.argv[4]) if len(sys.argv) > 4 else None  # 0: skip the CPU baseline (profiling runs)
+    for r in measure(lg, only, reps, cpu_sample):
+        print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":

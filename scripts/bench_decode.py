@@ -15,11 +15,8 @@ from cockroach_amd import _lib, coldata as cd, device as dev  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    batch_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 10 << 20
-    _lib.check(_lib.load().crgpu_init(0))
+def measure(n=1 << 22, reps=8, batch_bytes=10 << 20, device_index=0):
+    _lib.check(_lib.load().crgpu_init(device_index))
     rng = np.random.default_rng(3)
     kt, kd = [cd.INT64, cd.INT64], [0, 0]
     vt = [cd.INT64, cd.INT64, cd.FLOAT64, cd.FLOAT64, cd.FLOAT64, cd.FLOAT64, cd.BYTES, cd.BYTES, cd.INT64, cd.INT64,
@@ -85,12 +82,20 @@ def main():
     cpu = {"value": len(cpu_out[0]) / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
            "sample": f"one replica ({one} bytes, {len(cpu_out[0])} rows) of the same batches (oracle/crdb_kv.c, 1 thread)"}
     out_bytes = rows * (4 * 8 + 2 * (1 + 4) + 8)
-    print(json.dumps({"rows": rows, "input_bytes": in_bytes, "bytes_per_row": in_bytes / rows, "batches_per_call": len(offs) - 1,
+    d.close()
+    return ({"rows": rows, "input_bytes": in_bytes, "bytes_per_row": in_bytes / rows, "batches_per_call": len(offs) - 1,
                       "wall_ms": dt * 1e3, "kv_walk_ms": walk_ms, "kv_decode_ms": dec_ms,
                       "rows_per_s": rows / dt, "input_GBps_wall": in_bytes / dt / 1e9,
                       "decode_kernel_GBps": (in_bytes + out_bytes) / (dec_ms / 1e3) / 1e9 if dec_ms else None,
                       "walk_kernel_GBps": 2 * in_bytes / (walk_ms / 1e3) / 1e9 if walk_ms else None,
-                      "cpu_baseline": cpu}))
+                      "cpu_baseline": cpu})
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    batch_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 10 << 20
+    print(json.dumps(measure(n, reps, batch_bytes)))
 
 
 if __name__ == "__main__":
