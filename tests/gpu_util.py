@@ -72,3 +72,16 @@ def gpu_agg(cols, group_cols, aggs, chunks=1):
     out = dev.result_to_vecs(res)
     a.close()
     return out
+
+
+def wrap_torch(col, n, dtype, device):
+    """torch view (no copy) of the data buffer of a device column (library-owned result or input)."""
+    import torch
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+    h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(col.data_ptr), False), "version": 3}
+    return torch.as_tensor(h, device=device)

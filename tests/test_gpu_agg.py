@@ -159,3 +159,55 @@ def test_agg_reset_reuses_handle(oracle):
         assert np.array_equal(_canon(got), _canon(want))
         a.reset()
     a.close()
+
+
+@pytest.mark.parametrize("ngroups", [5, 3000, 200_000, 5_000_000, 1 << 26])
+def test_agg_full_size_invariants(ngroups):
+    """2^26 rows resident in HBM (the bench shapes; too large for the oracle in the test budget): size-independent
+    properties that any loss, duplication or mis-grouping of rows would break -- one output row per distinct key,
+    COUNT_ROWS sums to the row count, SUM_INT/MIN/MAX per group equal an independent torch reduction, and
+    two passes over halves give the same result as one pass."""
+    import torch
+    from cockroach_amd import device as dev
+    n = 1 << 26
+    dv = torch.device("cuda", 0)
+    g = torch.Generator(device=dv)
+    g.manual_seed(ngroups)
+    if ngroups == n:
+        k = torch.randperm(n, generator=g, device=dv, dtype=torch.int64) * 7 - 12345
+    else:
+        k = torch.randint(0, ngroups, (n,), generator=g, device=dv, dtype=torch.int64) * 7 - 12345
+    x = torch.randint(-10**9, 10**9, (n,), generator=g, device=dv, dtype=torch.int64)
+    torch.cuda.synchronize()
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64], [0], aggs)
+
+    def result():
+        res = a.finish()
+        cols = dev.result_columns(res)
+        m = int(res.n)
+        return [G.wrap_torch(c, m, torch.int64, dv).clone() for c in cols]
+
+    a.consume([dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)], n)
+    keys, sums, cnts, mins, maxs = result()
+    uk, inv = torch.unique(k, return_inverse=True)
+    assert keys.numel() == uk.numel()
+    order = torch.argsort(keys)
+    assert torch.equal(keys[order], uk)
+    assert int(cnts.sum().item()) == n
+    assert torch.equal(cnts[order], torch.bincount(inv, minlength=uk.numel()))
+    ref_sum = torch.zeros(uk.numel(), dtype=torch.int64, device=dv).index_add_(0, inv, x)
+    assert torch.equal(sums[order], ref_sum)
+    ref_min = torch.full((uk.numel(),), 2**62, dtype=torch.int64, device=dv).scatter_reduce_(0, inv, x, "amin")
+    ref_max = torch.full((uk.numel(),), -2**62, dtype=torch.int64, device=dv).scatter_reduce_(0, inv, x, "amax")
+    assert torch.equal(mins[order], ref_min) and torch.equal(maxs[order], ref_max)
+    # online: two consume calls over the halves
+    a.reset()
+    h = n // 2
+    a.consume([dev.from_torch(cd.INT64, k[:h]), dev.from_torch(cd.INT64, x[:h])], h)
+    a.consume([dev.from_torch(cd.INT64, k[h:]), dev.from_torch(cd.INT64, x[h:])], n - h)
+    keys2, sums2, cnts2, mins2, maxs2 = result()
+    o2 = torch.argsort(keys2)
+    assert torch.equal(keys2[o2], uk) and torch.equal(sums2[o2], ref_sum) and torch.equal(cnts2[o2], cnts[order])
+    assert torch.equal(mins2[o2], ref_min) and torch.equal(maxs2[o2], ref_max)
+    a.close()
