@@ -681,6 +681,57 @@ __device__ inline void lds_flush_op(const OpK &op, const unsigned long long *lds
   }
 }
 
+// merge group g of a single-replica partial table into the HBM accumulators when no other workgroup touches
+// these groups during the kernel: plain read-modify-write, no atomics
+__device__ inline void lds_flush_exclusive(const OpK &op, const unsigned long long *ldsw, const uint8_t *ldss, uint32_t G,
+                                           uint32_t g, uint32_t gid) {
+  if (op.kind == ACC_ANY_KEY) return;
+  const unsigned long long v0 = ldsw[static_cast<size_t>(op.lw0) * G + g];
+  const unsigned long long v1 = op.lw1 >= 0 ? ldsw[static_cast<size_t>(op.lw1) * G + g] : 0ull;
+  if (op.lseen >= 0 && ldss[static_cast<size_t>(op.lseen) * G + g] == 0) return;
+  switch (op.kind) {
+    case ACC_COUNT_ROWS:
+    case ACC_COUNT: if (v0) op.w0[gid] += v0; break;
+    case ACC_SUM_F64:
+      op.w0[gid] = static_cast<unsigned long long>(__double_as_longlong(
+          __longlong_as_double(static_cast<long long>(op.w0[gid])) + __longlong_as_double(static_cast<long long>(v0))));
+      op.seen[gid] = 1;
+      break;
+    case ACC_AVG_F64:
+      if (v1) {
+        op.w0[gid] = static_cast<unsigned long long>(__double_as_longlong(
+            __longlong_as_double(static_cast<long long>(op.w0[gid])) + __longlong_as_double(static_cast<long long>(v0))));
+        op.w1[gid] += v1;
+      }
+      break;
+    case ACC_SUM_I128: {
+      const unsigned long long lo = op.w0[gid], s = lo + v0;
+      op.w0[gid] = s;
+      op.w1[gid] += v1 + (s < lo ? 1ull : 0ull);
+      op.seen[gid] = 1;
+      break;
+    }
+    case ACC_MIN_I64: {
+      const long long o = static_cast<long long>(op.w0[gid]), t = static_cast<long long>(v0);
+      op.w0[gid] = static_cast<unsigned long long>(t < o ? t : o);
+      op.seen[gid] = 1;
+      break;
+    }
+    case ACC_MAX_I64: {
+      const long long o = static_cast<long long>(op.w0[gid]), t = static_cast<long long>(v0);
+      op.w0[gid] = static_cast<unsigned long long>(t > o ? t : o);
+      op.seen[gid] = 1;
+      break;
+    }
+    case ACC_MIN_F64: { const unsigned long long o = op.w0[gid]; op.w0[gid] = v0 < o ? v0 : o; op.seen[gid] = 1; break; }
+    case ACC_MAX_F64: { const unsigned long long o = op.w0[gid]; op.w0[gid] = v0 > o ? v0 : o; op.seen[gid] = 1; break; }
+    case ACC_BOOL_AND: op.w0[gid] &= v0; op.seen[gid] = 1; break;
+    case ACC_BOOL_OR: op.w0[gid] |= v0; op.seen[gid] = 1; break;
+    case ACC_ANY_ROW: { const unsigned long long o = op.w0[gid]; op.w0[gid] = v0 < o ? v0 : o; break; }
+    default: break;
+  }
+}
+
 struct AccArgs {
   KeyCols keys;
   KeyStore store;
@@ -856,10 +907,11 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
 // with everything accumulation needs -- the gid, one "takes this row" bit per aggregation (FILTER and NULL
 // tests evaluated here, once) and the input values widened to 64 bits, each as a dense column.  Every
 // partition is then accumulated by a few workgroups in an LDS partial table exactly like the small case.
-static constexpr int kPartTile = 16384;       // rows per tile: 256 threads x 64 (long runs per partition: the stores combine in L2)
+static constexpr int kPartTileMin = 16384;    // rows per tile; tiles grow with the partition count so that a (tile, partition) run
+                                              // stays >= ~32 rows and its stores combine in L2
 static constexpr int kPartRows = 8;           // rows per thread and step (two steps per tile)
 static constexpr int kMaxPartCols = 12;
-static constexpr uint32_t kMaxParts = 1024;
+static constexpr uint32_t kMaxParts = 8192;    // 2 x 32 KiB of LDS counters
 
 struct PartArgs {
   int64_t m;
@@ -867,7 +919,8 @@ struct PartArgs {
   const uint32_t *out_gid;
   const unsigned long long *meta;
   uint32_t shift, P, ntiles;
-  int32_t naggs, ncols, _pad;
+  int32_t naggs, ncols;
+  int32_t tile_rows;          // multiple of 256 * kPartRows
   uint32_t *gid_res;          // [m] resolved gid (kGidDefer: row is not part of this pass)
   uint32_t *tile_hist;        // [P][ntiles]
   const uint64_t *offsets;    // exclusive scan of tile_hist
@@ -885,9 +938,8 @@ __global__ __launch_bounds__(256) void agg_part_hist_kernel(PartArgs a) {
   for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     for (uint32_t p = threadIdx.x; p < a.P; p += 256) cnt[p] = 0;
     __syncthreads();
-    const int64_t base = static_cast<int64_t>(tile) * kPartTile;
-#pragma unroll
-    for (int r = 0; r < kPartTile / 256; r++) {
+    const int64_t base = static_cast<int64_t>(tile) * a.tile_rows;
+    for (int r = 0; r < a.tile_rows / 256; r++) {
       const int64_t i = base + r * 256 + threadIdx.x;
       if (i < a.m) {
         uint32_t g = a.out_gid[i];
@@ -946,8 +998,8 @@ __global__ __launch_bounds__(256) void agg_part_scatter_kernel(PartArgs a) {
       start[p] = static_cast<uint32_t>(a.offsets[static_cast<size_t>(p) * a.ntiles + tile]);
     }
     __syncthreads();
-    const int64_t base = static_cast<int64_t>(tile) * kPartTile;
-    for (int step = 0; step < kPartTile / 256 / kPartRows; step++) {
+    const int64_t base = static_cast<int64_t>(tile) * a.tile_rows;
+    for (int step = 0; step < a.tile_rows / 256 / kPartRows; step++) {
       int64_t row[kPartRows];
       uint32_t g[kPartRows], dest[kPartRows], bits[kPartRows];
 #pragma unroll
@@ -1008,7 +1060,8 @@ __global__ __launch_bounds__(256) void agg_part_starts_kernel(const uint64_t *__
 }
 
 struct PartWg {  // one workgroup of the partitioned accumulate: rows [begin, end) of partition `part`
-  uint32_t part, _pad;
+  uint32_t part;
+  uint32_t exclusive;  // the only workgroup of its partition: merges with plain read-modify-writes instead of atomics
   uint64_t begin, end;
 };
 struct PartAccArgs {
@@ -1070,7 +1123,8 @@ __global__ __launch_bounds__(512) void agg_part_accum_kernel(PartAccArgs a) {
   const uint32_t pairs = G * static_cast<uint32_t>(a.naggs);
   for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
     const uint32_t f = t / G, g = t - f * G;
-    lds_flush_op(a.ops[f], lds_words, lds_seen, plane, 1, g, gid_lo + g);
+    if (d.exclusive) lds_flush_exclusive(a.ops[f], lds_words, lds_seen, plane, g, gid_lo + g);
+    else lds_flush_op(a.ops[f], lds_words, lds_seen, plane, 1, g, gid_lo + g);
   }
 }
 
@@ -1955,7 +2009,9 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
 static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const AccPlan &plan) {
   hipStream_t st = stream();
   const uint32_t P = plan.P;
-  const uint32_t ntiles = static_cast<uint32_t>((in.m + kPartTile - 1) / kPartTile);
+  int64_t tile_rows = kPartTileMin;
+  while (tile_rows < static_cast<int64_t>(P) * 32 && (in.m + tile_rows - 1) / tile_rows > 512) tile_rows *= 2;
+  const uint32_t ntiles = static_cast<uint32_t>((in.m + tile_rows - 1) / tile_rows);
   const size_t m = static_cast<size_t>(in.m);
   // aggregation descriptors + the distinct value columns they read
   std::vector<OpK> ops;
@@ -2003,6 +2059,7 @@ static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const 
   pa.shift = plan.shift;
   pa.P = P;
   pa.ntiles = ntiles;
+  pa.tile_rows = static_cast<int32_t>(tile_rows);
   pa.naggs = static_cast<int32_t>(ops.size());
   pa.ncols = static_cast<int32_t>(cols.size());
   pa.gid_res = a->p_gid_res.as<uint32_t>();
@@ -2051,7 +2108,7 @@ static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const 
     for (uint64_t w = 0; w < nw; w++) {
       PartWg d;
       d.part = q;
-      d._pad = 0;
+      d.exclusive = nw == 1 ? 1u : 0u;
       d.begin = b + w * per;
       d.end = d.begin + per < e ? d.begin + per : e;
       if (d.begin < d.end) wgs.push_back(d);
