@@ -933,23 +933,31 @@ struct PartArgs {
   OpK ops[kMaxOpsPerLaunch];  // FILTER / validity pointers of each aggregation
 };
 
-__global__ __launch_bounds__(256) void agg_part_hist_kernel(PartArgs a) {
+__global__ __launch_bounds__(1024) void agg_part_hist_kernel(PartArgs a) {
   __shared__ uint32_t cnt[kMaxParts];
   for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    for (uint32_t p = threadIdx.x; p < a.P; p += 256) cnt[p] = 0;
+    for (uint32_t p = threadIdx.x; p < a.P; p += blockDim.x) cnt[p] = 0;
     __syncthreads();
     const int64_t base = static_cast<int64_t>(tile) * a.tile_rows;
-    for (int r = 0; r < a.tile_rows / 256; r++) {
-      const int64_t i = base + r * 256 + threadIdx.x;
-      if (i < a.m) {
-        uint32_t g = a.out_gid[i];
-        if (g != kGidDefer && (g & kGidSlotRef)) g = static_cast<uint32_t>(a.meta[g & ~kGidSlotRef]);
-        a.gid_res[i] = g;
-        if (g != kGidDefer) atomicAdd(&cnt[g >> a.shift], 1u);
+    for (int step = 0; step < a.tile_rows / static_cast<int>(blockDim.x) / kPartRows; step++) {
+      uint32_t g[kPartRows];
+#pragma unroll
+      for (int k = 0; k < kPartRows; k++) {
+        const int64_t i = base + (step * kPartRows + k) * blockDim.x + threadIdx.x;
+        g[k] = i < a.m ? a.out_gid[i] : kGidDefer;
+      }
+#pragma unroll
+      for (int k = 0; k < kPartRows; k++)
+        if (g[k] != kGidDefer && (g[k] & kGidSlotRef)) g[k] = static_cast<uint32_t>(a.meta[g[k] & ~kGidSlotRef]);
+#pragma unroll
+      for (int k = 0; k < kPartRows; k++) {
+        const int64_t i = base + (step * kPartRows + k) * blockDim.x + threadIdx.x;
+        if (i < a.m) a.gid_res[i] = g[k];
+        if (g[k] != kGidDefer) atomicAdd(&cnt[g[k] >> a.shift], 1u);
       }
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < a.P; p += 256) a.tile_hist[static_cast<size_t>(p) * a.ntiles + tile] = cnt[p];
+    for (uint32_t p = threadIdx.x; p < a.P; p += blockDim.x) a.tile_hist[static_cast<size_t>(p) * a.ntiles + tile] = cnt[p];
     __syncthreads();
   }
 }
@@ -990,21 +998,21 @@ __device__ __forceinline__ void take_bits(const OpK *ops, int naggs, const int64
   }
 }
 
-__global__ __launch_bounds__(256) void agg_part_scatter_kernel(PartArgs a) {
+__global__ __launch_bounds__(1024) void agg_part_scatter_kernel(PartArgs a) {
   __shared__ uint32_t cnt[kMaxParts], start[kMaxParts];
   for (uint32_t tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    for (uint32_t p = threadIdx.x; p < a.P; p += 256) {
+    for (uint32_t p = threadIdx.x; p < a.P; p += blockDim.x) {
       cnt[p] = 0;
       start[p] = static_cast<uint32_t>(a.offsets[static_cast<size_t>(p) * a.ntiles + tile]);
     }
     __syncthreads();
     const int64_t base = static_cast<int64_t>(tile) * a.tile_rows;
-    for (int step = 0; step < a.tile_rows / 256 / kPartRows; step++) {
+    for (int step = 0; step < a.tile_rows / static_cast<int>(blockDim.x) / kPartRows; step++) {
       int64_t row[kPartRows];
       uint32_t g[kPartRows], dest[kPartRows], bits[kPartRows];
 #pragma unroll
       for (int k = 0; k < kPartRows; k++) {
-        const int64_t i = base + (step * kPartRows + k) * 256 + threadIdx.x;
+        const int64_t i = base + (step * kPartRows + k) * blockDim.x + threadIdx.x;
         const bool active = i < a.m;
         g[k] = active ? a.gid_res[i] : kGidDefer;
         row[k] = active ? (a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i) : 0;
@@ -1074,7 +1082,7 @@ struct PartAccArgs {
   const uint32_t *flags;
   const PartWg *wgs;
 };
-__global__ __launch_bounds__(512) void agg_part_accum_kernel(PartAccArgs a) {
+__global__ __launch_bounds__(1024) void agg_part_accum_kernel(PartAccArgs a) {
   extern __shared__ unsigned long long lds_words[];
   const PartWg d = a.wgs[blockIdx.x];
   const uint32_t gid_lo = d.part << a.shift;
@@ -1148,12 +1156,15 @@ __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
   // Same-address HBM atomics serialise (~10 ns each), so new-group / deferred-row slots are
   // reserved per workgroup tile: waves count in LDS, one thread reserves for the whole tile.
   __shared__ unsigned int s_cnt[2], s_base[2];
+  __shared__ unsigned int s_cas_first;  // claim without looking first: follows the share of new groups in the previous tile
   const KeyStore &store = a.store;
   const int64_t tile_rows = 256 * kResolveRows;
   const int64_t ntiles = (a.m + tile_rows - 1) / tile_rows;
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_cas_first = a.cas_first;
   __syncthreads();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const bool cas_first = s_cas_first != 0;
     uint32_t res[kResolveRows], slot[kResolveRows], loc[kResolveRows];
     unsigned long long word[kResolveRows];
     int64_t row[kResolveRows];
@@ -1174,7 +1185,7 @@ __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
         uint32_t idx = rh.idx & a.mask;
         for (int probes = 0; probes < kMaxProbe; probes++) {
           // A failed CAS still costs an HBM atomic (~24 G/s), a load does not: look first unless most rows are new groups
-          unsigned long long e = a.cas_first ? kMetaEmpty : __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned long long e = cas_first ? kMetaEmpty : __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (e == kMetaEmpty) e = atomicCAS(&a.meta[idx], kMetaEmpty, claim);
           if (e == kMetaEmpty) {
             is_new[k] = true;
@@ -1219,6 +1230,7 @@ __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
       const unsigned int c = s_cnt[threadIdx.x];
       s_base[threadIdx.x] = c ? atomicAdd(&a.counters[threadIdx.x], c) : 0;
       s_cnt[threadIdx.x] = 0;
+      if (threadIdx.x == 0) s_cas_first = c * 2 > static_cast<unsigned int>(tile_rows) ? 1u : 0u;
     }
     __syncthreads();
     const unsigned int base_new = s_base[0], base_def = s_base[1];
@@ -2074,17 +2086,19 @@ static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const 
   }
   if (!ops.empty()) std::memcpy(pa.ops, ops.data(), sizeof(OpK) * ops.size());
   const dim3 grid(static_cast<unsigned int>(ntiles < static_cast<uint32_t>(num_cus()) * 8 ? ntiles : num_cus() * 8));
+  // few, large tiles when there are many ranges: 16 waves per workgroup keep the CU busy
+  const dim3 pblock(tile_rows >= 65536 ? 1024 : 256);
   uint64_t total = 0;
   {
     ProfScope prof("agg_part_hist");
-    hipLaunchKernelGGL(agg_part_hist_kernel, grid, dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(agg_part_hist_kernel, grid, pblock, 0, st, pa);
     CRGPU_HIP(hipGetLastError());
   }
   CRGPU_TRY(exclusive_scan_u32(a->p_hist.as<uint32_t>(), static_cast<int64_t>(P) * ntiles, a->p_offsets.as<uint64_t>(),
                                a->scratch, &total));
   {
     ProfScope prof("agg_part_scatter");
-    hipLaunchKernelGGL(agg_part_scatter_kernel, grid, dim3(256), 0, st, pa);
+    hipLaunchKernelGGL(agg_part_scatter_kernel, grid, pblock, 0, st, pa);
     CRGPU_HIP(hipGetLastError());
   }
   // partition boundaries: offsets[p * ntiles] for every p, then `total`
@@ -2133,7 +2147,8 @@ static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const 
   aa.wgs = a->p_wgs.as<PartWg>();
   {
     ProfScope prof("agg_part_accum");
-    hipLaunchKernelGGL(agg_part_accum_kernel, dim3(static_cast<unsigned int>(wgs.size())), dim3(512),
+    // one workgroup per CU when the table is large: make it 16 waves
+    hipLaunchKernelGGL(agg_part_accum_kernel, dim3(static_cast<unsigned int>(wgs.size())), dim3(plan.lds_bytes > 76 * 1024 ? 1024 : 512),
                        (plan.lds_bytes + 15) & ~size_t(15), st, aa);
     CRGPU_HIP(hipGetLastError());
   }
@@ -2344,12 +2359,13 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
     if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null data pointer");
     in.push_back(to_dcol(cols[c]));
   }
-  // chunking: a small first chunk discovers the cardinality regime, then 16M-row chunks (the per-row
-  // temporaries of find-or-insert are sized by the chunk); once hardly any new group appears the fused
-  // pass needs none of them and larger chunks mean fewer merges of the LDS partial tables
+  // chunking: a small first chunk discovers the cardinality regime; after that chunks are large (2^27 rows,
+  // ~50 B of temporaries per row in the find-or-insert / partitioned paths): every chunk costs one merge of the
+  // LDS partial tables and one pass over all gid ranges, so fewer chunks are cheaper
   int64_t pos = 0;
   while (pos < n) {
-    const int64_t kChunk = (a->seq > 0 && a->new_ratio < 0.01 && !a->need_any_fix) ? int64_t(1) << 28 : int64_t(1) << 24;
+    // 2^16 rows, then 2^22 (refines the share of new groups, which picks claim-first or look-first), then 2^27
+    const int64_t kChunk = a->seq >= (1u << 22) ? int64_t(1) << 27 : int64_t(1) << 22;
     int64_t len = n - pos < kChunk ? n - pos : kChunk;
     if (a->seq == 0 && len > 65536) len = 65536;
     std::vector<DCol> chunk = in;
