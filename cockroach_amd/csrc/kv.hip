@@ -40,6 +40,8 @@ struct FetchOut {
   uint8_t *valid[kMaxOutFetch];    // one byte per row
   uint32_t *lens[kMaxOutFetch];    // BYTES: decoded length per row (pass 0)
   const uint32_t *offs[kMaxOutFetch];  // BYTES: offsets (pass 1)
+  uint32_t *src[kMaxOutFetch];     // BYTES value columns: payload position inside the record (pass 0), so that
+                                   // pass 1 is a plain copy and does not parse the row again
 };
 
 enum : int32_t { KV_OK = 0, KV_TRUNCATED = 1, KV_BAD_MVCC_KEY = 2, KV_BAD_KEY = 3, KV_NOT_TUPLE = 4, KV_BAD_VALUE = 5 };
@@ -502,8 +504,10 @@ __device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, cons
             const int nn = dec_nonsorting_uvarint(d, drem, &l);
             if (nn < 0 || static_cast<int64_t>(l) > drem - nn) code = KV_BAD_VALUE;
             else {
-              if (PASS == 0) o.lens[oc][row] = static_cast<uint32_t>(l);
-              else {
+              if (PASS == 0) {
+                o.lens[oc][row] = static_cast<uint32_t>(l);
+                o.src[oc][row] = static_cast<uint32_t>(d + nn - p);
+              } else {
                 uint8_t *dst = static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row];
                 for (uint64_t t = 0; t < l; t++) dst[t] = d[nn + t];
               }
@@ -581,6 +585,23 @@ __global__ __launch_bounds__(256) void kv_decode_kernel(const uint8_t *__restric
   }
 }
 
+// Pass 1 when no BYTES KEY column is fetched (those need unescaping): copy the value payloads found by pass 0.
+__global__ __launch_bounds__(256) void kv_copy_bytes_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ rec_off,
+                                                            int64_t n, FetchSpec f, FetchOut o) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+    const uint8_t *rec = repr + rec_off[row];
+    for (int c = 0; c < f.n_out; c++) {
+      if (f.out_types[c] != CRGPU_BYTES) continue;
+      const uint32_t a0 = o.offs[c][row], len = o.offs[c][row + 1] - a0;
+      if (len == 0) continue;
+      const uint8_t *s = rec + o.src[c][row];
+      uint8_t *dst = static_cast<uint8_t *>(o.data[c]) + a0;
+      for (uint32_t t = 0; t < len; t++) dst[t] = s[t];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void kv_narrow_offsets_kernel(const uint64_t *__restrict__ in, int64_t n,
                                                                 uint32_t *__restrict__ out) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -602,7 +623,7 @@ struct crgpu_decoder {
   FetchSpec spec;
   DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
   std::vector<OutCol> out;
-  std::vector<DevBuf> valid_bytes, lens;
+  std::vector<DevBuf> valid_bytes, lens, srcpos;
   std::vector<crgpu_dcol> views;
 };
 
@@ -653,6 +674,7 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
   d->out = std::vector<OutCol>(f.n_out);
   d->valid_bytes = std::vector<DevBuf>(f.n_out);
   d->lens = std::vector<DevBuf>(f.n_out);
+  d->srcpos = std::vector<DevBuf>(f.n_out);
   d->views.resize(f.n_out);
   *out = d;
   return CRGPU_OK;
@@ -781,6 +803,8 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
       CRGPU_TRY(d->lens[c].ensure(static_cast<size_t>(cap) * 4));
       CRGPU_TRY(oc.offsets.ensure(static_cast<size_t>(cap + 1) * 4));
       o.lens[c] = d->lens[c].as<uint32_t>();
+      CRGPU_TRY(d->srcpos[c].ensure(static_cast<size_t>(cap) * 4));
+      o.src[c] = d->srcpos[c].as<uint32_t>();
       if (n == 0) CRGPU_HIP(hipMemsetAsync(oc.offsets.p, 0, 4, st));
     } else {
       CRGPU_TRY(oc.data.ensure(static_cast<size_t>(cap) * type_width(oc.type)));
@@ -808,9 +832,14 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
         o.data[c] = d->out[c].data.p;
         o.offs[c] = d->out[c].offsets.as<uint32_t>();
       }
+      bool bytes_key = false;
+      for (int c = 0; c < f.n_key; c++) bytes_key |= f.key_types[c] == CRGPU_BYTES && f.key_out[c] >= 0;
       ProfScope prof("kv_decode");
-      hipLaunchKernelGGL(kv_decode_kernel<1>, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
-                         d->err.as<KvError>());
+      if (bytes_key)
+        hipLaunchKernelGGL(kv_decode_kernel<1>, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
+                           d->err.as<KvError>());
+      else
+        hipLaunchKernelGGL(kv_copy_bytes_kernel, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o);
       CRGPU_HIP(hipGetLastError());
     }
     for (int c = 0; c < f.n_out; c++) CRGPU_TRY(pack_bitmap(o.valid[c], n, d->out[c].valid.as<uint8_t>()));
