@@ -31,6 +31,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def np_log(x):
+    import math
+    return math.log(x)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-log2-build", type=int, default=25)
     ap.add_argument("--cpu-log2-probe", type=int, default=27)
     ap.add_argument("--no-other-paths", action="store_true", help="skip the aggregation / decode side measurements")
+    ap.add_argument("--variant", default="hit100", choices=["hit100", "hit50", "zipf", "null1"],
+                    help="probe-key variants of config J (SURVEY.md 8(d)): 100%% hit (the headline), 50%% hit, "
+                         "Zipf-like skew (theta=1), 1%% NULL probe keys")
     return ap.parse_args()
 
 
@@ -130,7 +138,22 @@ def main():
         bk = bk * world + rank  # globally unique keys, spread over all destinations
     bv = bk * 3 + 1
     g.manual_seed(43 + rank)
-    pk = torch.randint(0, nb * world, (npr,), generator=g, device=device, dtype=torch.int64)  # 100 % hit
+    pk_valid = None
+    if args.variant == "hit50":
+        pk = torch.randint(0, 2 * nb * world, (npr,), generator=g, device=device, dtype=torch.int64)
+    elif args.variant == "zipf":
+        # P(rank r) ~ 1/r over [1, nb*world): inverse CDF of the continuous 1/x density, ranks spread over the key
+        # domain by an odd multiplier (a bijection mod 2^k)
+        u = torch.rand(npr, generator=g, device=device, dtype=torch.float64)
+        r = torch.exp(u * float(np_log(nb * world))).to(torch.int64).clamp_(1, nb * world - 1)
+        pk = (r * 0x9E3779B1) % (nb * world)
+        del u, r
+    else:
+        pk = torch.randint(0, nb * world, (npr,), generator=g, device=device, dtype=torch.int64)  # 100 % hit
+    if args.variant == "null1":
+        isnull = torch.rand(npr, generator=g, device=device) < 0.01
+        bits = (~isnull).view(-1, 8).to(torch.uint8)  # coldata.Nulls: bit = 1 => present, LSB first
+        pk_valid = (bits * (2 ** torch.arange(8, device=device, dtype=torch.uint8))).sum(1, dtype=torch.uint8).contiguous()
     pw = torch.arange(npr, device=device, dtype=torch.int64) + rank * npr
     torch.cuda.synchronize()
 
@@ -158,7 +181,10 @@ def main():
             p_cols, npl = exchange(part_p, [pk, pw], npr)
             torch.cuda.synchronize()
         join.build([dev.from_torch(I64, t) for t in b_cols], nbl)
-        res = join.probe([dev.from_torch(I64, t) for t in p_cols], npl)
+        pcols = [dev.from_torch(I64, t) for t in p_cols]
+        if pk_valid is not None and world == 1:
+            pcols[0] = dev.from_torch(I64, p_cols[0], valid=pk_valid)
+        res = join.probe(pcols, npl)
         return res, b_cols, p_cols
 
     def barrier():
@@ -186,8 +212,11 @@ def main():
     v_out = _wrap(torch, res.cols[1].data, out_rows, device)
     ok = True
     if world == 1:
-        ok = out_rows == npr and int(v_out.sum().item()) == int((pk * 3 + 1).sum().item()) \
-            and int(w_out.sum().item()) == int(pw.sum().item())
+        hit = pk < nb  # build keys are a permutation of [0, nb)
+        if args.variant == "null1":
+            hit = hit & ~isnull
+        ok = out_rows == int(hit.sum().item()) and int(v_out.sum().item()) == int(((pk * 3 + 1) * hit).sum().item()) \
+            and int(w_out.sum().item()) == int((pw * hit).sum().item())
     if world > 1:
         t = torch.tensor([dt, float(out_rows), float(ok)], device=device, dtype=torch.float64)
         tmax = t.clone()
@@ -229,7 +258,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
             "data": "synthetic",
             "config": {"workload": f"hash join microbench: int64 keys, 2^{args.log2_build} build x "
-                                   f"2^{args.log2_probe} probe rows per GPU, INNER, unique build keys, 100% hit, "
+                                   f"2^{args.log2_probe} probe rows per GPU, INNER, unique build keys, "
+                                   f"{ {'hit100': '100% hit', 'hit50': '50% hit', 'zipf': 'Zipf-like probe keys (theta=1)', 'null1': '1% NULL probe keys'}[args.variant]}, "
                                    "output (w, v)",
                        "parallelism": "single GPU" if world == 1 else f"hash repartition all-to-all over {world} GPUs",
                        "result_check": "ok" if ok else "MISMATCH"},
