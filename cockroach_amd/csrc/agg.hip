@@ -39,6 +39,7 @@
 #include <memory>
 
 #include "device.h"
+#include "radix.h"
 
 namespace crgpu {
 
@@ -1136,6 +1137,139 @@ __global__ __launch_bounds__(1024) void agg_part_accum_kernel(PartAccArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ bulk aggregation of a high-cardinality input
+// A fresh table fed one large input of mostly distinct keys would pay one random HBM CAS (~10 G/s with the
+// returned value) plus a random 8-byte write per row in find-or-insert.  When the shape allows it (one INT64 key
+// column and at most one 8-byte value column, no NULLs, no FILTER) the rows are instead radix-partitioned by key
+// hash with the join's build-side kernels (radix.hip: 1024 partitions, then <= 64 sub-partitions of <= 2560 rows)
+// and every sub-partition is grouped and aggregated ENTIRELY IN LDS by one workgroup: equal keys share a
+// sub-partition, so its groups are final and are appended to the per-group arrays (one HBM atomic per workgroup
+// reserves their group ids).  The hash index is not touched; it is rebuilt from the hash words if more input follows.
+static constexpr int kBulkSlots = 4096;       // LDS index of one sub-partition
+static constexpr uint32_t kBulkRows = 4096;   // rows a sub-partition may hold (region size of the split)
+static constexpr uint32_t kBulkGroups = 2816; // groups a sub-partition may hold (LDS accumulator planes)
+struct BulkArgs {
+  const ulonglong2 *rows;       // {key, value} rows, kBulkRows per sub-partition
+  const uint32_t *sub_count;
+  OpK ops[kMaxOpsPerLaunch];    // accumulator pointers and LDS plane numbers; inputs all come from the row's value
+  int32_t naggs;
+  uint32_t nwords, nseen;
+  int32_t key_type;
+  uint8_t *key_data;            // key store of the single group column
+  uint8_t *key_present;
+  unsigned long long *gword;
+  unsigned int *ngroups;        // running group count (HBM)
+  unsigned int *failed;         // a sub-partition held more than kBulkGroups groups
+  uint32_t g0;
+  uint32_t _pad;
+};
+__global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
+  extern __shared__ unsigned long long lds_words[];  // [nwords][kBulkGroups + 1] accumulators, then the seen planes
+  __shared__ uint32_t idx[kBulkSlots];               // slot -> representative row, later -> local group id
+  __shared__ uint32_t rep[kBulkGroups];              // local group id -> representative row
+  __shared__ uint32_t s_ngrp, s_base, s_claims;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  const uint32_t plane = kBulkGroups + 1;
+  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
+  const int q = blockIdx.x;
+  const ulonglong2 *rows = a.rows + static_cast<int64_t>(q) * kBulkRows;
+  const uint32_t n = a.sub_count[q];
+  if (n == 0) return;
+  for (uint32_t i = threadIdx.x; i < kBulkSlots; i += blockDim.x) idx[i] = kNone;
+  for (int f = 0; f < a.naggs; f++) {
+    const OpK &op = a.ops[f];
+    if (op.lw0 >= 0) {
+      const unsigned long long init = acc_init_w0(op.kind);
+      for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * plane + i] = init;
+    }
+    if (op.lw1 >= 0)
+      for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * plane + i] = 0ull;
+  }
+  for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
+  if (threadIdx.x == 0) s_ngrp = 0, s_claims = 0;
+  __syncthreads();
+  // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key).  There are at
+  //    least as many slots as rows, so every probe sequence ends.
+  constexpr int kRows = kBulkRows / 1024;  // rows per thread at 1024 threads
+  uint32_t slot_of[kRows];
+  unsigned long long val[kRows];
+#pragma unroll
+  for (int k = 0; k < kRows; k++) {
+    const uint32_t i = k * blockDim.x + threadIdx.x;
+    slot_of[k] = kNone;
+    val[k] = 0;
+    if (i < n) {
+      const ulonglong2 r = rows[i];
+      val[k] = r.y;
+      uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & (kBulkSlots - 1);
+      for (;;) {
+        uint32_t cur = idx[sl];
+        if (cur == kNone) {
+          cur = atomicCAS(&idx[sl], kNone, i);
+          if (cur == kNone) {
+            atomicAdd(&s_claims, 1u);
+            break;
+          }
+        }
+        if (rows[cur].x == r.x) break;
+        sl = (sl + 1) & (kBulkSlots - 1);
+      }
+      slot_of[k] = sl;
+    }
+  }
+  __syncthreads();
+  if (s_claims > kBulkGroups) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
+    if (threadIdx.x == 0) atomicOr(a.failed, 1u);
+    return;
+  }
+  // 2. number the groups of this sub-partition
+  for (uint32_t sl = threadIdx.x; sl < kBulkSlots; sl += blockDim.x) {
+    const uint32_t r = idx[sl];
+    if (r != kNone) {
+      const uint32_t lid = atomicAdd(&s_ngrp, 1u);
+      rep[lid] = r;
+      idx[sl] = lid;
+    }
+  }
+  __syncthreads();
+  // 3. accumulate in LDS (apply_rows_lds: straight-line updates; rows past the end go to the trash group)
+  {
+    uint32_t gr[kRows];
+    int64_t rowi[kRows];
+    uint32_t takem = 0;
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+      gr[k] = slot_of[k] != kNone ? idx[slot_of[k]] : 0;
+      rowi[k] = 0;
+      takem |= (slot_of[k] != kNone ? 1u : 0u) << k;
+    }
+    for (int f = 0; f < a.naggs; f++)
+      apply_rows_lds<kRows>(a.ops[f], val, takem, gr, kBulkGroups, plane, lds_words, lds_seen, rowi, 0ull);
+  }
+  __syncthreads();
+  // 4. append the groups: ids [base, base + ngrp), everything written with plain coalesced stores
+  const uint32_t ngrp = s_ngrp;
+  if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, ngrp);
+  __syncthreads();
+  const uint32_t base = a.g0 + s_base;
+  for (uint32_t l = threadIdx.x; l < ngrp; l += blockDim.x) {
+    const uint32_t gid = base + l;
+    const unsigned long long key = rows[rep[l]].x;
+    reinterpret_cast<unsigned long long *>(a.key_data)[gid] = key;
+    a.key_present[gid] = 1;
+    // hash word of the index entry this group gets if the index is ever rebuilt (agg_hash of one INT64 column)
+    const uint64_t h = fmix64(hash_step(0x9E3779B97F4A7C15ull, key));
+    a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
+                   (static_cast<uint32_t>(h) & kIdxHashMask);
+    for (int f = 0; f < a.naggs; f++) {
+      const OpK &op = a.ops[f];
+      op.w0[gid] = lds_words[static_cast<size_t>(op.lw0) * plane + l];
+      if (op.w1 != nullptr) op.w1[gid] = op.lw1 >= 0 ? lds_words[static_cast<size_t>(op.lw1) * plane + l] : 0ull;
+      if (op.seen != nullptr) op.seen[gid] = op.lseen >= 0 ? lds_seen[static_cast<size_t>(op.lseen) * plane + l] : 0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ find-or-insert (rows whose group may not exist yet)
 struct ResolveArgs {
   KeyCols keys;
@@ -1574,6 +1708,10 @@ struct crgpu_agg {
   DevBuf ops_dev, tails_dev, any_tails_dev, any_ptrs_dev;
   DevBuf counters, out_gid, list_a, list_b, rep_pos, rep_slot, rep_word, scratch, err_dev;
   DevBuf lens_tmp, offs64_tmp, present_tmp;
+  // bulk aggregation of a high-cardinality first input (radix.hip buffers); the index is rebuilt lazily afterwards
+  RadixTable radix;
+  bool index_valid = true;
+  DevBuf bulk_count;
   // gid-partitioned accumulation
   DevBuf p_gid_res, p_hist, p_offsets, p_gid, p_flags, p_wgs, p_starts;
   DevBuf p_cols[kMaxPartCols];
@@ -1825,6 +1963,8 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 32 * 1024)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_part_accum_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     lds_attr_set = true;
@@ -1844,6 +1984,7 @@ extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   a->ngroups = 0;
   a->seq = 0;
   a->new_ratio = 1.0;
+  a->index_valid = true;
   for (auto &k : a->ks) k.tail = 0;
   for (auto &o : a->ops) o.any_tail = 0;
   CRGPU_HIP(hipMemsetAsync(a->tails_dev.p, 0, kMaxKeyCols * 8, stream()));
@@ -2346,6 +2487,114 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
   return CRGPU_OK;
 }
 
+static constexpr int64_t kBulkMinRows = int64_t(1) << 23;
+
+__global__ void agg_sample_keys_kernel(const long long *__restrict__ keys, int64_t stride, int nsample, long long *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nsample) out[i] = keys[static_cast<int64_t>(i) * stride];
+}
+
+// Bulk path (see agg_bulk_kernel).  *done = true when the whole input was aggregated; otherwise nothing was changed
+// and the caller continues with the incremental path.
+static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
+  *done = false;
+  if (a->ngroups != 0 || a->seq != 0 || n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix) return CRGPU_OK;
+  if (a->group_cols.size() != 1 || a->types[a->group_cols[0]] != CRGPU_INT64) return CRGPU_OK;
+  const DCol &key = cols[a->group_cols[0]];
+  if (key.valid != nullptr || (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0) return CRGPU_OK;
+  int vcol = -1, nops = 0;
+  size_t lds = 0;
+  for (const AggOpHost &h : a->ops) {
+    if (h.kind == ACC_ANY_KEY) continue;
+    nops++;
+    if (h.filter_col >= 0) return CRGPU_OK;
+    if (h.kind != ACC_COUNT_ROWS) {
+      if (h.in_type != CRGPU_INT64 && h.in_type != CRGPU_FLOAT64) return CRGPU_OK;
+      if (vcol >= 0 && vcol != h.col) return CRGPU_OK;
+      vcol = h.col;
+    }
+  }
+  if (nops > kMaxOpsPerLaunch) return CRGPU_OK;
+  if (vcol >= 0 && (cols[vcol].valid != nullptr || (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0)) return CRGPU_OK;
+  lds = (static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen)) * (kBulkGroups + 1);
+  if (lds > kLdsMax - 32 * 1024) return CRGPU_OK;  // idx + rep take 27 KiB of static LDS
+  hipStream_t st = stream();
+  // high cardinality?  8192 keys sampled at a fixed stride: s^2 / 2G of them collide for G equally likely groups,
+  // so <= 8 duplicates means G >~ 4 M (fewer, larger groups overflow the sub-partition regions and are better
+  // served by the incremental paths anyway)
+  {
+    const int kSample = 8192;
+    std::vector<int64_t> sample(kSample);
+    const int64_t stride = n / kSample;
+    CRGPU_TRY(a->scratch.ensure(kSample * 8));
+    hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), stride,
+                       kSample, a->scratch.as<long long>());
+    CRGPU_HIP(hipGetLastError());
+    CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, kSample * 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    std::sort(sample.begin(), sample.end());
+    const int64_t distinct = std::unique(sample.begin(), sample.end()) - sample.begin();
+    if (kSample - distinct > 8) return CRGPU_OK;
+  }
+  RadixSrc src;
+  std::memset(&src, 0, sizeof(src));
+  src.key = key;
+  src.pay = vcol >= 0 ? static_cast<const uint8_t *>(cols[vcol].data) : nullptr;
+  src.pay_width = vcol >= 0 ? 8 : 0;
+  src.fast = vcol >= 0 ? 1 : 0;
+  bool ok = false;
+  CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows));
+  if (!ok) return CRGPU_OK;  // a sub-partition overflowed: many rows per key after all
+  CRGPU_TRY(ensure_groups(a, static_cast<size_t>(n)));
+  CRGPU_TRY(upload_descriptors(a, &cols));
+  CRGPU_TRY(a->bulk_count.ensure(8));
+  CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 8, st));
+  BulkArgs b;
+  std::memset(&b, 0, sizeof(b));
+  b.rows = a->radix.rows_b.as<ulonglong2>();
+  b.sub_count = a->radix.sub_count.as<uint32_t>();
+  int f = 0;
+  for (const AggOpHost &h : a->ops) {
+    if (h.kind == ACC_ANY_KEY) continue;
+    OpK &k = b.ops[f++];
+    k.kind = static_cast<int8_t>(h.kind);
+    k.in_type = static_cast<int8_t>(h.in_type);
+    k.lw0 = static_cast<int8_t>(h.lw0);
+    k.lw1 = static_cast<int8_t>(h.lw1);
+    k.lseen = static_cast<int8_t>(h.lseen);
+    k.w0 = h.w0.as<unsigned long long>();
+    k.w1 = h.w1.as<unsigned long long>();
+    k.seen = h.seen.as<uint8_t>();
+  }
+  b.naggs = f;
+  b.nwords = static_cast<uint32_t>(a->lds_words);
+  b.nseen = static_cast<uint32_t>(a->lds_seen);
+  b.key_type = CRGPU_INT64;
+  b.key_data = a->ks[0].data.as<uint8_t>();
+  b.key_present = a->ks[0].present.as<uint8_t>();
+  b.gword = a->gword.as<unsigned long long>();
+  b.ngroups = a->bulk_count.as<unsigned int>();
+  b.failed = a->bulk_count.as<unsigned int>() + 1;
+  b.g0 = 0;
+  const unsigned nsubs = static_cast<unsigned>(kRadixP1) << a->radix.sub_bits;
+  {
+    ProfScope prof("agg_bulk");
+    hipLaunchKernelGGL(agg_bulk_kernel, dim3(nsubs), dim3(1024), (lds + 15) & ~size_t(15), st, b);
+    CRGPU_HIP(hipGetLastError());
+  }
+  unsigned int tf[2] = {0, 0};
+  CRGPU_HIP(hipMemcpyAsync(tf, a->bulk_count.p, 8, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  if (tf[1]) return CRGPU_OK;  // nothing was committed: the groups written so far lie beyond ngroups == 0
+  const unsigned int total = tf[0];
+  a->ngroups = total;
+  a->seq = static_cast<unsigned long long>(n);
+  a->new_ratio = static_cast<double>(total) / static_cast<double>(n);
+  a->index_valid = false;  // the groups exist, their index entries do not
+  *done = true;
+  return CRGPU_OK;
+}
+
 extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
   if (a == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null handle");
   if (n < 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: negative row count");
@@ -2358,6 +2607,17 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
     if (cols[c].type == CRGPU_BYTES && cols[c].offsets == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: BYTES column without offsets");
     if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null data pointer");
     in.push_back(to_dcol(cols[c]));
+  }
+  {
+    bool done = false;
+    CRGPU_TRY(try_bulk(a, in, n, &done));
+    if (done) return CRGPU_OK;
+  }
+  if (!a->index_valid) {  // groups appended by the bulk path: give them index entries before looking anything up
+    const uint64_t want = next_pow2((static_cast<uint64_t>(a->ngroups) + 1) * 2);
+    if (want > kMaxCap) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^29 groups per GPU");
+    CRGPU_TRY(reindex(a, static_cast<uint32_t>(want > a->cap ? want : a->cap)));
+    a->index_valid = true;
   }
   // chunking: a small first chunk discovers the cardinality regime; after that chunks are large (2^27 rows,
   // ~50 B of temporaries per row in the find-or-insert / partitioned paths): every chunk costs one merge of the

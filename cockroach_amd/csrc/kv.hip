@@ -623,7 +623,7 @@ struct crgpu_decoder {
   FetchSpec spec;
   DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
   std::vector<OutCol> out;
-  std::vector<DevBuf> valid_bytes, lens, srcpos;
+  std::vector<DevBuf> valid_bytes, lens, srcpos, offs64c;
   std::vector<crgpu_dcol> views;
 };
 
@@ -675,6 +675,7 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
   d->valid_bytes = std::vector<DevBuf>(f.n_out);
   d->lens = std::vector<DevBuf>(f.n_out);
   d->srcpos = std::vector<DevBuf>(f.n_out);
+  d->offs64c = std::vector<DevBuf>(f.n_out);
   d->views.resize(f.n_out);
   *out = d;
   return CRGPU_OK;
@@ -771,9 +772,11 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
     hipLaunchKernelGGL(kv_seg_errors_kernel, dim3(vgrid), dim3(256), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_err.as<int32_t>(),
                        d->err.as<KvError>());
     CRGPU_HIP(hipGetLastError());
-    CRGPU_TRY(kv_check_error(d, "batch"));
+    // row number of every segment's first record; the grand total comes back with the error word in one round trip
     uint64_t total = 0;
-    CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, &total));
+    CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, nullptr));
+    CRGPU_HIP(hipMemcpyAsync(&total, d->seg_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, st));
+    CRGPU_TRY(kv_check_error(d, "batch"));
     n = static_cast<int64_t>(total);
     if (n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: more than 2^31 rows in one call");
     if (n > 0) {
@@ -818,15 +821,23 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
                          d->err.as<KvError>());
       CRGPU_HIP(hipGetLastError());
     }
-    CRGPU_TRY(kv_check_error(d, "row"));
+    // BYTES columns: lengths -> offsets; all scans are queued, then the totals and the error word come back together
+    std::vector<uint64_t> totals(static_cast<size_t>(f.n_out), 0);
     if (any_bytes) {
-      CRGPU_TRY(d->offs64.ensure(static_cast<size_t>(n + 1) * 8));
       for (int c = 0; c < f.n_out; c++) {
         if (f.out_types[c] != CRGPU_BYTES) continue;
-        uint64_t total = 0;
-        CRGPU_TRY(exclusive_scan_u32(d->lens[c].as<uint32_t>(), n, d->offs64.as<uint64_t>(), d->scratch, &total));
+        CRGPU_TRY(d->offs64c[c].ensure(static_cast<size_t>(n + 1) * 8));
+        CRGPU_TRY(exclusive_scan_u32(d->lens[c].as<uint32_t>(), n, d->offs64c[c].as<uint64_t>(), d->scratch, nullptr));
+        CRGPU_HIP(hipMemcpyAsync(&totals[c], d->offs64c[c].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+      }
+    }
+    CRGPU_TRY(kv_check_error(d, "row"));
+    if (any_bytes) {
+      for (int c = 0; c < f.n_out; c++) {
+        if (f.out_types[c] != CRGPU_BYTES) continue;
+        const uint64_t total = totals[c];
         if (total > 0xFFFFFFFFull) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: a BYTES column exceeds 4 GiB; decode fewer batches per call");
-        hipLaunchKernelGGL(kv_narrow_offsets_kernel, dim3(kv_grid(n + 1, 256)), dim3(256), 0, st, d->offs64.as<uint64_t>(), n + 1,
+        hipLaunchKernelGGL(kv_narrow_offsets_kernel, dim3(kv_grid(n + 1, 256)), dim3(256), 0, st, d->offs64c[c].as<uint64_t>(), n + 1,
                            d->out[c].offsets.as<uint32_t>());
         CRGPU_TRY(d->out[c].data.ensure(static_cast<size_t>(total ? total : 1)));
         o.data[c] = d->out[c].data.p;

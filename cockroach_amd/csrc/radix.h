@@ -63,6 +63,10 @@ struct RadixTable {
   DevBuf p_rows, p_hist, p_totals, p_starts;  // probe-side partition buffers
 };
 
+// Levels 1 and 2 only (hash aggregation of high-cardinality inputs reuses them): t.rows_b holds the rows of
+// sub-partition q in [q * subcap, q * subcap + sub_count[q]), q < kRadixP1 << t.sub_bits.
+// *ok = false when a sub-partition overflowed its region of `subcap` rows.
+crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap);
 // Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows
 // kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
 crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok);

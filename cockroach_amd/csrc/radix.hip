@@ -251,7 +251,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
                                                            const uint32_t *__restrict__ starts,
                                                            const uint32_t *__restrict__ totals, uint32_t smask,
                                                            ulonglong2 *__restrict__ out, uint32_t *__restrict__ sub_count,
-                                                           uint32_t *__restrict__ overflow) {
+                                                           uint32_t *__restrict__ overflow, uint32_t subcap) {
   constexpr int THREADS = 1024, ROWS = 4, TILE = THREADS * ROWS;
   const int p = blockIdx.x;
   const uint32_t nsub = smask + 1;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
   if (threadIdx.x < 64) tcnt[threadIdx.x] = 0, cur[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t s0 = starts[p], n = totals[p];
-  ulonglong2 *obase = out + static_cast<int64_t>(p) * nsub * kRadixSubCap;
+  ulonglong2 *obase = out + static_cast<int64_t>(p) * nsub * subcap;
   for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
     ulonglong2 row[ROWS];
     uint32_t sp[ROWS], rk[ROWS];
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
       const ulonglong2 r = stage[i];
       const uint32_t s = rsub(fmix64(r.x), smask);
       const uint32_t pos = cur[s] + (i - tstart[s]);
-      if (pos < static_cast<uint32_t>(kRadixSubCap)) obase[static_cast<int64_t>(s) * kRadixSubCap + pos] = r;
+      if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
   if (threadIdx.x < nsub) {
     const uint32_t c = cur[threadIdx.x];
     sub_count[p * nsub + threadIdx.x] = c;
-    if (c > static_cast<uint32_t>(kRadixSubCap)) atomicOr(overflow, 1u);
+    if (c > subcap) atomicOr(overflow, 1u);
   }
 }
 
@@ -610,7 +610,9 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
   return CRGPU_OK;
 }
 
-crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok) {
+// Levels 1 and 2: t.rows_b holds the rows of sub-partition q in [q * subcap, q * subcap + sub_count[q]).
+// *ok = false when a sub-partition overflowed its region (too many rows share hash bits: duplicate-heavy input).
+crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap) {
   hipStream_t st = stream();
   *ok = false;
   t.ready = false;
@@ -623,24 +625,35 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   t.sub_bits = sb;
   const uint32_t nsub = 1u << sb;
   CRGPU_TRY(radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter"));
-  CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSubCap * 16));
+  CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(kRadixP1) * nsub * subcap * 16));
   CRGPU_TRY(t.sub_count.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
-  CRGPU_TRY(t.table.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSlots * 16));
-  CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
   CRGPU_TRY(t.flag.ensure(4));
   CRGPU_HIP(hipMemsetAsync(t.flag.p, 0, 4, st));
-  CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
   {
     ProfScope prof("radix_build_split");
     hipLaunchKernelGGL(radix_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
                        t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
-                       t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>());
+                       t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>(), subcap);
     CRGPU_HIP(hipGetLastError());
   }
   uint32_t overflow = 0;
   CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
-  if (overflow) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
+  *ok = overflow == 0;
+  return CRGPU_OK;
+}
+
+crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok) {
+  hipStream_t st = stream();
+  *ok = false;
+  bool split_ok = false;
+  CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap));
+  if (!split_ok) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
+  const uint32_t nsub = 1u << t.sub_bits;
+  CRGPU_TRY(t.table.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSlots * 16));
+  CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
+  CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
+  uint32_t overflow = 0;
   {
     ProfScope prof("radix_build_table");
     hipLaunchKernelGGL(radix_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
