@@ -1159,9 +1159,9 @@ struct BulkArgs {
   uint8_t *key_present;
   unsigned long long *gword;
   unsigned int *ngroups;        // running group count (HBM)
-  unsigned int *failed;         // a sub-partition held more than kBulkGroups groups
+  unsigned int *failed;         // a sub-partition held more than gmax groups
   uint32_t g0;
-  uint32_t _pad;
+  uint32_t gmax;                // groups a sub-partition may hold (<= kBulkGroups; sized to the LDS the planes need)
 };
 __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
   extern __shared__ unsigned long long lds_words[];  // [nwords][kBulkGroups + 1] accumulators, then the seen planes
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
   __shared__ uint32_t rep[kBulkGroups];              // local group id -> representative row
   __shared__ uint32_t s_ngrp, s_base, s_claims;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
-  const uint32_t plane = kBulkGroups + 1;
+  const uint32_t plane = a.gmax + 1;
   uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
   const int q = blockIdx.x;
   const ulonglong2 *rows = a.rows + static_cast<int64_t>(q) * kBulkRows;
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
     }
   }
   __syncthreads();
-  if (s_claims > kBulkGroups) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
+  if (s_claims > a.gmax) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
     if (threadIdx.x == 0) atomicOr(a.failed, 1u);
     return;
   }
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       takem |= (slot_of[k] != kNone ? 1u : 0u) << k;
     }
     for (int f = 0; f < a.naggs; f++)
-      apply_rows_lds<kRows>(a.ops[f], val, takem, gr, kBulkGroups, plane, lds_words, lds_seen, rowi, 0ull);
+      apply_rows_lds<kRows>(a.ops[f], val, takem, gr, a.gmax, plane, lds_words, lds_seen, rowi, 0ull);
   }
   __syncthreads();
   // 4. append the groups: ids [base, base + ngrp), everything written with plain coalesced stores
@@ -2516,12 +2516,19 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   }
   if (nops > kMaxOpsPerLaunch) return CRGPU_OK;
   if (vcol >= 0 && (cols[vcol].valid != nullptr || (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0)) return CRGPU_OK;
-  lds = (static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen)) * (kBulkGroups + 1);
-  if (lds > kLdsMax - 32 * 1024) return CRGPU_OK;  // idx + rep take 27 KiB of static LDS
+  // accumulator planes: as many groups per sub-partition as fit beside the 27 KiB of static LDS (idx + rep); ~2048
+  // groups are expected for all-distinct keys, so anything below 2400 would fail too often
+  const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
+  if (bpg == 0) return CRGPU_OK;
+  size_t gmax = (kLdsMax - 32 * 1024) / bpg - 1;
+  if (gmax > kBulkGroups) gmax = kBulkGroups;
+  if (gmax < 2400) return CRGPU_OK;
+  lds = bpg * (gmax + 1);
   hipStream_t st = stream();
-  // high cardinality?  8192 keys sampled at a fixed stride: s^2 / 2G of them collide for G equally likely groups,
-  // so <= 8 duplicates means G >~ 4 M (fewer, larger groups overflow the sub-partition regions and are better
-  // served by the incremental paths anyway)
+  // high cardinality?  s = 8192 keys sampled at a fixed stride: about s^2 / 2G of them collide for G equally likely
+  // groups, so d duplicates mean ~2 d n / s^2 rows per group.  Up to ~32 rows per group the sub-partition regions hold
+  // (2048 rows expected, sigma = sqrt(2048 * 32) = 256, capacity 4096); fewer, larger groups are better served by the
+  // incremental paths anyway
   {
     const int kSample = 8192;
     std::vector<int64_t> sample(kSample);
@@ -2534,7 +2541,10 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     CRGPU_HIP(hipStreamSynchronize(st));
     std::sort(sample.begin(), sample.end());
     const int64_t distinct = std::unique(sample.begin(), sample.end()) - sample.begin();
-    if (kSample - distinct > 8) return CRGPU_OK;
+    int64_t dmax = 16 * (int64_t(kSample) * kSample) / n;
+    if (dmax < 8) dmax = 8;
+    if (dmax > kSample / 4) dmax = kSample / 4;
+    if (kSample - distinct > dmax) return CRGPU_OK;
   }
   RadixSrc src;
   std::memset(&src, 0, sizeof(src));
@@ -2576,6 +2586,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.ngroups = a->bulk_count.as<unsigned int>();
   b.failed = a->bulk_count.as<unsigned int>() + 1;
   b.g0 = 0;
+  b.gmax = static_cast<uint32_t>(gmax);
   const unsigned nsubs = static_cast<unsigned>(kRadixP1) << a->radix.sub_bits;
   {
     ProfScope prof("agg_bulk");

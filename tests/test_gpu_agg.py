@@ -211,3 +211,57 @@ def test_agg_full_size_invariants(ngroups):
     assert torch.equal(keys2[o2], uk) and torch.equal(sums2[o2], ref_sum) and torch.equal(cnts2[o2], cnts[order])
     assert torch.equal(mins2[o2], ref_min) and torch.equal(maxs2[o2], ref_max)
     a.close()
+
+
+def test_agg_bulk_path_then_more_input_vs_oracle(oracle):
+    """A fresh table fed >= 2^23 mostly distinct INT64 keys takes the bulk path (radix partition, grouping in LDS, no
+    hash index); the second, small input forces the index to be rebuilt from the groups' hash words and then goes
+    through the incremental path.  Everything is compared with the oracle on the concatenated input."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(21)
+    n1, n2 = 1 << 23, 150_000
+    base = rng.permutation(n1 // 2).astype(np.int64) * 1_000_003 - 7
+    k1 = np.concatenate([base, base])  # every key twice
+    rng.shuffle(k1)
+    k2 = np.concatenate([rng.choice(base, n2 // 2), np.arange(n2 // 2, dtype=np.int64) * 1_000_003 + 1])  # old and new keys
+    x = rng.integers(-10**9, 10**9, size=n1 + n2, dtype=np.int64)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1),
+            (F["COUNT"], 1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64], [0], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k1)), dev.upload(cd.Vec.from_numpy(cd.INT64, x[:n1]))], n1)
+    assert dev.prof_get("agg_bulk")[1] == 1, "the bulk path did not run"
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k2)), dev.upload(cd.Vec.from_numpy(cd.INT64, x[n1:]))], n2)
+    dev.prof_enable(False)
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    want = oracle.hash_agg([cd.Vec.from_numpy(cd.INT64, np.concatenate([k1, k2])), cd.Vec.from_numpy(cd.INT64, x)], [0], aggs)
+    assert np.array_equal(_canon(got), _canon(want))
+
+
+def test_agg_bulk_path_float_values_and_fallback(oracle):
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(22)
+    n = 1 << 23
+    k = rng.permutation(n).astype(np.int64) - n // 2
+    v = rng.integers(-1000, 1000, size=n).astype(np.float64)  # integer-valued: sums are exact in any order
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM"], 1, -1), (F["AVG"], 1, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1),
+            (F["COUNT_ROWS"], -1, -1)]
+    cols = [cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.FLOAT64, v)]
+    dev.prof_enable(True)
+    dev.prof_reset()
+    got = G.gpu_agg(cols, [0], aggs)
+    assert dev.prof_get("agg_bulk")[1] == 1
+    assert np.array_equal(_canon(got), _canon(oracle.hash_agg(cols, [0], aggs)))
+    # a hot key hidden from the 8192-key sample (stride n / 8192) makes its sub-partition overflow after the sample
+    # looked distinct: the bulk attempt is abandoned and the incremental path produces the result
+    k2 = k.copy()
+    hot = np.arange(n) % 1024 == 1
+    k2[hot] = 123456789
+    cols2 = [cd.Vec.from_numpy(cd.INT64, k2), cd.Vec.from_numpy(cd.FLOAT64, v)]
+    dev.prof_reset()
+    got2 = G.gpu_agg(cols2, [0], aggs)
+    assert dev.prof_get("radix_build_split")[1] == 1 and dev.prof_get("agg_bulk")[1] == 0, "expected an abandoned bulk attempt"
+    dev.prof_enable(False)
+    assert np.array_equal(_canon(got2), _canon(oracle.hash_agg(cols2, [0], aggs)))
