@@ -2529,15 +2529,14 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   // groups, so d duplicates mean ~2 d n / s^2 rows per group.  Up to ~32 rows per group the sub-partition regions hold
   // (2048 rows expected, sigma = sqrt(2048 * 32) = 256, capacity 4096); fewer, larger groups are better served by the
   // incremental paths anyway
-  {
-    const int kSample = 8192;
+  for (const int kSample : {512, 8192}) {  // the small sample rejects low-cardinality inputs for ~30 us
     std::vector<int64_t> sample(kSample);
     const int64_t stride = n / kSample;
-    CRGPU_TRY(a->scratch.ensure(kSample * 8));
+    CRGPU_TRY(a->scratch.ensure(static_cast<size_t>(kSample) * 8));
     hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), stride,
                        kSample, a->scratch.as<long long>());
     CRGPU_HIP(hipGetLastError());
-    CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, kSample * 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, static_cast<size_t>(kSample) * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     std::sort(sample.begin(), sample.end());
     const int64_t distinct = std::unique(sample.begin(), sample.end()) - sample.begin();
