@@ -221,6 +221,7 @@ def test_agg_bulk_path_then_more_input_vs_oracle(oracle):
     rng = np.random.default_rng(21)
     n1, n2 = 1 << 23, 150_000
     base = rng.permutation(n1 // 2).astype(np.int64) * 1_000_003 - 7
+    base[:4] = [-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]  # -1 is the radix kernels' empty-slot marker
     k1 = np.concatenate([base, base])  # every key twice
     rng.shuffle(k1)
     k2 = np.concatenate([rng.choice(base, n2 // 2), np.arange(n2 // 2, dtype=np.int64) * 1_000_003 + 1])  # old and new keys
