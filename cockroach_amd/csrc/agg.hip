@@ -1141,14 +1141,14 @@ __global__ __launch_bounds__(1024) void agg_part_accum_kernel(PartAccArgs a) {
 // A fresh table fed one large input of mostly distinct keys would pay one random HBM CAS (~10 G/s with the
 // returned value) plus a random 8-byte write per row in find-or-insert.  When the shape allows it (one INT64 key
 // column and at most one 8-byte value column, no NULLs, no FILTER) the rows are instead radix-partitioned by key
-// hash with the join's build-side kernels (radix.hip: 1024 partitions, then <= 64 sub-partitions of <= 2560 rows)
+// hash with the join's build-side kernels (radix.hip: 1024 partitions, then <= 128 sub-partitions of ~1024 rows)
 // and every sub-partition is grouped and aggregated ENTIRELY IN LDS by one workgroup: equal keys share a
 // sub-partition, so its groups are final and are appended to the per-group arrays (one HBM atomic per workgroup
 // reserves their group ids).  The hash index is not touched; it is rebuilt from the hash words if more input follows.
-static constexpr int kBulkSlots = 4096;       // LDS index of one sub-partition
-static constexpr uint32_t kBulkRows = 4096;   // rows a sub-partition may hold (region size of the split; 8192 made the
+static constexpr int kBulkSlots = 2048;       // LDS index of one sub-partition
+static constexpr uint32_t kBulkRows = 2048;   // rows a sub-partition may hold (region size of the split; 8192 made the
                                               // kernel 1.5x slower: 8 rows per thread and twice the region traffic)
-static constexpr uint32_t kBulkGroups = 2816; // groups a sub-partition may hold (LDS accumulator planes)
+static constexpr uint32_t kBulkGroups = 1536; // groups a sub-partition may hold (LDS accumulator planes)
 struct BulkArgs {
   const ulonglong2 *rows;       // {key, value} rows, kBulkRows per sub-partition
   const uint32_t *sub_count;
@@ -2522,13 +2522,14 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   }
   if (nops > kMaxOpsPerLaunch) return CRGPU_OK;
   if (vcol >= 0 && (cols[vcol].valid != nullptr || (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0)) return CRGPU_OK;
-  // accumulator planes: as many groups per sub-partition as fit beside the 27 KiB of static LDS (idx + rep); ~2048
-  // groups are expected for all-distinct keys, so anything below 2400 would fail too often
+  // accumulator planes: as many groups per sub-partition as fit beside the 14 KiB of static LDS (idx + rep); ~1024
+  // groups are expected for all-distinct keys, so anything below 1280 would fail too often
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0) return CRGPU_OK;
-  size_t gmax = (kLdsMax - 32 * 1024) / bpg - 1;
+  size_t gmax = (kLdsMax / 2 - 15 * 1024) / bpg - 1;  // two workgroups per CU
+  if (gmax < 1280) gmax = (kLdsMax - 15 * 1024) / bpg - 1;  // wide accumulator sets: one workgroup per CU
   if (gmax > kBulkGroups) gmax = kBulkGroups;
-  if (gmax < 2400) return CRGPU_OK;
+  if (gmax < 1280) return CRGPU_OK;
   lds = bpg * (gmax + 1);
   hipStream_t st = stream();
   // high cardinality?  s = 8192 keys sampled at a fixed stride: about s^2 / 2G of them collide for G equally likely
@@ -2558,7 +2559,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   src.pay_width = vcol >= 0 ? 8 : 0;
   src.fast = vcol >= 0 ? 1 : 0;
   bool ok = false;
-  CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows));
+  CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
   if (!ok) return CRGPU_OK;  // a sub-partition overflowed: many rows per key after all
   CRGPU_TRY(ensure_groups(a, static_cast<size_t>(n)));
   CRGPU_TRY(upload_descriptors(a, &cols));

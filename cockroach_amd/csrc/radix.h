@@ -15,7 +15,7 @@
 namespace crgpu {
 
 static constexpr int kRadixP1 = 1024;        // level-1 partitions: hash bits 54..63
-static constexpr int kRadixMaxSubBits = 6;   // level-2 sub-partitions per partition: hash bits 48..53
+static constexpr int kRadixMaxSubBits = 6;   // level-2 sub-partitions per partition: hash bits from 47 up (47..52 for the join; a caller may ask for 7: 47..53)
 static constexpr int kRadixSlots = 3072;     // slots of one sub-partition's table (48 KiB, built in LDS)
 static constexpr int kRadixSubCap = 2560;    // rows one sub-partition may hold (load factor <= 0.83; ~0.67 typical)
 static constexpr unsigned long long kRadixEmpty = 0xFFFFFFFFFFFFFFFFull;
@@ -66,7 +66,9 @@ struct RadixTable {
 // Levels 1 and 2 only (hash aggregation of high-cardinality inputs reuses them): t.rows_b holds the rows of
 // sub-partition q in [q * subcap, q * subcap + sub_count[q]), q < kRadixP1 << t.sub_bits.
 // *ok = false when a sub-partition overflowed its region of `subcap` rows.
-crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap);
+// About 2^log2_rows_per_sub rows per sub-partition, at most 2^max_sub_bits (<= 7) sub-partitions per partition.
+crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,
+                                   int max_sub_bits);
 // Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows
 // kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
 crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok);

@@ -22,7 +22,7 @@ namespace crgpu {
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t rpart(uint64_t h) { return static_cast<uint32_t>(h >> 54); }
-__device__ __forceinline__ uint32_t rsub(uint64_t h, uint32_t smask) { return static_cast<uint32_t>(h >> 48) & smask; }
+__device__ __forceinline__ uint32_t rsub(uint64_t h, uint32_t smask) { return static_cast<uint32_t>(h >> 47) & smask; }
 // The three candidate slots of a key inside its sub-partition's table (3-way cuckoo hashing):
 // 32-bit hash fields scaled to [0, kRadixSlots).
 __device__ __forceinline__ uint32_t rscale(uint32_t x) {
@@ -256,8 +256,9 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
   const int p = blockIdx.x;
   const uint32_t nsub = smask + 1;
   __shared__ ulonglong2 stage[TILE];
-  __shared__ uint32_t tcnt[64], tstart[64], cur[64];
-  if (threadIdx.x < 64) tcnt[threadIdx.x] = 0, cur[threadIdx.x] = 0;
+  __shared__ uint32_t tcnt[128], tstart[128], cur[128];  // up to 128 sub-partitions (the join uses <= 64)
+  __shared__ uint32_t s_half;
+  if (threadIdx.x < 128) tcnt[threadIdx.x] = 0, cur[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t s0 = starts[p], n = totals[p];
   ulonglong2 *obase = out + static_cast<int64_t>(p) * nsub * subcap;
@@ -275,10 +276,14 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
       }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 128) {  // two waves scan 64 counters each; the second half is shifted by the first half's total
       const uint32_t c = tcnt[threadIdx.x];
-      tstart[threadIdx.x] = wave_incl_scan_u32(c) - c;
+      const uint32_t incl = wave_incl_scan_u32(c);
+      tstart[threadIdx.x] = incl - c;
+      if (threadIdx.x == 63) s_half = incl;
     }
+    __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 128) tstart[threadIdx.x] += s_half;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ROWS; j++)
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
       if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 128) {
       cur[threadIdx.x] += tcnt[threadIdx.x];
       tcnt[threadIdx.x] = 0;
     }
@@ -612,16 +617,17 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
 
 // Levels 1 and 2: t.rows_b holds the rows of sub-partition q in [q * subcap, q * subcap + sub_count[q]).
 // *ok = false when a sub-partition overflowed its region (too many rows share hash bits: duplicate-heavy input).
-crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap) {
+crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,
+                                   int max_sub_bits) {
   hipStream_t st = stream();
   *ok = false;
   t.ready = false;
   t.n = n;
   int lg = 0;
   while ((int64_t(1) << lg) < n) lg++;
-  int sb = lg - 21;  // ~2048 rows per sub-partition
+  int sb = lg - 10 - log2_rows_per_sub;  // 1024 level-1 partitions, then ~2^log2_rows_per_sub rows per sub-partition
   if (sb < 0) sb = 0;
-  if (sb > kRadixMaxSubBits) sb = kRadixMaxSubBits;
+  if (sb > max_sub_bits) sb = max_sub_bits;
   t.sub_bits = sb;
   const uint32_t nsub = 1u << sb;
   CRGPU_TRY(radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter"));
@@ -647,7 +653,7 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   hipStream_t st = stream();
   *ok = false;
   bool split_ok = false;
-  CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap));
+  CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap, 11, kRadixMaxSubBits));
   if (!split_ok) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
   const uint32_t nsub = 1u << t.sub_bits;
   CRGPU_TRY(t.table.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSlots * 16));
