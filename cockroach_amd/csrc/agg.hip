@@ -1633,6 +1633,20 @@ __global__ __launch_bounds__(256) void agg_finalize_kernel(FinalArgs a) {
   }
 }
 
+// SUM_INT whose low word is handed out in place (see crgpu_dev_agg_finish): only the range check remains
+__global__ __launch_bounds__(256) void agg_sum_check_kernel(const unsigned long long *__restrict__ lo,
+                                                            const unsigned long long *__restrict__ hi,
+                                                            const uint8_t *__restrict__ seen, int64_t ngroups,
+                                                            unsigned int *__restrict__ err) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  bool bad = false;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < ngroups; s += stride) {
+    const unsigned long long want_hi = (lo[s] >> 63) ? ~0ull : 0ull;
+    bad |= seen[s] && hi[s] != want_hi;
+  }
+  if (bad) *err = 1;
+}
+
 // BYTES outputs (ANY_NOT_NULL of a BYTES group key or column): lengths -> offsets -> payload copy
 __global__ __launch_bounds__(256) void bytes_view_kernel(const uint32_t *__restrict__ len, const uint8_t *__restrict__ present_in,
                                                          bool any_row, const unsigned long long *__restrict__ w0,
@@ -2660,6 +2674,27 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
   return CRGPU_OK;
 }
 
+// Output columns that need no finalisation pass: the accumulator word (or the stored group key) of group g already is
+// the value of output row g.  Below kAliasMinGroups the copy costs nothing and keeps the result independent of the
+// handle's arrays.
+static constexpr int64_t kAliasMinGroups = int64_t(1) << 16;
+static bool alias_source(crgpu_agg *a, const AggOpHost &op, const AggOpDev &dev, const void **data, const uint8_t **present) {
+  switch (op.kind) {
+    case ACC_COUNT_ROWS:
+    case ACC_COUNT: *data = dev.w0; *present = nullptr; return true;
+    case ACC_SUM_F64:
+    case ACC_SUM_I128:
+    case ACC_MIN_I64:
+    case ACC_MAX_I64: *data = dev.w0; *present = dev.seen; return true;
+    case ACC_ANY_KEY:
+      if (type_width(a->types[a->group_cols[op.key_idx]]) != 8) return false;
+      *data = a->ks[op.key_idx].data.p;
+      *present = a->ks[op.key_idx].present.as<uint8_t>();
+      return true;
+    default: return false;
+  }
+}
+
 extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res) {
   if (a == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_finish: null argument");
   hipStream_t st = stream();
@@ -2670,6 +2705,8 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
   std::vector<AggOpDev> ops(a->ops.size());
   CRGPU_HIP(hipMemcpyAsync(ops.data(), a->ops_dev.p, sizeof(AggOpDev) * ops.size(), hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
+  std::vector<const void *> alias(a->ops.size(), nullptr);
+  const uint8_t *alias_present = nullptr;
   for (size_t f = 0; f < a->ops.size(); f++) {
     AggOpHost &op = a->ops[f];
     OutCol &o = a->out[f];
@@ -2702,6 +2739,20 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
                            o.offsets.as<uint32_t>(), o.data.as<uint8_t>());
         CRGPU_HIP(hipGetLastError());
       }
+    } else if (ng >= kAliasMinGroups && type_width(op.out_type) == 8 && alias_source(a, op, ops[f], &alias[f], &alias_present)) {
+      // the per-group array already IS the output column (group g is row g): hand it out in place and only build the
+      // validity bitmap; values under a NULL are unspecified (as in the reference's vectors)
+      if (op.kind == ACC_SUM_I128) {
+        hipLaunchKernelGGL(agg_sum_check_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, ops[f].w0, ops[f].w1, ops[f].seen, ng,
+                           a->err_dev.as<unsigned int>());
+        CRGPU_HIP(hipGetLastError());
+      }
+      if (alias_present == nullptr) {
+        CRGPU_HIP(hipMemsetAsync(o.valid.p, 0xFF, static_cast<size_t>((ng + 7) / 8), st));
+      } else {
+        CRGPU_TRY(pack_bitmap(alias_present, ng, o.valid.as<uint8_t>()));
+      }
+      continue;
     } else {
       CRGPU_TRY(o.data.ensure(static_cast<size_t>(ng > 0 ? ng : 1) * type_width(op.out_type)));
       if (ng > 0) {
@@ -2727,7 +2778,10 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
   CRGPU_HIP(hipMemcpyAsync(&err, a->err_dev.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
   if (err) return fail(CRGPU_ERR_INT_OUT_OF_RANGE, "integer out of range");  // tree.ErrIntOutOfRange
-  for (size_t f = 0; f < a->out.size(); f++) a->views[f] = a->out[f].view();
+  for (size_t f = 0; f < a->out.size(); f++) {
+    a->views[f] = a->out[f].view();
+    if (alias[f] != nullptr) a->views[f].data = alias[f];
+  }
   res->n = ng;
   res->ncols = static_cast<int32_t>(a->out.size());
   res->_pad = 0;

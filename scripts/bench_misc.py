@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""The sub-measurements SURVEY.md 8(d) asks for beside the headline join: hash-only (colexechash.rehash), build-only
+(config J build side), HashRouter repartition (TupleHashDistributor + per-output copies) and the config G variants
+(SUM_INT + COUNT_ROWS over all-distinct int64 keys, each key 4x, 16-byte BYTES keys).  Inputs resident in HBM; each
+line carries the single-threaded CPU port timed on a bounded sample of the same input.  One JSON line per case."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cockroach_amd import _lib, coldata as cd, device as dev  # noqa: E402
+
+CPU_SAMPLE = 1 << 22
+MIX = 0x9E3779B97F4A7C15 - (1 << 64)  # odd multiplier: k -> k * MIX is a bijection of the int64 values
+
+
+def _sync():
+    torch.cuda.synchronize()
+    _lib.load().crgpu_dev_synchronize()
+
+
+def _timed(fn, reps):
+    fn()
+    _sync()
+    dev.prof_enable(True); dev.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    _lib.load().crgpu_dev_synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def _kernels(names, reps):
+    out = {}
+    for k in names:
+        ms, cnt = dev.prof_get(k)
+        if cnt:
+            out[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
+    return out
+
+
+def _line(case, rows, dt, alg_bytes, kernels, cpu):
+    return {"case": case, "rows": rows, "ms": dt * 1e3, "rows_per_s": rows / dt, "alg_GBps": alg_bytes / dt / 1e9,
+            "frac_of_8TBps": alg_bytes / dt / 8e12, "kernels": kernels, "cpu_baseline": cpu}
+
+
+def _cpu(fn, m, what):
+    if not CPU_SAMPLE:
+        return None
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "rows/s", "cores": 1, "kind": "port", "sample": f"first {m} rows of the same input ({what}, 1 thread)"}
+
+
+def bench_hash(lg, reps, dv, g):
+    n = 1 << lg
+    k = torch.randint(-2**62, 2**62, (n,), generator=g, device=dv, dtype=torch.int64)
+    out = torch.empty(n, device=dv, dtype=torch.int64)
+    col = dev.from_torch(cd.INT64, k)
+    arr = dev.dcol_array([col])
+    lib = _lib.load()
+
+    def go():
+        _lib.check(lib.crgpu_dev_hash_cols(arr, 1, n, 1, 64, 0, C.c_void_p(out.data_ptr())))
+    dt = _timed(go, reps)
+    kern = _kernels(["hash"], reps)
+    m = min(n, CPU_SAMPLE)
+    cpu = None
+    if CPU_SAMPLE:
+        from oracle import oracle as O  # test infrastructure: the reported CPU baseline only
+        hv = cd.Vec.from_numpy(cd.INT64, k[:m].cpu().numpy())
+        cpu = _cpu(lambda: O.hash_cols([hv], width=64), m, "oracle rehash restatement")
+    return _line(f"hash only: rehash of one int64 column, 64-bit running hash, 2^{lg} rows", n, dt, n * 16.0, kern, cpu)
+
+
+def bench_build(lg, reps, dv, g):
+    n = 1 << lg
+    k = torch.randperm(n, generator=g, device=dv, dtype=torch.int64)
+    v = k * 3 + 1
+    cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, v)]
+    j = dev.Join(0, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], True, out_cols=[1, 3])
+
+    def go():
+        j.reset()
+        j.build(cols, n)
+    dt = _timed(go, reps)
+    kern = _kernels(["radix_build_hist", "radix_build_scatter", "radix_build_split", "radix_build_table", "join_build"], reps)
+    j.close()
+    return _line(f"build only: config J build side, 2^{lg} unique int64 keys + int64 payload", n, dt, n * 16.0, kern, None)
+
+
+def bench_router(lg, reps, dv, g, outputs):
+    n = 1 << lg
+    k = torch.randint(0, 1 << 40, (n,), generator=g, device=dv, dtype=torch.int64)
+    w = torch.arange(n, device=dv, dtype=torch.int64)
+    cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, w)]
+    p = dev.Partitioner([cd.INT64, cd.INT64], [0], outputs)
+    counts = [None]
+
+    def go():
+        _res, counts[0] = p.partition(cols, n)
+    dt = _timed(go, reps)
+    kern = _kernels(["partition"], reps)
+    assert int(counts[0].sum()) == n
+    m = min(n, CPU_SAMPLE)
+    cpu = None
+    if CPU_SAMPLE:
+        from oracle import oracle as O
+        hv = [cd.Vec.from_numpy(cd.INT64, k[:m].cpu().numpy()), cd.Vec.from_numpy(cd.INT64, w[:m].cpu().numpy())]
+        cpu = _cpu(lambda: O.distribute(hv, [0], outputs), m, "oracle TupleHashDistributor restatement, selection vectors only")
+    p.close()
+    return _line(f"router repartition: (int64 key, int64 payload) into {outputs} outputs, 2^{lg} rows", n, dt, n * 32.0, kern, cpu)
+
+
+AGG_KERNELS = ["agg_fused_lds", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
+               "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "radix_build_hist",
+               "radix_build_scatter", "radix_build_split"]
+
+
+def _agg(case, cols, types, aggs, n, alg_bytes, reps, expect):
+    a = dev.Agg(types, [0], aggs)
+    ng = [0]
+
+    def go():
+        a.reset()
+        a.consume(cols, n)
+        ng[0] = int(a.finish().n)
+    dt = _timed(go, reps)
+    kern = _kernels(AGG_KERNELS, reps)
+    if ng[0] != expect:
+        raise SystemExit(f"{case}: {ng[0]} groups, expected {expect}")
+    cpu = None
+    if CPU_SAMPLE:
+        from oracle import oracle as O
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from bench_agg import to_host_vec
+        m = min(n, CPU_SAMPLE)
+        host = [to_host_vec(c, m) for c in cols]
+        cpu = _cpu(lambda: O.hash_agg(host, [0], aggs), m, "oracle hashAggregator restatement")
+    a.close()
+    r = _line(case, n, dt, alg_bytes, kern, cpu)
+    r["groups"] = ng[0]
+    return r
+
+
+def bench_config_g(lg, reps, dv, g, which):
+    n = 1 << lg
+    aggs = [(0, 0, -1), (11, 1, -1), (14, -1, -1)]  # ANY_NOT_NULL(k), SUM_INT(x), COUNT_ROWS
+    x = torch.randint(-1000, 1000, (n,), generator=g, device=dv, dtype=torch.int64)
+    if which == "distinct":
+        k = torch.randperm(n, generator=g, device=dv, dtype=torch.int64) * MIX
+        cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)]
+        return _agg(f"config G: 2^{lg} rows, all keys distinct, SUM_INT + COUNT_ROWS", cols, [cd.INT64, cd.INT64], aggs, n,
+                    n * 16.0 + n * 24.0, reps, n)
+    if which == "x4":
+        k = (torch.randperm(n, generator=g, device=dv, dtype=torch.int64) >> 2) * MIX
+        cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)]
+        return _agg(f"config G: 2^{lg} rows, each key 4x, SUM_INT + COUNT_ROWS", cols, [cd.INT64, cd.INT64], aggs, n,
+                    n * 16.0 + (n // 4) * 24.0, reps, n // 4)
+    # 16-byte BYTES keys: lowercase hex of the (distinct) key
+    k = torch.randperm(n, generator=g, device=dv, dtype=torch.int64) * MIX
+    hexd = torch.tensor(list(b"0123456789abcdef"), device=dv, dtype=torch.uint8)
+    data = torch.empty((n, 16), device=dv, dtype=torch.uint8)
+    for d in range(16):
+        data[:, d] = hexd[((k >> (60 - 4 * d)) & 15)]
+    del k
+    offs = torch.arange(n + 1, device=dv, dtype=torch.int32) * 16
+    cols = [dev.from_torch(cd.BYTES, data.reshape(-1), offsets=offs), dev.from_torch(cd.INT64, x)]
+    return _agg(f"config G: 2^{lg} rows, distinct 16-byte BYTES keys (hex), SUM_INT + COUNT_ROWS", cols, [cd.BYTES, cd.INT64], aggs, n,
+                n * 28.0 + n * 36.0, reps, n)
+
+
+def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_rows=27, lg_bytes=26):
+    global CPU_SAMPLE
+    if cpu_sample is not None:
+        CPU_SAMPLE = cpu_sample
+    _lib.check(_lib.load().crgpu_init(device_index))
+    dv = torch.device("cuda", device_index)
+    g = torch.Generator(device=dv); g.manual_seed(7)
+    want = lambda name: only is None or name in only  # noqa: E731
+    if want("hash"):
+        yield bench_hash(lg_hash, reps, dv, g)
+    if want("build"):
+        yield bench_build(lg_rows, reps, dv, g)
+    if want("router"):
+        yield bench_router(lg_rows, reps, dv, g, 8)
+    if want("g_distinct"):
+        yield bench_config_g(lg_rows, reps, dv, g, "distinct")
+    if want("g_x4"):
+        yield bench_config_g(lg_rows, reps, dv, g, "x4")
+    if want("g_bytes"):
+        yield bench_config_g(lg_bytes, reps, dv, g, "bytes")
+
+
+def main():
+    only = sys.argv[1].split(",") if len(sys.argv) > 1 and sys.argv[1] != "all" else None
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    cpu_sample = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    for r in measure(only, reps, cpu_sample):
+        print(json.dumps(r), flush=True)
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,41 @@ def test_agg_sum_int_overflow_and_empty(oracle):
     assert len(out[0]) == 0  # hash_aggregator_tmpl.go:229-239
 
 
+def test_agg_many_groups_outputs_in_place(oracle):
+    """From 2^16 groups on, finish hands out the accumulator arrays themselves for outputs that need no finalisation
+    (counts, INT64 MIN/MAX, SUM_INT low word, FLOAT64 SUM, 8-byte group keys): NULL results, the SUM_INT range check
+    and a second finish after more input must behave as with the copying path."""
+    from cockroach_amd import _lib, device as dev
+    rng = np.random.default_rng(77)
+    n, ng = 400_000, 100_000
+    k = rng.integers(0, ng, size=n, dtype=np.int64)
+    x = rng.integers(-10**15, 10**15, size=n, dtype=np.int64)
+    xf = rng.integers(-1000, 1000, size=n).astype(np.float64)
+    cols = [cd.Vec.from_numpy(cd.INT64, k, rng.random(n) > 0.01), cd.Vec.from_numpy(cd.INT64, x, rng.random(n) > 0.6),
+            cd.Vec.from_numpy(cd.FLOAT64, xf, rng.random(n) > 0.6)]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1), (F["COUNT"], 1, -1),
+            (F["COUNT_ROWS"], -1, -1), (F["SUM"], 2, -1), (F["AVG"], 2, -1)]
+    a = dev.Agg([v.type for v in cols], [0], aggs)
+    half = n // 2
+    a.consume([dev.upload(v.slice(0, half)) for v in cols], half)
+    got = dev.result_to_vecs(a.finish())
+    assert np.array_equal(_canon(got), _canon(oracle.hash_agg([v.slice(0, half) for v in cols], [0], aggs)))
+    a.consume([dev.upload(v.slice(half, n)) for v in cols], n - half)
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    want = oracle.hash_agg(cols, [0], aggs)
+    assert any(not v.present().all() for v in want[1:4]), "the case should contain NULL results"
+    assert np.array_equal(_canon(got), _canon(want))
+    # one group out of 2^17 exceeds int64
+    k2 = np.arange(1 << 17, dtype=np.int64)
+    x2 = np.ones(1 << 17, dtype=np.int64)
+    k2 = np.concatenate([k2, [99_999, 99_999]])
+    x2 = np.concatenate([x2, [2**63 - 1, 2**63 - 1]]).astype(np.int64)
+    with pytest.raises(_lib.CrgpuError) as e:
+        G.gpu_agg([cd.Vec.from_numpy(cd.INT64, k2), cd.Vec.from_numpy(cd.INT64, x2)], [0], [(F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)])
+    assert e.value.code == _lib.ERR_INT_OUT_OF_RANGE
+
+
 def test_agg_all_distinct_keys_growth():
     """Config G shape scaled down: every key distinct => the table grows repeatedly."""
     n = 1_500_000
