@@ -288,7 +288,8 @@ def main():
 def other_paths(device_index):
     """Hash aggregation (Q1 shape, 1024 groups, all-distinct = config G shape; 2^27 rows) and KV fetch decode
     (lineitem-shaped rows, 10 MiB batch responses), inputs resident in HBM, each with the single-threaded CPU port
-    timed on a bounded sample.  scripts/bench_agg.py and scripts/bench_decode.py are the standalone forms."""
+    timed on a bounded sample; then SURVEY.md 8(d)'s sub-measurements: hash only, build only, the router's repartition
+    and the config G variants.  scripts/bench_agg.py, bench_decode.py and bench_misc.py are the standalone forms."""
     import importlib.util
 
     def load(name):
@@ -306,6 +307,12 @@ def other_paths(device_index):
         dec = load("bench_decode").measure(1 << 21, 4, 10 << 20, device_index)
         out["kv_fetch_decode"] = {k: dec[k] for k in ("rows", "input_bytes", "wall_ms", "kv_walk_ms", "kv_decode_ms", "rows_per_s",
                                                       "input_GBps_wall", "cpu_baseline")}
+        import torch
+        torch.cuda.empty_cache()
+        misc = load("bench_misc")
+        out["sub_kernels_and_variants"] = [
+            {k: r[k] for k in ("case", "rows", "ms", "rows_per_s", "frac_of_8TBps", "kernels", "cpu_baseline")}
+            for r in misc.measure(None, reps=3, cpu_sample=1 << 21, device_index=device_index)]
     except Exception as e:  # the join line must not be lost to a failure in the side measurements
         out["error"] = repr(e)
     return out

@@ -146,10 +146,15 @@ __device__ inline RowHash agg_hash(const KeyCols &k, int64_t row) {
     if (x.type == CRGPU_BYTES) {
       const uint32_t a0 = x.offsets[row], len = x.offsets[row + 1] - a0;
       const uint8_t *p = reinterpret_cast<const uint8_t *>(x.data) + a0;
-      for (uint32_t t = 0; t < len; t += 8) {
-        const uint32_t kk = len - t < 8 ? len - t : 8;
+      uint32_t t = 0;
+      for (; t + 8 <= len; t += 8) {  // unaligned 8-byte loads (little endian: same word as the byte loop below builds)
+        uint64_t w;
+        __builtin_memcpy(&w, p + t, 8);
+        h = hash_step(h, w);
+      }
+      if (t < len) {
         uint64_t w = 0;
-        for (uint32_t j = 0; j < kk; j++) w |= static_cast<uint64_t>(p[t + j]) << (8 * j);
+        for (uint32_t j = 0; t + j < len; j++) w |= static_cast<uint64_t>(p[t + j]) << (8 * j);
         h = hash_step(h, w);
       }
       h = hash_step(h, 0xB17E5ull + len);
@@ -1481,42 +1486,117 @@ struct FixupArgs {
   unsigned long long *any_tails;
   unsigned long long seq_base;
 };
+// Per-lane byte copy with unaligned 8-byte accesses (global memory allows them), bytes for the tail.
+__device__ __forceinline__ void copy_bytes_lane(uint8_t *dst, const uint8_t *src, uint32_t len) {
+  uint32_t t = 0;
+  for (; t + 8 <= len; t += 8) {
+    unsigned long long v;
+    __builtin_memcpy(&v, src + t, 8);
+    __builtin_memcpy(dst + t, &v, 8);
+  }
+  for (; t < len; t++) dst[t] = src[t];
+}
+
+// Exclusive scan of `v` over the workgroup (256 threads) + one atomicAdd of the total on *tail by thread 0: returns
+// tail_before + (sum of v over lower threads).  A same-address HBM atomic costs ~10 ns, so the key bytes of new groups
+// are reserved once per workgroup pass, not per group or wave; the groups' payloads also end up adjacent in gid order.
+__device__ __forceinline__ unsigned long long block_reserve(uint32_t v, unsigned long long *tail, uint32_t *s_wave,
+                                                            unsigned long long *s_base) {
+  const uint32_t incl = wave_incl_scan_u32(v);
+  const uint32_t w = threadIdx.x >> 6;
+  if (lane_id() == 63) s_wave[w] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t i = 0; i < (blockDim.x >> 6); i++) {
+      const uint32_t c = s_wave[i];
+      s_wave[i] = tot;
+      tot += c;
+    }
+    *s_base = tot ? atomicAdd(tail, static_cast<unsigned long long>(tot)) : 0ull;
+  }
+  __syncthreads();
+  const unsigned long long off = *s_base + s_wave[w] + (incl - v);
+  __syncthreads();  // s_wave / s_base are reused by the next column
+  return off;
+}
+
+static constexpr int kFixupGroups = 1;  // new groups per thread and pass (4 measured slower: 5.3 vs 4.6 ms per 2^26 groups with
+                                        // 16-byte keys; the reservation atomics are not what bounds the kernel)
 __global__ __launch_bounds__(256) void agg_fixup_kernel(FixupArgs a) {
+  __shared__ uint32_t s_wave[4];
+  __shared__ unsigned long long s_base;
   const KeyStore &st = a.store;
-  const unsigned int stride = gridDim.x * blockDim.x;
-  for (unsigned int p = blockIdx.x * blockDim.x + threadIdx.x; p < a.nnew; p += stride) {
-    const uint32_t gid = a.g0 + p;
-    const uint32_t pos = a.rep_pos[p];
-    const int64_t row = a.list != nullptr ? static_cast<int64_t>(a.list[pos]) : static_cast<int64_t>(pos);
+  const unsigned int per_pass = 256 * kFixupGroups;
+  const unsigned int npass = (a.nnew + per_pass - 1) / per_pass;
+  for (unsigned int pass = blockIdx.x; pass < npass; pass += gridDim.x) {  // uniform per workgroup (block_reserve syncs)
+    unsigned int p[kFixupGroups];
+    int64_t row[kFixupGroups];
+    bool active[kFixupGroups];
+#pragma unroll
+    for (int j = 0; j < kFixupGroups; j++) {
+      p[j] = pass * per_pass + j * 256 + threadIdx.x;
+      active[j] = p[j] < a.nnew;
+      const uint32_t pos = active[j] ? a.rep_pos[p[j]] : 0;
+      row[j] = !active[j] ? 0 : a.list != nullptr ? static_cast<int64_t>(a.list[pos]) : static_cast<int64_t>(pos);
+    }
     for (int c = 0; c < a.keys.n; c++) {
       const DCol &x = a.keys.c[c];
       const KeyStoreCol &s = st.c[c];
-      const bool isnull = col_is_null(x, row);
-      s.present[gid] = isnull ? 0 : 1;
-      switch (x.type) {
-        case CRGPU_BOOL: s.data[gid] = isnull ? 0 : static_cast<uint8_t>(col_get_bool(x, row)); break;
-        case CRGPU_INT16: reinterpret_cast<int16_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int16_t *>(x.data)[row]; break;
-        case CRGPU_INT32: reinterpret_cast<int32_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int32_t *>(x.data)[row]; break;
-        case CRGPU_INT64: reinterpret_cast<int64_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int64_t *>(x.data)[row]; break;
-        case CRGPU_FLOAT64: reinterpret_cast<double *>(s.data)[gid] = isnull ? 0.0 : col_get_f64(x, row); break;
-        case CRGPU_BYTES: {
-          uint32_t a0 = x.offsets[row], len = isnull ? 0 : x.offsets[row + 1] - a0;
-          unsigned long long off = len ? atomicAdd(&a.b_tails[c], static_cast<unsigned long long>(len)) : 0ull;
-          s.b_off[gid] = off;
-          s.b_len[gid] = len;
-          const uint8_t *src = reinterpret_cast<const uint8_t *>(x.data) + a0;
-          for (uint32_t t = 0; t < len; t++) s.b_buf[off + t] = src[t];
-          break;
+      if (x.type == CRGPU_BYTES) {
+        uint32_t a0[kFixupGroups], len[kFixupGroups], sum = 0;
+        bool isnull[kFixupGroups];
+#pragma unroll
+        for (int j = 0; j < kFixupGroups; j++) {
+          a0[j] = 0;
+          len[j] = 0;
+          isnull[j] = true;
+          if (active[j]) {
+            isnull[j] = col_is_null(x, row[j]);
+            a0[j] = x.offsets[row[j]];
+            len[j] = isnull[j] ? 0 : x.offsets[row[j] + 1] - a0[j];
+          }
+          sum += len[j];
         }
-        default: break;
+        unsigned long long off = block_reserve(sum, &a.b_tails[c], s_wave, &s_base);
+#pragma unroll
+        for (int j = 0; j < kFixupGroups; j++) {
+          if (!active[j]) continue;
+          const uint32_t gid = a.g0 + p[j];
+          s.present[gid] = isnull[j] ? 0 : 1;
+          s.b_off[gid] = len[j] ? off : 0ull;
+          s.b_len[gid] = len[j];
+          copy_bytes_lane(s.b_buf + off, reinterpret_cast<const uint8_t *>(x.data) + a0[j], len[j]);
+          off += len[j];
+        }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < kFixupGroups; j++) {
+        if (!active[j]) continue;
+        const uint32_t gid = a.g0 + p[j];
+        const bool isnull = col_is_null(x, row[j]);
+        s.present[gid] = isnull ? 0 : 1;
+        switch (x.type) {
+          case CRGPU_BOOL: s.data[gid] = isnull ? 0 : static_cast<uint8_t>(col_get_bool(x, row[j])); break;
+          case CRGPU_INT16: reinterpret_cast<int16_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int16_t *>(x.data)[row[j]]; break;
+          case CRGPU_INT32: reinterpret_cast<int32_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int32_t *>(x.data)[row[j]]; break;
+          case CRGPU_INT64: reinterpret_cast<int64_t *>(s.data)[gid] = isnull ? 0 : reinterpret_cast<const int64_t *>(x.data)[row[j]]; break;
+          case CRGPU_FLOAT64: reinterpret_cast<double *>(s.data)[gid] = isnull ? 0.0 : col_get_f64(x, row[j]); break;
+          default: break;
+        }
       }
     }
-    const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row);
-    for (int f = 0; f < a.naggs; f++)
-      first_row_store(a.ops[f], f, row, seq, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
-    const unsigned long long w = a.rep_word[p];
-    a.gword[gid] = w;
-    a.meta[a.rep_slot[p]] = (w & 0xFFFFFFFF00000000ull) | gid;
+    for (int j = 0; j < kFixupGroups; j++) {
+      if (!active[j]) continue;
+      const uint32_t gid = a.g0 + p[j];
+      const unsigned long long seq = a.seq_base + static_cast<unsigned long long>(row[j]);
+      for (int f = 0; f < a.naggs; f++)
+        first_row_store(a.ops[f], f, row[j], seq, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
+      const unsigned long long w = a.rep_word[p[j]];
+      a.gword[gid] = w;
+      a.meta[a.rep_slot[p[j]]] = (w & 0xFFFFFFFF00000000ull) | gid;
+    }
   }
 }
 
@@ -2454,7 +2534,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
       f.any_tails = a->any_tails_dev.as<unsigned long long>();
       f.seq_base = a->seq;
       ProfScope prof("agg_fixup");
-      hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for(nnew, 256)), dim3(256), 0, st, f);
+      hipLaunchKernelGGL(agg_fixup_kernel, dim3(grid_for((static_cast<int64_t>(nnew) + kFixupGroups - 1) / kFixupGroups, 256)), dim3(256), 0, st, f);
       CRGPU_HIP(hipGetLastError());
       a->ngroups += nnew;
     }

@@ -26,6 +26,7 @@ def _sync():
 
 
 def _timed(fn, reps):
+    _sync()  # inputs are produced on torch's stream, the library runs on its own: offsets read early are garbage
     fn()
     _sync()
     dev.prof_enable(True); dev.prof_reset()
