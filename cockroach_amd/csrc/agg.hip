@@ -1150,13 +1150,18 @@ __global__ __launch_bounds__(1024) void agg_part_accum_kernel(PartAccArgs a) {
 // and every sub-partition is grouped and aggregated ENTIRELY IN LDS by one workgroup: equal keys share a
 // sub-partition, so its groups are final and are appended to the per-group arrays (one HBM atomic per workgroup
 // reserves their group ids).  The hash index is not touched; it is rebuilt from the hash words if more input follows.
-static constexpr int kBulkSlots = 2048;       // LDS index of one sub-partition
-static constexpr uint32_t kBulkRows = 2048;   // rows a sub-partition may hold (region size of the split; 8192 made the
+// Two forms, chosen from a key sample:
+//   sub : ~all keys distinct up to ~32 rows per key: the level-2 split gives fixed regions of <= kBulkRows rows;
+//   part: ~16 ... ~2000 groups per level-1 partition (2^14 ... ~2^21 groups in all): no level-2 split; a workgroup
+//         walks the variable-length partition in tiles of kBulkRows rows and its groups stay in LDS across the tiles.
+static constexpr uint32_t kBulkRows = 2048;   // rows per tile = rows a sub-partition region holds (8192 made the
                                               // kernel 1.5x slower: 8 rows per thread and twice the region traffic)
-static constexpr uint32_t kBulkGroups = 1536; // groups a sub-partition may hold (LDS accumulator planes)
+static constexpr uint32_t kBulkSubSlots = 2048;   // sub form: LDS index slots / groups a sub-partition may hold
+static constexpr uint32_t kBulkSubGroups = 1536;
 struct BulkArgs {
-  const ulonglong2 *rows;       // {key, value} rows, kBulkRows per sub-partition
-  const uint32_t *sub_count;
+  const ulonglong2 *rows;       // {key, value} rows
+  const uint32_t *starts;       // part form: first row of region q (nullptr: q * kBulkRows)
+  const uint32_t *counts;       // rows of region q
   OpK ops[kMaxOpsPerLaunch];    // accumulator pointers and LDS plane numbers; inputs all come from the row's value
   int32_t naggs;
   uint32_t nwords, nseen;
@@ -1165,23 +1170,28 @@ struct BulkArgs {
   uint8_t *key_present;
   unsigned long long *gword;
   unsigned int *ngroups;        // running group count (HBM)
-  unsigned int *failed;         // a sub-partition held more than gmax groups
+  unsigned int *failed;         // a region held more than gmax groups
   uint32_t g0;
-  uint32_t gmax;                // groups a sub-partition may hold (<= kBulkGroups; sized to the LDS the planes need)
+  uint32_t gmax;                // groups a region may hold (sized to the LDS the planes need)
+  uint32_t slots;               // LDS index size (power of two, > gmax)
 };
 __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
-  extern __shared__ unsigned long long lds_words[];  // [nwords][kBulkGroups + 1] accumulators, then the seen planes
-  __shared__ uint32_t idx[kBulkSlots];               // slot -> representative row, later -> local group id
-  __shared__ uint32_t rep[kBulkGroups];              // local group id -> representative row
-  __shared__ uint32_t s_ngrp, s_base, s_claims;
+  // dynamic LDS: [nwords][gmax + 1] accumulator words, [slots] slot -> representative row, [slots] slot -> local group
+  // id, [gmax] local group id -> representative row, then the seen planes (bytes)
+  extern __shared__ unsigned long long lds_words[];
+  __shared__ uint32_t s_base, s_claims;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t plane = a.gmax + 1;
-  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
+  uint32_t *idx = reinterpret_cast<uint32_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
+  uint32_t *lid = idx + a.slots;
+  uint32_t *rep = lid + a.slots;
+  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(rep + a.gmax);
   const int q = blockIdx.x;
-  const ulonglong2 *rows = a.rows + static_cast<int64_t>(q) * kBulkRows;
-  const uint32_t n = a.sub_count[q];
+  const uint32_t n = a.counts[q];
   if (n == 0) return;
-  for (uint32_t i = threadIdx.x; i < kBulkSlots; i += blockDim.x) idx[i] = kNone;
+  const ulonglong2 *rows = a.rows + (a.starts != nullptr ? static_cast<int64_t>(a.starts[q]) : static_cast<int64_t>(q) * kBulkRows);
+  const uint32_t smask = a.slots - 1;
+  for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) idx[i] = kNone;
   for (int f = 0; f < a.naggs; f++) {
     const OpK &op = a.ops[f];
     if (op.lw0 >= 0) {
@@ -1192,74 +1202,74 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * plane + i] = 0ull;
   }
   for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
-  if (threadIdx.x == 0) s_ngrp = 0, s_claims = 0;
+  if (threadIdx.x == 0) s_claims = 0;
   __syncthreads();
-  // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key)
-  constexpr int kRows = kBulkRows / 1024;  // rows per thread at 1024 threads
-  uint32_t slot_of[kRows];
-  unsigned long long val[kRows];
+  constexpr int kRows = kBulkRows / 1024;  // rows per thread and tile at 1024 threads
+  for (uint32_t t0 = 0; t0 < n; t0 += kBulkRows) {
+    // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key); the claimant
+    //    numbers the group
+    uint32_t slot_of[kRows];
+    unsigned long long val[kRows];
 #pragma unroll
-  for (int k = 0; k < kRows; k++) {
-    const uint32_t i = k * blockDim.x + threadIdx.x;
-    slot_of[k] = kNone;
-    val[k] = 0;
-    if (i < n) {
-      const ulonglong2 r = rows[i];
-      val[k] = r.y;
-      uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & (kBulkSlots - 1);
-      int probes = 0;
-      for (;; probes++) {
-        if (probes == kBulkSlots) {  // the index is full of other keys: far more groups than the planes hold
-          atomicAdd(&s_claims, kBulkGroups + 1);
-          sl = kNone;
-          break;
-        }
-        uint32_t cur = idx[sl];
-        if (cur == kNone) {
-          cur = atomicCAS(&idx[sl], kNone, i);
-          if (cur == kNone) {
-            atomicAdd(&s_claims, 1u);
+    for (int k = 0; k < kRows; k++) {
+      const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
+      slot_of[k] = kNone;
+      val[k] = 0;
+      if (i < n) {
+        const ulonglong2 r = rows[i];
+        val[k] = r.y;
+        uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & smask;
+        uint32_t probes = 0;
+        for (;; probes++) {
+          if (probes == a.slots) {  // the index is full of other keys: far more groups than the planes hold
+            atomicAdd(&s_claims, a.gmax + 1);
+            sl = kNone;
             break;
           }
+          uint32_t cur = idx[sl];
+          if (cur == kNone) {
+            cur = atomicCAS(&idx[sl], kNone, i);
+            if (cur == kNone) {
+              const uint32_t l = atomicAdd(&s_claims, 1u);
+              lid[sl] = l;  // read after the barrier below
+              if (l < a.gmax) rep[l] = i;
+              break;
+            }
+          }
+          if (rows[cur].x == r.x) break;
+          sl = (sl + 1) & smask;
         }
-        if (rows[cur].x == r.x) break;
-        sl = (sl + 1) & (kBulkSlots - 1);
+        slot_of[k] = sl;
       }
-      slot_of[k] = sl;
     }
-  }
-  __syncthreads();
-  if (s_claims > a.gmax) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
-    if (threadIdx.x == 0) atomicOr(a.failed, 1u);
-    return;
-  }
-  // 2. number the groups of this sub-partition
-  for (uint32_t sl = threadIdx.x; sl < kBulkSlots; sl += blockDim.x) {
-    const uint32_t r = idx[sl];
-    if (r != kNone) {
-      const uint32_t lid = atomicAdd(&s_ngrp, 1u);
-      rep[lid] = r;
-      idx[sl] = lid;
+    __syncthreads();
+    if (s_claims > a.gmax) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
+      if (threadIdx.x == 0) atomicOr(a.failed, 1u);
+      return;
     }
-  }
-  __syncthreads();
-  // 3. accumulate in LDS (apply_rows_lds: straight-line updates; rows past the end go to the trash group)
-  {
+    // 2. accumulate in LDS (apply_rows_lds: straight-line updates; rows past the end go to the trash group)
     uint32_t gr[kRows];
     int64_t rowi[kRows];
     uint32_t takem = 0;
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
-      gr[k] = slot_of[k] != kNone ? idx[slot_of[k]] : 0;
+      gr[k] = slot_of[k] != kNone ? lid[slot_of[k]] : a.gmax;
+      if (gr[k] > a.gmax) gr[k] = a.gmax;  // only while a faster wave has already overflowed the planes (attempt abandoned)
       rowi[k] = 0;
       takem |= (slot_of[k] != kNone ? 1u : 0u) << k;
     }
     for (int f = 0; f < a.naggs; f++)
       apply_rows_lds<kRows>(a.ops[f], val, takem, gr, a.gmax, plane, lds_words, lds_seen, rowi, 0ull);
+    // no barrier needed before the next tile's inserts: they touch idx / lid / rep / s_claims, the updates above touch
+    // the planes; lid entries read above were written before the barrier and are never rewritten
   }
   __syncthreads();
-  // 4. append the groups: ids [base, base + ngrp), everything written with plain coalesced stores
-  const uint32_t ngrp = s_ngrp;
+  if (s_claims > a.gmax) {  // a wave that was ahead overflowed after the others had passed the check above
+    if (threadIdx.x == 0) atomicOr(a.failed, 1u);
+    return;
+  }
+  // 3. append the groups: ids [base, base + ngrp), everything written with plain coalesced stores
+  const uint32_t ngrp = s_claims;
   if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, ngrp);
   __syncthreads();
   const uint32_t base = a.g0 + s_base;
@@ -2064,7 +2074,7 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 32 * 1024)));
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_part_accum_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     lds_attr_set = true;
@@ -2603,7 +2613,6 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   const DCol &key = cols[a->group_cols[0]];
   if (key.valid != nullptr || (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0) return CRGPU_OK;
   int vcol = -1, nops = 0;
-  size_t lds = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
     nops++;
@@ -2616,21 +2625,14 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   }
   if (nops > kMaxOpsPerLaunch) return CRGPU_OK;
   if (vcol >= 0 && (cols[vcol].valid != nullptr || (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0)) return CRGPU_OK;
-  // accumulator planes: as many groups per sub-partition as fit beside the 14 KiB of static LDS (idx + rep); ~1024
-  // groups are expected for all-distinct keys, so anything below 1280 would fail too often
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0) return CRGPU_OK;
-  size_t gmax = (kLdsMax / 2 - 15 * 1024) / bpg - 1;  // two workgroups per CU
-  if (gmax < 1280) gmax = (kLdsMax - 15 * 1024) / bpg - 1;  // wide accumulator sets: one workgroup per CU
-  if (gmax > kBulkGroups) gmax = kBulkGroups;
-  if (gmax < 1280) return CRGPU_OK;
-  lds = bpg * (gmax + 1);
   hipStream_t st = stream();
-  // high cardinality?  s = 8192 keys sampled at a fixed stride: about s^2 / 2G of them collide for G equally likely
-  // groups, so d duplicates mean ~2 d n / s^2 rows per group.  Up to ~32 rows per group the sub-partition regions hold
-  // (2048 rows expected, sigma = sqrt(2048 * 32) = 256, capacity 4096); fewer, larger groups are better served by the
-  // incremental paths anyway
-  for (const int kSample : {512, 8192}) {  // the small sample rejects low-cardinality inputs for ~30 us
+  // Which form?  s keys sampled at a fixed stride: for G equally likely groups the sample holds G (1 - exp(-s / G))
+  // distinct keys.  The small sample rejects low-cardinality inputs for ~30 us.
+  int64_t distinct = 0, maxrun = 0;
+  constexpr int kBigSample = 8192;
+  for (const int kSample : {512, kBigSample}) {
     std::vector<int64_t> sample(kSample);
     const int64_t stride = n / kSample;
     CRGPU_TRY(a->scratch.ensure(static_cast<size_t>(kSample) * 8));
@@ -2640,29 +2642,76 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, static_cast<size_t>(kSample) * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     std::sort(sample.begin(), sample.end());
-    const int64_t distinct = std::unique(sample.begin(), sample.end()) - sample.begin();
-    int64_t dmax = 16 * (int64_t(kSample) * kSample) / n;
-    if (dmax < 8) dmax = 8;
-    if (dmax > kSample / 4) dmax = kSample / 4;
-    if (kSample - distinct > dmax) return CRGPU_OK;
+    distinct = 0;
+    maxrun = 0;
+    for (int i = 0, run = 0; i < kSample; i++) {
+      run = (i > 0 && sample[i] == sample[i - 1]) ? run + 1 : 1;
+      if (run == 1) distinct++;
+      if (run > maxrun) maxrun = run;
+    }
+    if (kSample == 512 && distinct < 384) return CRGPU_OK;  // fewer than ~1000 groups: the fused pass is the right tool
   }
+  // sub form: up to ~32 rows per group the sub-partition regions hold (1024 rows expected, capacity 2048)
+  int64_t dmax = 16 * (int64_t(kBigSample) * kBigSample) / n;
+  if (dmax < 8) dmax = 8;
+  if (dmax > kBigSample / 4) dmax = kBigSample / 4;
+  const bool sub_form = kBigSample - distinct <= dmax;
+  size_t gmax = 0, slots = 0;
+  if (sub_form) {
+    slots = kBulkSubSlots;
+    gmax = (kLdsMax / 2 - 64 - slots * 8 - bpg) / (bpg + 4);  // two workgroups per CU
+    if (gmax < 1280) gmax = (kLdsMax - 64 - slots * 8 - bpg) / (bpg + 4);  // wide accumulator sets: one workgroup per CU
+    if (gmax > kBulkSubGroups) gmax = kBulkSubGroups;
+    if (gmax < 1280) return CRGPU_OK;  // ~1024 groups are expected for all-distinct keys
+  } else {
+    // part form: estimate G by bisection on G (1 - exp(-s / G)) = distinct
+    double lo = 1.0, hi = 1e12;
+    for (int it = 0; it < 60; it++) {
+      const double mid = std::sqrt(lo * hi);
+      if (mid * (1.0 - std::exp(-static_cast<double>(kBigSample) / mid)) < static_cast<double>(distinct)) lo = mid;
+      else hi = mid;
+    }
+    // a hot key would serialise its partition's workgroup: a key sampled far more often than the s / G expected (or
+    // more than 8 times = 0.1 % of the rows, when that is larger) leaves the input to the other paths
+    const double mu = static_cast<double>(kBigSample) / hi;
+    if (static_cast<double>(maxrun) > std::max(8.0, 3.0 * mu + 6.0)) return CRGPU_OK;
+    // few groups per partition: the lanes of a wave collide on the same LDS words (measured: 8 per partition 3.3 ms,
+    // 16 3.1 ms, 64 3.0 ms per 2^27 rows; the gid-partitioned path takes 4.5 ms there)
+    static const double min_per_part = getenv("CRGPU_BULK_MIN_PER_PART") ? atof(getenv("CRGPU_BULK_MIN_PER_PART")) : 3.0;
+    const double per_part = hi / kRadixP1;
+    if (per_part < min_per_part) return CRGPU_OK;
+    for (const size_t sl : {size_t(2048), size_t(4096), size_t(8192)}) {
+      if (kLdsMax < 64 + sl * 8 + bpg) continue;
+      size_t g = (kLdsMax - 64 - sl * 8 - bpg) / (bpg + 4);
+      if (g > sl * 3 / 4) g = sl * 3 / 4;
+      if (g > gmax) gmax = g, slots = sl;
+    }
+    if (per_part * 1.3 + 4.0 * std::sqrt(per_part) + 16.0 > static_cast<double>(gmax)) return CRGPU_OK;
+  }
+  const size_t lds = (static_cast<size_t>(a->lds_words) * 8 * (gmax + 1) + slots * 8 + gmax * 4 +
+                      static_cast<size_t>(a->lds_seen) * (gmax + 1) + 15) & ~size_t(15);
   RadixSrc src;
   std::memset(&src, 0, sizeof(src));
   src.key = key;
   src.pay = vcol >= 0 ? static_cast<const uint8_t *>(cols[vcol].data) : nullptr;
   src.pay_width = vcol >= 0 ? 8 : 0;
   src.fast = vcol >= 0 ? 1 : 0;
-  bool ok = false;
-  CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
-  if (!ok) return CRGPU_OK;  // a sub-partition overflowed: many rows per key after all
+  if (sub_form) {
+    bool ok = false;
+    CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
+    if (!ok) return CRGPU_OK;  // a sub-partition overflowed: many rows per key after all
+  } else {
+    CRGPU_TRY(radix_partition_level1(a->radix, src, n));
+  }
   CRGPU_TRY(ensure_groups(a, static_cast<size_t>(n)));
   CRGPU_TRY(upload_descriptors(a, &cols));
   CRGPU_TRY(a->bulk_count.ensure(8));
   CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 8, st));
   BulkArgs b;
   std::memset(&b, 0, sizeof(b));
-  b.rows = a->radix.rows_b.as<ulonglong2>();
-  b.sub_count = a->radix.sub_count.as<uint32_t>();
+  b.rows = sub_form ? a->radix.rows_b.as<ulonglong2>() : a->radix.rows_a.as<ulonglong2>();
+  b.starts = sub_form ? nullptr : a->radix.starts.as<uint32_t>();
+  b.counts = sub_form ? a->radix.sub_count.as<uint32_t>() : a->radix.totals.as<uint32_t>();
   int f = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
@@ -2687,10 +2736,11 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.failed = a->bulk_count.as<unsigned int>() + 1;
   b.g0 = 0;
   b.gmax = static_cast<uint32_t>(gmax);
-  const unsigned nsubs = static_cast<unsigned>(kRadixP1) << a->radix.sub_bits;
+  b.slots = static_cast<uint32_t>(slots);
+  const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) << a->radix.sub_bits : static_cast<unsigned>(kRadixP1);
   {
-    ProfScope prof("agg_bulk");
-    hipLaunchKernelGGL(agg_bulk_kernel, dim3(nsubs), dim3(1024), (lds + 15) & ~size_t(15), st, b);
+    ProfScope prof(sub_form ? "agg_bulk" : "agg_bulk_part");
+    hipLaunchKernelGGL(agg_bulk_kernel, dim3(nregions), dim3(1024), lds, st, b);
     CRGPU_HIP(hipGetLastError());
   }
   unsigned int tf[2] = {0, 0};

@@ -63,6 +63,8 @@ struct RadixTable {
   DevBuf p_rows, p_hist, p_totals, p_starts;  // probe-side partition buffers
 };
 
+// Level 1 only: t.rows_a holds partition p's rows in [starts[p], starts[p] + totals[p]) (uint32 arrays of kRadixP1).
+crgpu_status radix_partition_level1(RadixTable &t, const RadixSrc &src, int64_t n);
 // Levels 1 and 2 only (hash aggregation of high-cardinality inputs reuses them): t.rows_b holds the rows of
 // sub-partition q in [q * subcap, q * subcap + sub_count[q]), q < kRadixP1 << t.sub_bits.
 // *ok = false when a sub-partition overflowed its region of `subcap` rows.

@@ -615,6 +615,13 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
   return CRGPU_OK;
 }
 
+// Level 1 only: t.rows_a holds partition p's rows in [starts[p], starts[p] + totals[p]).
+crgpu_status radix_partition_level1(RadixTable &t, const RadixSrc &src, int64_t n) {
+  t.ready = false;
+  t.n = n;
+  return radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter");
+}
+
 // Levels 1 and 2: t.rows_b holds the rows of sub-partition q in [q * subcap, q * subcap + sub_count[q]).
 // *ok = false when a sub-partition overflowed its region (too many rows share hash bits: duplicate-heavy input).
 crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,

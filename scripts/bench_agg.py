@@ -56,7 +56,7 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
         raise SystemExit(f"{name}: {ngroups} groups, expected {expect}")
     kern = {}
     for k in ("agg_fused_lds", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
-              "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "radix_build_hist",
+              "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_part", "radix_build_hist",
               "radix_build_scatter", "radix_build_split"):
         ms, cnt = dev.prof_get(k)
         if cnt:
@@ -88,7 +88,7 @@ def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
     if only is None or "q1" in only:
         yield run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0, reps=reps)
     del cols, f, rf, ls
-    for groups in (1 << 10, 1 << 16, 1 << 20, 1 << 24, n):
+    for groups in (1 << 10, 1 << 13, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 21, 1 << 22, 1 << 24, n):
         if groups > n or (only is not None and str(groups) not in only):
             continue
         k = torch.randint(0, groups, (n,), generator=g, device=dv, dtype=torch.int64) if groups < n else \
@@ -103,7 +103,7 @@ def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
 
 def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 27
-    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # e.g. "q1,1024,65536"
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None  # e.g. "q1,1024,65536"
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     cpu_sample = int(sys.argv[4]) if len(sys.argv) > 4 else None  # 0: skip the CPU baseline (profiling runs)
     for r in measure(lg, only, reps, cpu_sample):

@@ -196,7 +196,7 @@ def test_agg_reset_reuses_handle(oracle):
     a.close()
 
 
-@pytest.mark.parametrize("ngroups", [5, 3000, 200_000, 5_000_000, 1 << 26])
+@pytest.mark.parametrize("ngroups", [5, 3000, 40_000, 200_000, 1_500_000, 5_000_000, 1 << 26])
 def test_agg_full_size_invariants(ngroups):
     """2^26 rows resident in HBM (the bench shapes; too large for the oracle in the test budget): size-independent
     properties that any loss, duplication or mis-grouping of rows would break -- one output row per distinct key,
@@ -274,6 +274,58 @@ def test_agg_bulk_path_then_more_input_vs_oracle(oracle):
     a.close()
     want = oracle.hash_agg([cd.Vec.from_numpy(cd.INT64, np.concatenate([k1, k2])), cd.Vec.from_numpy(cd.INT64, x)], [0], aggs)
     assert np.array_equal(_canon(got), _canon(want))
+
+
+@pytest.mark.parametrize("ngroups", [20_000, 150_000])
+def test_agg_bulk_part_form_vs_oracle(oracle, ngroups):
+    """Mid cardinality (tens to ~2000 groups per radix partition): the bulk path without the level-2 split; a
+    workgroup walks its variable-length partition in tiles and keeps the groups in LDS.  More input afterwards goes
+    through the rebuilt index."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(ngroups)
+    n1, n2 = 1 << 23, 100_000
+    base = rng.permutation(ngroups * 4)[:ngroups].astype(np.int64) * 7_919 - 3
+    base[:4] = [-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    k1 = base[rng.integers(0, ngroups, size=n1)]
+    k2 = np.concatenate([rng.choice(base, n2 // 2), np.arange(n2 // 2, dtype=np.int64) * 7_919 + 1])
+    x = rng.integers(-10**9, 10**9, size=n1 + n2, dtype=np.int64)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64], [0], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k1)), dev.upload(cd.Vec.from_numpy(cd.INT64, x[:n1]))], n1)
+    assert dev.prof_get("agg_bulk_part")[1] == 1, "the part form of the bulk path did not run"
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k2)), dev.upload(cd.Vec.from_numpy(cd.INT64, x[n1:]))], n2)
+    dev.prof_enable(False)
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    want = oracle.hash_agg([cd.Vec.from_numpy(cd.INT64, np.concatenate([k1, k2])), cd.Vec.from_numpy(cd.INT64, x)], [0], aggs)
+    assert np.array_equal(_canon(got), _canon(want))
+
+
+def test_agg_bulk_part_form_skew_and_overflow(oracle):
+    """A hot key (10 % of the rows) keeps the input away from the part form; a group count the sample underestimates
+    (half of the rows on 30 000 keys, the other half all distinct) overflows the LDS planes and the attempt is
+    abandoned.  Either way the result is the oracle's."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(5)
+    n = 1 << 23
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    x = rng.integers(-1000, 1000, size=n, dtype=np.int64)
+    k = rng.integers(0, 200_000, size=n, dtype=np.int64)
+    k[rng.random(n) < 0.1] = 77
+    cols = [cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.INT64, x)]
+    dev.prof_enable(True)
+    dev.prof_reset()
+    got = G.gpu_agg(cols, [0], aggs)
+    assert dev.prof_get("agg_bulk_part")[1] == 0 and dev.prof_get("agg_bulk")[1] == 0
+    assert np.array_equal(_canon(got), _canon(oracle.hash_agg(cols, [0], aggs)))
+    k = np.where(np.arange(n) % 2 == 0, rng.integers(0, 30_000, size=n, dtype=np.int64), np.arange(n, dtype=np.int64) + 10**9)
+    cols = [cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.INT64, x)]
+    dev.prof_reset()
+    got = G.gpu_agg(cols, [0], aggs)
+    dev.prof_enable(False)
+    assert np.array_equal(_canon(got), _canon(oracle.hash_agg(cols, [0], aggs)))
 
 
 def test_agg_bulk_path_float_values_and_fallback(oracle):
