@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrgpu.so")
 
-OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM, ERR_INT_OUT_OF_RANGE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE = range(8)
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM, ERR_INT_OUT_OF_RANGE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_DUPLICATE = range(9)
 
 
 class CrgpuError(RuntimeError):
@@ -105,6 +105,10 @@ SYMBOLS = [
     ("crgpu_dev_partitioner_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(_VP)]),
     ("crgpu_dev_partition", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult), C.POINTER(_I64)]),
     ("crgpu_dev_partitioner_destroy", None, [_VP]),
+    ("crgpu_dev_distinct_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _I32, _I32, C.POINTER(_VP)]),
+    ("crgpu_dev_distinct_consume", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult)]),
+    ("crgpu_dev_distinct_reset", _I32, [_VP]),
+    ("crgpu_dev_distinct_destroy", None, [_VP]),
     ("crgpu_dev_decoder_create", _I32, [C.POINTER(FetchSpec), C.POINTER(_VP)]),
     ("crgpu_dev_decode_kv", _I32, [_VP, _VP, C.POINTER(_I64), _I64, C.POINTER(DevResult)]),
     ("crgpu_dev_decoder_destroy", None, [_VP]),

@@ -1,0 +1,380 @@
+// distinct.hip -- device-resident unordered DISTINCT.
+//
+// Replaces colexec.UnorderedDistinct.Next (pkg/sql/colexec/unordered_distinct.go:94-121) and
+// colexechash.HashTable.DistinctBuild (pkg/sql/colexec/colexechash/hashtable.go:628-649): of every input batch
+// only the tuples whose distinct columns were not seen before -- in earlier batches or earlier in the same batch --
+// are emitted, all columns of the FIRST such row, in input order.
+//
+// Design (not the reference's chained table over 1024-row batches):
+//  * Seen keys are numbered densely in emission order ("gid"); the distinct columns of emitted rows are appended to
+//    a key store (the reference's ht.Vals in distinct build mode keeps the key columns only, hashtable.go:262-266).
+//    Since a batch's new keys are exactly its output rows, the store is appended by copying the key columns of the
+//    output (device-to-device, coalesced).
+//  * The hash index is an open-addressing array of 64-bit entries {tag:23 | null mask:8 | gid:32}, at most half full
+//    (capacity is ensured before a batch, so linear probing always ends).  While a batch is resolved an entry may hold
+//    {claim bit | tag | mask | row position}: rows of the same key compare against the claimant's ROW (inputs are
+//    immutable during the call) and lower the entry to the SMALLEST position with a 64-bit atomicMin, which is what
+//    makes the emitted row the first occurrence without any ordering between workgroups.
+//  * nullsAreDistinct (UPSERT plans): a row with a NULL among its distinct columns never matches anything; it is
+//    emitted and not inserted (hashtable.go allowNullEquality=false).
+//
+// Roofline: HBM-bound; one random index access per row (the 24 G/s atomics wall for new keys, L2-resident lookups
+// for repeated ones) + the output gather.
+#include <cstring>
+#include <memory>
+
+#include "device.h"
+
+namespace crgpu {
+
+static constexpr unsigned long long kDEmpty = ~0ull;
+static constexpr uint32_t kDClaim = 0x80000000u;
+static constexpr uint32_t kDNone = 0xFFFFFFFFu;
+static constexpr uint32_t kDMaxCap = 1u << 30;
+
+struct DHash {
+  uint32_t idx;    // index position before masking (30 bits)
+  uint32_t upper;  // tag << 8 | null mask
+};
+__device__ __forceinline__ DHash distinct_hash(const KeyCols &k, int64_t row) {
+  uint32_t nm = 0;
+  for (int c = 0; c < k.n; c++) nm |= (col_is_null(k.c[c], row) ? 1u : 0u) << c;
+  // the reference's rehash (NULL leaves the running hash unchanged; the mask is compared separately), then a finaliser
+  const uint64_t h = fmix64(hash_row64(k, row, 1) ^ (static_cast<uint64_t>(nm) << 56));
+  DHash r;
+  r.idx = static_cast<uint32_t>(h) & (kDMaxCap - 1);
+  r.upper = (static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8 | nm;
+  return r;
+}
+
+// row of the batch vs stored key gid; columns NULL on both sides (equal masks) are skipped
+__device__ inline bool row_equals_store(const KeyCols &k, int64_t row, const KeyCols &st, uint32_t gid, uint32_t nm) {
+  for (int c = 0; c < k.n; c++) {
+    if ((nm >> c) & 1u) continue;
+    const DCol &x = k.c[c];
+    const DCol &s = st.c[c];
+    switch (x.type) {
+      case CRGPU_BOOL:
+        if (col_get_bool(x, row) != col_get_bool(s, gid)) return false;
+        break;
+      case CRGPU_INT16:
+      case CRGPU_INT32:
+      case CRGPU_INT64:
+        if (col_get_int(x, row) != col_get_int(s, gid)) return false;
+        break;
+      case CRGPU_FLOAT64: {
+        const double p = col_get_f64(x, row), q = col_get_f64(s, gid);
+        if (!(p == q || (p != p && q != q))) return false;
+        break;
+      }
+      case CRGPU_BYTES: {
+        const uint32_t xa = x.offsets[row], xl = x.offsets[row + 1] - xa;
+        const uint32_t sa = s.offsets[gid], sl = s.offsets[gid + 1] - sa;
+        if (xl != sl) return false;
+        const uint8_t *px = reinterpret_cast<const uint8_t *>(x.data) + xa;
+        const uint8_t *ps = reinterpret_cast<const uint8_t *>(s.data) + sa;
+        for (uint32_t t = 0; t < xl; t++)
+          if (px[t] != ps[t]) return false;
+        break;
+      }
+      default: return false;
+    }
+  }
+  return true;
+}
+
+struct DResolveArgs {
+  KeyCols keys;   // distinct columns of the batch
+  KeyCols store;  // distinct columns of the keys seen so far (no validity: the entry's mask says which are NULL)
+  int64_t n;
+  unsigned long long *meta;
+  uint32_t mask;
+  int32_t nulls_are_distinct;
+  uint32_t *slot_of;  // [n] index slot the row ended at (kDNone: repeats a stored key, or bypasses the table)
+  uint8_t *flags;     // [n] preset for rows that bypass the table
+};
+__global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const DHash h = distinct_hash(a.keys, i);
+    uint32_t slot = kDNone;
+    uint8_t flag = 0;
+    if (a.nulls_are_distinct && (h.upper & 0xFFu) != 0) {
+      flag = 1;  // never equal to anything, never looked up
+    } else {
+      const unsigned long long claim = (static_cast<unsigned long long>(h.upper | kDClaim) << 32) | static_cast<uint32_t>(i);
+      uint32_t idx = h.idx & a.mask;
+      for (;;) {  // ends: the index is at most half full (ensured by the host before the launch)
+        unsigned long long e = __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == kDEmpty) e = atomicCAS(&a.meta[idx], kDEmpty, claim);
+        if (e == kDEmpty) {
+          slot = idx;
+          break;
+        }
+        const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
+        if ((up & ~kDClaim) == h.upper) {
+          if (up & kDClaim) {
+            if (keys_equal(a.keys, i, a.keys, static_cast<int64_t>(lo), true)) {
+              atomicMin(&a.meta[idx], claim);  // same upper word: the smallest position wins
+              slot = idx;
+              break;
+            }
+          } else if (row_equals_store(a.keys, i, a.store, lo, h.upper & 0xFFu)) {
+            break;  // seen in an earlier batch
+          }
+        }
+        idx = (idx + 1) & a.mask;
+      }
+    }
+    a.slot_of[i] = slot;
+    a.flags[i] = flag;
+  }
+}
+
+// a row is emitted iff its entry ended up holding its own position
+__global__ __launch_bounds__(256) void distinct_mark_kernel(const unsigned long long *__restrict__ meta,
+                                                            const uint32_t *__restrict__ slot_of, int64_t n,
+                                                            uint8_t *__restrict__ flags) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t s = slot_of[i];
+    if (s != kDNone) flags[i] = static_cast<uint32_t>(meta[s]) == static_cast<uint32_t>(i) ? 1 : 0;
+  }
+}
+
+// emitted row j becomes key g0 + j: its entry now names the stored key; hash word kept for index rebuilds
+__global__ __launch_bounds__(256) void distinct_publish_kernel(const int32_t *__restrict__ idx, int64_t m,
+                                                               const uint32_t *__restrict__ slot_of, uint32_t g0,
+                                                               KeyCols keys, unsigned long long *__restrict__ meta,
+                                                               unsigned long long *__restrict__ gword) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < m; j += stride) {
+    const int64_t row = idx[j];
+    const uint32_t s = slot_of[row];
+    const DHash h = distinct_hash(keys, row);
+    gword[g0 + j] = s == kDNone ? kDEmpty : (static_cast<unsigned long long>(h.upper) << 32) | h.idx;
+    if (s != kDNone) meta[s] = (static_cast<unsigned long long>(h.upper) << 32) | (g0 + static_cast<uint32_t>(j));
+  }
+}
+
+__global__ __launch_bounds__(256) void distinct_reindex_kernel(const unsigned long long *__restrict__ gword, uint32_t ngroups,
+                                                               unsigned long long *__restrict__ meta, uint32_t mask) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < ngroups; gid += stride) {
+    const unsigned long long w = gword[gid];
+    if (w == kDEmpty) continue;  // a nullsAreDistinct row: stored, never indexed
+    const unsigned long long e = (w & 0xFFFFFFFF00000000ull) | gid;
+    uint32_t idx = static_cast<uint32_t>(w) & mask;
+    while (atomicCAS(&meta[idx], kDEmpty, e) != kDEmpty) idx = (idx + 1) & mask;
+  }
+}
+
+// BYTES key store append: offsets of the output column rebased onto the store's tail
+__global__ __launch_bounds__(256) void distinct_append_offsets_kernel(const uint32_t *__restrict__ out_offsets, int64_t m,
+                                                                      uint32_t base, uint32_t *__restrict__ dst) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j <= m; j += stride) dst[j] = base + out_offsets[j];
+}
+
+static inline int dgrid(int64_t n) {
+  int64_t want = (n + 255) / 256;
+  const int64_t cap = static_cast<int64_t>(num_cus()) * 8;
+  if (want < 1) want = 1;
+  return static_cast<int>(want < cap ? want : cap);
+}
+
+}  // namespace crgpu
+
+using namespace crgpu;
+
+struct crgpu_distinct {
+  std::vector<int> types, dcols;
+  bool nulls_are_distinct = false, error_on_dup = false;
+  uint32_t cap = 0;      // index entries
+  uint32_t ngroups = 0;  // keys stored
+  size_t gcap = 0;       // key store capacity (keys)
+  DevBuf meta, gword, slot_of, flags, idx, scratch;
+  struct KS { DevBuf data, offsets; uint64_t tail = 0; };
+  std::vector<std::unique_ptr<KS>> ks;
+  std::vector<OutCol> out;
+  std::vector<crgpu_dcol> views;
+};
+
+static crgpu_status distinct_ensure(crgpu_distinct *d, size_t need_groups) {
+  hipStream_t st = stream();
+  if (need_groups > d->gcap) {
+    size_t g = d->gcap ? d->gcap : 1024;
+    while (g < need_groups) g *= 2;
+    for (size_t k = 0; k < d->dcols.size(); k++) {
+      const int t = d->types[d->dcols[k]];
+      if (t == CRGPU_BYTES) {
+        const bool fresh = d->ks[k]->offsets.p == nullptr;
+        CRGPU_TRY(d->ks[k]->offsets.ensure((g + 1) * 4, true));
+        if (fresh) CRGPU_HIP(hipMemsetAsync(d->ks[k]->offsets.p, 0, 4, st));
+      } else {
+        CRGPU_TRY(d->ks[k]->data.ensure(g * type_width(t), true));
+      }
+    }
+    CRGPU_TRY(d->gword.ensure(g * 8, true));
+    d->gcap = g;
+  }
+  uint64_t want = 1024;
+  while (want < 2 * static_cast<uint64_t>(need_groups)) want *= 2;
+  if (want > kDMaxCap) return fail(CRGPU_ERR_OOM, "crgpu_dev_distinct_consume: more than 2^29 distinct keys on one GPU");
+  if (want > d->cap) {
+    CRGPU_TRY(d->meta.ensure(static_cast<size_t>(want) * 8));
+    CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(want) * 8, st));
+    d->cap = static_cast<uint32_t>(want);
+    if (d->ngroups > 0) {
+      ProfScope prof("distinct_reindex");
+      hipLaunchKernelGGL(distinct_reindex_kernel, dim3(dgrid(d->ngroups)), dim3(256), 0, st, d->gword.as<unsigned long long>(),
+                         d->ngroups, d->meta.as<unsigned long long>(), d->cap - 1);
+      CRGPU_HIP(hipGetLastError());
+    }
+  }
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_distinct_create(const int32_t *types, int32_t n_cols, const int32_t *distinct_cols,
+                                                  int32_t n_distinct, int32_t nulls_are_distinct, int32_t error_on_dup,
+                                                  crgpu_distinct **out) {
+  CRGPU_TRY(ensure_init());
+  if (types == nullptr || distinct_cols == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_create: null argument");
+  if (n_cols < 1 || n_cols > kMaxCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_create: column count out of range");
+  if (n_distinct < 1 || n_distinct > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_create: between 1 and 8 distinct columns");
+  std::unique_ptr<crgpu_distinct> d(new crgpu_distinct());
+  for (int i = 0; i < n_cols; i++) {
+    if (!valid_type(types[i])) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_create: unsupported column type");
+    d->types.push_back(types[i]);
+  }
+  for (int i = 0; i < n_distinct; i++) {
+    if (distinct_cols[i] < 0 || distinct_cols[i] >= n_cols) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_create: distinct column ordinal out of range");
+    d->dcols.push_back(distinct_cols[i]);
+    d->ks.emplace_back(new crgpu_distinct::KS());
+  }
+  d->nulls_are_distinct = nulls_are_distinct != 0;
+  d->error_on_dup = error_on_dup != 0;
+  d->out = std::vector<OutCol>(n_cols);
+  d->views.resize(n_cols);
+  *out = d.release();
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_dev_distinct_destroy(crgpu_distinct *d) {
+  if (d == nullptr) return;
+  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
+  delete d;
+}
+
+extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
+  if (d == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_reset: null handle");
+  hipStream_t st = stream();
+  if (d->cap) CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(d->cap) * 8, st));
+  d->ngroups = 0;
+  for (auto &k : d->ks) k->tail = 0;
+  CRGPU_HIP(hipStreamSynchronize(st));
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *res) {
+  if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null argument");
+  if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_consume: at most 2^31 rows per call");
+  if (n > 0 && cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null columns");
+  const int nc = static_cast<int>(d->types.size());
+  hipStream_t st = stream();
+  std::vector<DCol> in;
+  for (int c = 0; c < nc; c++) {
+    DCol x{d->types[c], 0, nullptr, nullptr, nullptr};
+    if (n > 0) {
+      if (cols[c].type != d->types[c]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: column type differs from the spec");
+      if (cols[c].type == CRGPU_BYTES && cols[c].offsets == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: BYTES column without offsets");
+      if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null data pointer");
+      x = to_dcol(cols[c]);
+    }
+    in.push_back(x);
+  }
+  int64_t m = 0;
+  if (n > 0) {
+    CRGPU_TRY(distinct_ensure(d, static_cast<size_t>(d->ngroups) + static_cast<size_t>(n)));
+    CRGPU_TRY(d->slot_of.ensure(static_cast<size_t>(n) * 4));
+    CRGPU_TRY(d->flags.ensure(static_cast<size_t>(n)));
+    CRGPU_TRY(d->idx.ensure(static_cast<size_t>(n) * 4));
+    DResolveArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.keys.n = a.store.n = static_cast<int>(d->dcols.size());
+    for (size_t k = 0; k < d->dcols.size(); k++) {
+      a.keys.c[k] = in[d->dcols[k]];
+      a.store.c[k] = DCol{d->types[d->dcols[k]], 0, d->ks[k]->data.p, nullptr, d->ks[k]->offsets.as<uint32_t>()};
+    }
+    a.n = n;
+    a.meta = d->meta.as<unsigned long long>();
+    a.mask = d->cap - 1;
+    a.nulls_are_distinct = d->nulls_are_distinct ? 1 : 0;
+    a.slot_of = d->slot_of.as<uint32_t>();
+    a.flags = d->flags.as<uint8_t>();
+    {
+      ProfScope prof("distinct_resolve");
+      hipLaunchKernelGGL(distinct_resolve_kernel, dim3(dgrid(n)), dim3(256), 0, st, a);
+      CRGPU_HIP(hipGetLastError());
+      hipLaunchKernelGGL(distinct_mark_kernel, dim3(dgrid(n)), dim3(256), 0, st, d->meta.as<unsigned long long>(),
+                         d->slot_of.as<uint32_t>(), n, d->flags.as<uint8_t>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    CRGPU_TRY(select_flagged(d->flags.as<uint8_t>(), n, d->idx.as<int32_t>(), d->scratch, &m));
+    if (m > 0) {
+      ProfScope prof("distinct_publish");
+      hipLaunchKernelGGL(distinct_publish_kernel, dim3(dgrid(m)), dim3(256), 0, st, d->idx.as<int32_t>(), m,
+                         d->slot_of.as<uint32_t>(), d->ngroups, a.keys, d->meta.as<unsigned long long>(),
+                         d->gword.as<unsigned long long>());
+      CRGPU_HIP(hipGetLastError());
+    }
+  }
+  // the output: every column of the emitted rows, in input order
+  {
+    ProfScope prof("distinct_gather");
+    for (int c = 0; c < nc; c++) {
+      if (n == 0 || m == 0) {
+        OutCol &o = d->out[c];
+        o.type = d->types[c];
+        o.nullable = false;
+        CRGPU_TRY(o.data.ensure(16));
+        if (o.type == CRGPU_BYTES) {
+          CRGPU_TRY(o.offsets.ensure(4));
+          CRGPU_HIP(hipMemsetAsync(o.offsets.p, 0, 4, st));
+        }
+      } else {
+        CRGPU_TRY(materialize(in[c], d->idx.as<int32_t>(), m, false, d->out[c], d->scratch));
+      }
+    }
+  }
+  // the key store grows by the distinct columns of the output
+  for (size_t k = 0; m > 0 && k < d->dcols.size(); k++) {
+    const OutCol &o = d->out[d->dcols[k]];
+    crgpu_distinct::KS &s = *d->ks[k];
+    if (o.type == CRGPU_BYTES) {
+      uint32_t total = 0;
+      CRGPU_HIP(hipMemcpyAsync(&total, o.offsets.as<uint32_t>() + m, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipStreamSynchronize(st));
+      if (s.tail + total > 0xFFFFFFFFull) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_consume: more than 4 GiB of BYTES keys");
+      CRGPU_TRY(s.data.ensure(static_cast<size_t>(s.tail + total + 16), true));
+      if (total) CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + s.tail, o.data.p, total, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(distinct_append_offsets_kernel, dim3(dgrid(m + 1)), dim3(256), 0, st, o.offsets.as<uint32_t>(), m,
+                         static_cast<uint32_t>(s.tail), s.offsets.as<uint32_t>() + d->ngroups);
+      CRGPU_HIP(hipGetLastError());
+      s.tail += total;
+    } else {
+      const size_t w = static_cast<size_t>(type_width(o.type));
+      CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + static_cast<size_t>(d->ngroups) * w, o.data.p, static_cast<size_t>(m) * w,
+                               hipMemcpyDeviceToDevice, st));
+    }
+  }
+  d->ngroups += static_cast<uint32_t>(m);
+  CRGPU_HIP(hipStreamSynchronize(st));
+  for (int c = 0; c < nc; c++) d->views[c] = d->out[c].view();
+  res->n = m;
+  res->ncols = nc;
+  res->_pad = 0;
+  res->cols = d->views.data();
+  if (d->error_on_dup && m < n) return fail(CRGPU_ERR_DUPLICATE, "crgpu_dev_distinct_consume: duplicate tuple (errorOnDup)");
+  return CRGPU_OK;
+}

@@ -239,6 +239,36 @@ class Partitioner:
             pass
 
 
+class Distinct:
+    """crgpu_distinct handle (unordered DISTINCT): consume() returns the first occurrences of new tuples, in input order."""
+
+    def __init__(self, types, distinct_cols, nulls_are_distinct=False, error_on_dup=False):
+        self._types, self._dc = _i32arr(types), _i32arr(distinct_cols)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_distinct_create(self._types, len(types), self._dc, len(distinct_cols),
+                                                         int(bool(nulls_are_distinct)), int(bool(error_on_dup)), C.byref(self.h)))
+
+    def consume(self, cols, n=None) -> _lib.DevResult:
+        n = (cols[0].n if cols else 0) if n is None else n
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_distinct_consume(self.h, dcol_array(cols), n, C.byref(res)))
+        return res
+
+    def reset(self):
+        _lib.check(_lib.load().crgpu_dev_distinct_reset(self.h))
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_distinct_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Decoder:
     """crgpu_decoder handle: KV batch responses (device bytes) -> columns (cFetcher for one-KV-per-row indexes)."""
 

@@ -46,6 +46,8 @@ typedef int32_t crgpu_status;
 #define CRGPU_ERR_HIP 5              /* HIP runtime failure */
 #define CRGPU_ERR_NO_DEVICE 6        /* no gfx950 device visible */
 #define CRGPU_ERR_STATE 7            /* call made in the wrong operator state */
+#define CRGPU_ERR_DUPLICATE 8        /* unordered DISTINCT with errorOnDup saw a duplicate: the shell raises the plan's message
+                                        (colexecbase.UpsertDistinctHelper.MaybeEmitErrorOnDup) */
 
 /* canonical type families: col/typeconv/typeconv.go:30 */
 typedef enum {
@@ -198,6 +200,20 @@ crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32_t n_cols, 
 crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *out,
                                  int64_t *counts_host);
 void crgpu_dev_partitioner_destroy(crgpu_partitioner *p);
+
+/* ---- unordered DISTINCT: replaces colexec.UnorderedDistinct.Next (sql/colexec/unordered_distinct.go:94-121) and
+ * colexechash.HashTable.DistinctBuild (sql/colexec/colexechash/hashtable.go:628-649).  Every call takes one input
+ * batch and returns, in input order, all columns of the rows whose `distinct_cols` tuple was not seen before (in an
+ * earlier call or earlier in this batch): the first occurrence is the one emitted, as in the reference.  NULLs
+ * compare equal unless nulls_are_distinct (then a row with a NULL distinct column is always emitted).  With
+ * error_on_dup the call returns CRGPU_ERR_DUPLICATE when it dropped a row (the result is still valid). */
+typedef struct crgpu_distinct crgpu_distinct;
+crgpu_status crgpu_dev_distinct_create(const int32_t *types, int32_t n_cols, const int32_t *distinct_cols,
+                                       int32_t n_distinct, int32_t nulls_are_distinct, int32_t error_on_dup,
+                                       crgpu_distinct **out);
+crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *out);
+crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d);
+void crgpu_dev_distinct_destroy(crgpu_distinct *d);
 
 /* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for indexes that store one KV per
  * row (MaxKeysPerRow == 1 fast path, sql/colfetcher/cfetcher.go:758-1093,937-941) together with

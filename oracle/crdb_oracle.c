@@ -812,6 +812,81 @@ static void ht_append_all_distinct(hashtable *ht, const ora_col *cols, const int
   if ((double)ht_vals_len(ht) / (double)ht->num_buckets > ht->load_factor) ht_build_from_buffered(ht);
 }
 
+/* CheckBuildForDistinct: hashtable.go:839-870 */
+static uint32_t ht_check_build_for_distinct(hashtable *ht, uint32_t n_to_check, const int64_t *sel) {
+  for (int k = 0; k < ht->nkeys; k++) /* checkColsForDistinctTuples :751-761 */
+    ht_check_col(ht, &ht->keys[k], &ht->build_keys[k], n_to_check, sel, 0, 0);
+  uint32_t n_differs = 0;
+  uint32_t *tc = ht->to_check;
+  for (uint32_t pos = 0; pos < n_to_check && n_differs < n_to_check; pos++) {
+    uint32_t to_check = tc[pos];
+    if (ht->found_null[to_check]) {
+      /* only set when allowNullEquality is false: a NULL makes the tuple distinct from all others */
+      ht->found_null[to_check] = 0;
+      ht->head_id[to_check] = to_check + 1;
+    } else if (ht->differs[to_check]) {
+      ht->differs[to_check] = 0;
+      tc[n_differs++] = to_check;
+    }
+  }
+  return n_differs;
+}
+
+/* updateSel: hashtable_tmpl.go:779-838 (the batch always carries a selection vector here).
+ * Returns the new batch length; compacts sel and the hash buffer. */
+static int64_t ht_update_sel(hashtable *ht, int64_t *sel, int64_t batch_len) {
+  if (batch_len == 0) return 0;
+  uint8_t *visited = ht->found_null; /* "Reuse the buffer allocated for foundNull" */
+  memset(visited, 0, (size_t)batch_len);
+  int64_t distinct = 0;
+  for (int64_t i = 0; i < batch_len && distinct < batch_len; i++) {
+    uint32_t head = ht->head_id[i];
+    if (head != 0 && !visited[head - 1]) {
+      sel[distinct] = sel[head - 1];
+      visited[head - 1] = 1;
+      ht->hash_buffer[distinct] = ht->hash_buffer[i];
+      distinct++;
+    }
+  }
+  return distinct;
+}
+
+/* UnorderedDistinct: colexec/unordered_distinct.go:72-121 (Init: load factor 2.0, distinct build mode,
+ * allowNullEquality = !nullsAreDistinct) driving HashTable.DistinctBuild (hashtable.go:628-649) over
+ * batches of `batch_size` rows.  Emits every column of the rows that survive, in input order.
+ * *dropped = 1 when some batch lost a tuple (MaybeEmitErrorOnDup's condition, origLen > updatedLen). */
+ora_result *ora_unordered_distinct(const ora_col *cols, int ncols, int64_t n, const int32_t *distinct_cols, int ndistinct,
+                                   int32_t nulls_are_distinct, int32_t batch_size, uint32_t initial_buckets,
+                                   int32_t *dropped) {
+  int types[64];
+  for (int c = 0; c < ncols; c++) types[c] = cols[c].type;
+  hashtable ht;
+  ht_init(&ht, 2.0, initial_buckets ? initial_buckets : 128, types, ncols, distinct_cols, ndistinct,
+          !nulls_are_distinct, BUILD_DISTINCT, PROBE_DEFAULT);
+  ora_result *out = result_new(ncols, types);
+  int64_t *sel = (int64_t *)xmalloc((size_t)(batch_size > 0 ? batch_size : 1) * 8);
+  if (dropped) *dropped = 0;
+  for (int64_t start = 0; start < n; start += batch_size) {
+    int64_t len = n - start < batch_size ? n - start : batch_size;
+    const int64_t orig_len = len;
+    for (int64_t i = 0; i < len; i++) sel[i] = start + i;
+    /* DistinctBuild */
+    ht_compute_hash_and_build_chains(&ht, cols, len, sel);
+    ht_find_buckets(&ht, len, sel, ht.p_first, ht.p_next, ht_check_probe_for_distinct, 0, 1); /* RemoveDuplicates :686-702 */
+    len = ht_update_sel(&ht, sel, len);
+    if (ht_vals_len(&ht) > 0 && len > 0) {
+      ht_find_buckets(&ht, len, sel, ht.first, ht.next, ht_check_build_for_distinct, 0, 0);
+      len = ht_update_sel(&ht, sel, len);
+    }
+    if (len > 0) ht_append_all_distinct(&ht, cols, sel, len);
+    if (len < orig_len && dropped) *dropped = 1;
+    for (int c = 0; c < ncols && len > 0; c++) vec_append_range(&out->cols[c], &cols[c], sel, 0, len);
+  }
+  free(sel);
+  ht_free(&ht);
+  return out;
+}
+
 /* ------------------------------------------------------------------------ */
 /* hashJoiner: colexecjoin/hashjoiner.go + hashjoiner_tmpl.go                */
 /* ------------------------------------------------------------------------ */

@@ -97,6 +97,10 @@ ora_result *ora_hash_join(int32_t join_type,
  * colexecagg/hash_*_agg.eg.go).  One output column per aggregation, one row
  * per group in bucket-creation order.  Returns NULL with *err set (1 =
  * ErrIntOutOfRange) on SUM_INT overflow. */
+/* colexec.UnorderedDistinct over batches of batch_size rows (unordered_distinct.go:94-121, hashtable.go:628-649). */
+ora_result *ora_unordered_distinct(const ora_col *cols, int ncols, int64_t n, const int32_t *distinct_cols, int ndistinct,
+                                   int32_t nulls_are_distinct, int32_t batch_size, uint32_t initial_buckets,
+                                   int32_t *dropped);
 ora_result *ora_hash_agg(const ora_col *cols, int ncols, int64_t n,
                          const int32_t *group_cols, int ngroup,
                          const ora_agg_spec *aggs, int naggs,

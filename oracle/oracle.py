@@ -57,6 +57,9 @@ def lib():
         L.ora_hash_join.restype = C.c_void_p
         L.ora_hash_join.argtypes = [C.c_int32, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int64,
                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_uint32]
+        L.ora_unordered_distinct.restype = C.c_void_p
+        L.ora_unordered_distinct.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int32, C.c_int32,
+                                             C.c_uint32, C.c_void_p]
         L.ora_hash_agg.restype = C.c_void_p
         L.ora_hash_agg.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                    C.c_int32, C.c_int32, C.c_uint32, C.c_void_p]
@@ -188,6 +191,18 @@ def hash_agg(cols, group_cols, aggs, batch_size=cd.BATCH_SIZE, max_buffered=cd.M
     if err.value:
         raise OracleError(err.value)
     return _result_to_vecs(res)
+
+
+def unordered_distinct(cols, distinct_cols, nulls_are_distinct=False, batch_size=cd.BATCH_SIZE, initial_buckets=128):
+    """colexec.UnorderedDistinct (unordered_distinct.go:94-121): returns (output vecs in emission order, dropped) where
+    dropped says whether any batch lost a tuple (the errorOnDup condition)."""
+    cc, _k = make_cols(cols)
+    dc = np.ascontiguousarray(distinct_cols, dtype=np.int32)
+    dropped = C.c_int32(0)
+    n = len(cols[0]) if cols else 0
+    res = lib().ora_unordered_distinct(cc, len(cols), n, _ptr(dc), len(dc), int(bool(nulls_are_distinct)), batch_size,
+                                       initial_buckets, C.byref(dropped))
+    return _result_to_vecs(res), bool(dropped.value)
 
 
 def set_test_hash(mapping):

@@ -7,6 +7,7 @@ Reads (as text, in THIS container only; /root/reference does not travel):
                                                                    hashjoiner_test.go:1022)
   pkg/sql/colexec/aggregators_test.go     aggregatorsTestCases    (:186-785)
   pkg/sql/colexec/hash_aggregator_test.go hashAggregatorTestCases (:34-397)
+  pkg/sql/colexec/distinct_test.go        distinctTestCases       (:45-330)
 
 Only DATA is extracted: column types, input tuples, specs and expected tuples.
 `coldata.BatchSize()` is evaluated at its default of 1024 (pkg/col/coldata/batch.go:79).
@@ -297,6 +298,24 @@ def agg_cases(path, anchor, relpath):
     return out
 
 
+def distinct_cases(path, anchor, relpath):
+    text, cases, _p = parse_table(path, anchor)
+    out = []
+    for c in cases:
+        flags = {}
+        dc = {
+            "distinct_cols": c["distinctCols"], "types": c["typs"], "tuples": c["tuples"], "expected": c.get("expected", []),
+            "ordered_on_distinct_cols": bool(c.get("isOrderedOnDistinctCols", False)),
+            "nulls_are_distinct": bool(c.get("nullsAreDistinct", False)),
+            "error_on_dup": c.get("errorOnDup", ""), "no_error": bool(c.get("noError", False)),
+        }
+        dc = to_json(dc, flags)
+        dc["supported"] = bool(all(t in GPU_TYPES for t in dc["types"]) and not flags.get("unsupported"))
+        dc["source"] = relpath
+        out.append(dc)
+    return out
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     here = os.path.dirname(os.path.abspath(__file__))
@@ -310,8 +329,10 @@ def main():
     ha = agg_cases(os.path.join(colexec, "hash_aggregator_test.go"),
                    r"var hashAggregatorTestCases = \[\]aggregatorTestCase\{",
                    "pkg/sql/colexec/hash_aggregator_test.go:34-397")
+    di = distinct_cases(os.path.join(colexec, "distinct_test.go"), r"var distinctTestCases = \[\]distinctTestCase\{",
+                        "pkg/sql/colexec/distinct_test.go:45-330")
     for name, data in [("hashjoiner_cases.json", hj), ("mergejoiner_cases.json", mj),
-                       ("aggregator_cases.json", ag), ("hash_aggregator_cases.json", ha)]:
+                       ("aggregator_cases.json", ag), ("hash_aggregator_cases.json", ha), ("distinct_cases.json", di)]:
         with open(os.path.join(here, name), "w") as f:
             json.dump({"batch_size_assumed": BATCH_SIZE, "cases": data}, f, indent=1)
         print(name, len(data), "cases")

@@ -1,0 +1,108 @@
+"""GPU parity of the unordered DISTINCT (cockroach_amd/csrc/distinct.hip) through the C-ABI: the reference's literal
+cases (tests/golden/distinct_cases.json, ordered comparison as in distinct_test.go) and seeded random inputs against
+the oracle, fed in one call and in several (the key store and the index carry over), plus size-independent properties
+at 2^26 rows."""
+import numpy as np
+import pytest
+
+from cockroach_amd import coldata as cd
+from tests import helpers as H
+from tests.test_oracle_distinct import CASES, ordered_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_distinct(cols, distinct_cols, nulls_are_distinct=False, chunks=1, error_on_dup=False):
+    from cockroach_amd import device as dev
+    d = dev.Distinct([v.type for v in cols], distinct_cols, nulls_are_distinct, error_on_dup)
+    n = len(cols[0])
+    bounds = np.linspace(0, n, chunks + 1).astype(np.int64)
+    rows = []
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        chunk = [v.slice(int(s), int(e)) for v in cols]
+        out = dev.result_to_vecs(d.consume([dev.upload(v) for v in chunk], int(e - s)))
+        rows += H.vecs_to_tuples(out)
+    d.close()
+    return rows
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_distinct_reference_cases(case):
+    from cockroach_amd import _lib
+    cols = H.tuples_to_vecs(case["tuples"], case["types"])
+    for chunks in (1, 2, len(case["tuples"])):
+        if case["error_on_dup"] and not case["no_error"]:
+            with pytest.raises(_lib.CrgpuError) as e:
+                gpu_distinct(cols, case["distinct_cols"], case["nulls_are_distinct"], chunks, error_on_dup=True)
+            assert e.value.code == _lib.ERR_DUPLICATE
+            continue
+        got = gpu_distinct(cols, case["distinct_cols"], case["nulls_are_distinct"], chunks, error_on_dup=bool(case["error_on_dup"]))
+        ordered_equal(got, case["expected"], f"{case['id']} chunks={chunks}")
+
+
+@pytest.mark.parametrize("nulls_are_distinct", [False, True])
+@pytest.mark.parametrize("nkeys", [30, 5000, 400_000])
+def test_distinct_random_vs_oracle(oracle, nkeys, nulls_are_distinct):
+    rng = np.random.default_rng(nkeys + int(nulls_are_distinct))
+    n = 300_000
+    a = rng.integers(0, nkeys, size=n, dtype=np.int64)
+    f = rng.choice(np.array([0.0, -0.0, 1.5, float("nan"), -2.0, 1e300]), size=n)
+    b = rng.integers(0, 2, size=n).astype(np.uint8)
+    i16 = rng.integers(-3, 3, size=n).astype(np.int16)
+    s = [bytes([65 + int(x)]) * int(y) for x, y in zip(rng.integers(0, 3, size=n), rng.integers(0, 40, size=n))]
+    cols = [cd.Vec.from_numpy(cd.INT64, a, rng.random(n) > 0.05), cd.Vec.from_numpy(cd.FLOAT64, f, rng.random(n) > 0.05),
+            cd.Vec.from_values(cd.BYTES, s), cd.Vec.from_numpy(cd.BOOL, b), cd.Vec.from_numpy(cd.INT16, i16, rng.random(n) > 0.5),
+            cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64))]
+    for dc in ([0], [0, 1, 2], [2, 4, 3, 1]):
+        want, _ = oracle.unordered_distinct(cols, dc, nulls_are_distinct)
+        want = H.vecs_to_tuples(want)
+        for chunks in (1, 7):
+            got = gpu_distinct(cols, dc, nulls_are_distinct, chunks)
+            ordered_equal(got, want, f"dc={dc} chunks={chunks}")
+
+
+def test_distinct_reset_and_empty():
+    from cockroach_amd import device as dev
+    d = dev.Distinct([cd.INT64], [0])
+    v = cd.Vec.from_values(cd.INT64, [3, 3, 4])
+    assert dev.result_to_vecs(d.consume([dev.upload(v)], 3))[0].to_values() == [3, 4]
+    assert int(d.consume([dev.upload(v)], 3).n) == 0
+    assert int(d.consume([dev.upload(cd.Vec.from_values(cd.INT64, []))], 0).n) == 0
+    d.reset()
+    assert dev.result_to_vecs(d.consume([dev.upload(v)], 3))[0].to_values() == [3, 4]
+    d.close()
+
+
+@pytest.mark.parametrize("nkeys", [1000, 3_000_000, 1 << 26])
+def test_distinct_full_size_invariants(nkeys):
+    """2^26 rows in HBM: the output of the two halves fed one after the other holds every key exactly once, each with
+    the payload of its FIRST occurrence (the payload is the row number, so first occurrence = per-key minimum)."""
+    import torch
+    from cockroach_amd import device as dev
+    from tests.gpu_util import wrap_torch
+    n = 1 << 26
+    dv = torch.device("cuda", 0)
+    g = torch.Generator(device=dv)
+    g.manual_seed(nkeys)
+    k = torch.randperm(n, generator=g, device=dv, dtype=torch.int64) * 7 - 5 if nkeys == n else \
+        torch.randint(0, nkeys, (n,), generator=g, device=dv, dtype=torch.int64) * 11 - 3
+    w = torch.arange(n, device=dv, dtype=torch.int64)
+    torch.cuda.synchronize()
+    d = dev.Distinct([cd.INT64, cd.INT64], [0])
+    outs = []
+    h = n // 2
+    for lo, hi in ((0, h), (h, n)):
+        res = d.consume([dev.from_torch(cd.INT64, k[lo:hi]), dev.from_torch(cd.INT64, w[lo:hi])], hi - lo)
+        m = int(res.n)
+        rc = dev.result_columns(res)
+        ok, ow = wrap_torch(rc[0], m, torch.int64, dv), wrap_torch(rc[1], m, torch.int64, dv)
+        outs.append((ok.clone(), ow.clone()))
+        assert bool((ow[1:] > ow[:-1]).all()), "output is not in input order"
+    d.close()
+    ok = torch.cat([o[0] for o in outs])
+    ow = torch.cat([o[1] for o in outs])
+    uk, inv = torch.unique(k, return_inverse=True)
+    assert ok.numel() == uk.numel()
+    first = torch.full((uk.numel(),), n, device=dv, dtype=torch.int64).scatter_reduce(0, inv, w, reduce="amin")
+    order = torch.argsort(ok)
+    assert torch.equal(ok[order], uk) and torch.equal(ow[order], first)
