@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
         if ((up & ~kDClaim) == h.upper) {
           if (up & kDClaim) {
             if (keys_equal(a.keys, i, a.keys, static_cast<int64_t>(lo), true)) {
-              atomicMin(&a.meta[idx], claim);  // same upper word: the smallest position wins
+              // same upper word: the smallest position wins.  An entry only ever decreases, so a row behind the
+              // position it just read has nothing to do (with few distinct keys nearly every row: without this test
+              // 2^27 rows over 1024 keys took 26.7 ms in contended atomics)
+              if (static_cast<uint32_t>(i) < lo) atomicMin(&a.meta[idx], claim);
               slot = idx;
               break;
             }

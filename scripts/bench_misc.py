@@ -178,6 +178,33 @@ def bench_config_g(lg, reps, dv, g, which):
                 n * 28.0 + n * 36.0, reps, n)
 
 
+def bench_distinct(lg, reps, dv, g, nkeys):
+    """Unordered DISTINCT on (key) of (key, payload) rows, one call; algorithmic bytes = rows in + distinct rows out."""
+    n = 1 << lg
+    k = torch.randperm(n, generator=g, device=dv, dtype=torch.int64) * MIX if nkeys >= n else \
+        torch.randint(0, nkeys, (n,), generator=g, device=dv, dtype=torch.int64) * MIX
+    w = torch.arange(n, device=dv, dtype=torch.int64)
+    cols = [dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, w)]
+    d = dev.Distinct([cd.INT64, cd.INT64], [0])
+    m = [0]
+
+    def go():
+        d.reset()
+        m[0] = int(d.consume(cols, n).n)
+    dt = _timed(go, reps)
+    kern = _kernels(["distinct_resolve", "distinct_publish", "distinct_gather", "distinct_reindex"], reps)
+    cpu = None
+    if CPU_SAMPLE:
+        from oracle import oracle as O
+        s = min(n, CPU_SAMPLE)
+        hv = [cd.Vec.from_numpy(cd.INT64, k[:s].cpu().numpy()), cd.Vec.from_numpy(cd.INT64, w[:s].cpu().numpy())]
+        cpu = _cpu(lambda: O.unordered_distinct(hv, [0]), s, "oracle UnorderedDistinct restatement")
+    d.close()
+    r = _line(f"unordered DISTINCT on the int64 key of (key, payload), 2^{lg} rows, {m[0]} distinct", n, dt, (n + m[0]) * 16.0, kern, cpu)
+    r["groups"] = m[0]
+    return r
+
+
 def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_rows=27, lg_bytes=26):
     global CPU_SAMPLE
     if cpu_sample is not None:
@@ -196,6 +223,9 @@ def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_r
         yield bench_config_g(lg_rows, reps, dv, g, "distinct")
     if want("g_x4"):
         yield bench_config_g(lg_rows, reps, dv, g, "x4")
+    if want("distinct"):
+        for nkeys in (1 << 10, 1 << 20, 1 << lg_rows):
+            yield bench_distinct(lg_rows, reps, dv, g, nkeys)
     if want("g_bytes"):
         yield bench_config_g(lg_bytes, reps, dv, g, "bytes")
 
