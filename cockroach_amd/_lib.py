@@ -133,6 +133,12 @@ SYMBOLS = [
     ("crgpu_route_finish", _I32, [_VP]),
     ("crgpu_route_next_output", _I32, [_VP, _I32, C.POINTER(OutBatch)]),
     ("crgpu_route_free", None, [_VP]),
+    ("crgpu_distinct_new", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _I32, _I32, C.POINTER(_VP)]),
+    ("crgpu_distinct_append", _I32, [_VP, C.POINTER(Batch)]),
+    ("crgpu_distinct_finish", _I32, [_VP]),
+    ("crgpu_distinct_next_output", _I32, [_VP, C.POINTER(OutBatch)]),
+    ("crgpu_distinct_reset", _I32, [_VP]),
+    ("crgpu_distinct_free", None, [_VP]),
 ]
 
 _lib = None

@@ -523,6 +523,85 @@ extern "C" crgpu_status crgpu_agg_next_output(crgpu_ha *h, crgpu_out_batch *out)
   return emit_from_queue(h->outq, out);
 }
 
+// ====================================================================== unordered distinct shell
+struct crgpu_ud {
+  crgpu_distinct *dev = nullptr;
+  std::vector<int> types;
+  std::vector<HostCol> stage;
+  DevTable staged_dev;
+  bool finished = false;
+  std::deque<std::unique_ptr<HostResult>> outq;
+};
+
+extern "C" crgpu_status crgpu_distinct_new(const int32_t *types, int32_t n_cols, const int32_t *distinct_cols,
+                                           int32_t n_distinct, int32_t nulls_are_distinct, int32_t error_on_dup,
+                                           crgpu_ud **out) {
+  if (out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_new: null argument");
+  crgpu_distinct *dev = nullptr;
+  CRGPU_TRY(crgpu_dev_distinct_create(types, n_cols, distinct_cols, n_distinct, nulls_are_distinct, error_on_dup, &dev));
+  auto h = new crgpu_ud();
+  h->dev = dev;
+  for (int i = 0; i < n_cols; i++) h->types.push_back(types[i]);
+  init_cols(h->stage, h->types);
+  *out = h;
+  return CRGPU_OK;
+}
+
+extern "C" void crgpu_distinct_free(crgpu_ud *h) {
+  if (h == nullptr) return;
+  crgpu_dev_distinct_destroy(h->dev);
+  delete h;
+}
+
+extern "C" crgpu_status crgpu_distinct_reset(crgpu_ud *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_reset: null handle");
+  CRGPU_TRY(crgpu_dev_distinct_reset(h->dev));
+  clear_cols(h->stage);
+  h->outq.clear();
+  h->finished = false;
+  return CRGPU_OK;
+}
+
+// staged rows -> device -> the new tuples come back as one host result (input order is kept end to end)
+static crgpu_status ud_flush(crgpu_ud *h) {
+  const int64_t n = h->stage.empty() ? 0 : h->stage[0].n;
+  if (n == 0) return CRGPU_OK;
+  CRGPU_TRY(upload_table(h->stage, h->staged_dev));
+  clear_cols(h->stage);
+  crgpu_dev_result r;
+  const crgpu_status st = crgpu_dev_distinct_consume(h->dev, h->staged_dev.cols.data(), n, &r);
+  if (st != CRGPU_OK && st != CRGPU_ERR_DUPLICATE) return st;
+  if (r.n > 0) {
+    std::unique_ptr<HostResult> hr(new HostResult());
+    CRGPU_TRY(download_result(r, *hr));
+    h->outq.push_back(std::move(hr));
+  }
+  return st;  // CRGPU_ERR_DUPLICATE: errorOnDup plans raise their message; the output is still queued
+}
+
+extern "C" crgpu_status crgpu_distinct_append(crgpu_ud *h, const crgpu_batch *in) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_append: null handle");
+  if (h->finished) return fail(CRGPU_ERR_STATE, "crgpu_distinct_append: input already finished");
+  CRGPU_TRY(stage_batch(h->stage, in));
+  if (!h->stage.empty() && h->stage[0].n >= kFlushRows) CRGPU_TRY(ud_flush(h));
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_distinct_finish(crgpu_ud *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_finish: null handle");
+  h->finished = true;
+  return ud_flush(h);
+}
+
+extern "C" crgpu_status crgpu_distinct_next_output(crgpu_ud *h, crgpu_out_batch *out) {
+  if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_next_output: null argument");
+  out->length = 0;
+  while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
+  // the operator streams (unordered_distinct.go:113-119): nothing queued => push what is staged through the device
+  if (h->outq.empty()) CRGPU_TRY(ud_flush(h));
+  return emit_from_queue(h->outq, out);
+}
+
 // ====================================================================== hash router shell
 struct crgpu_router {
   crgpu_partitioner *dev = nullptr;

@@ -301,6 +301,69 @@ class HashAggregator(Operator):
             self.h = None
 
 
+# ---------------------------------------------------------------- unordered distinct
+class UnorderedDistinct(Operator):
+    """colexec.NewUnorderedDistinct(allocator, input, distinctCols, typs, nullsAreDistinct, errorOnDup)
+    (unordered_distinct.go:22-40): Next() returns the new distinct tuples of the input read so far, in input order."""
+
+    def __init__(self, types, distinct_cols, input: Operator, nulls_are_distinct=False, error_on_dup="",
+                 capacity=cd.BATCH_SIZE, lookahead=1):
+        self.lib = _lib.load()
+        self.input = input
+        self.error_on_dup = error_on_dup
+        self._keep = (_i32(types), _i32(distinct_cols))
+        self.h = C.c_void_p()
+        _lib.check(self.lib.crgpu_distinct_new(self._keep[0], len(types), self._keep[1], len(distinct_cols),
+                                               int(bool(nulls_are_distinct)), int(bool(error_on_dup)), C.byref(self.h)))
+        self.out = _OutBatch(list(types), capacity)
+        self.lookahead = max(1, lookahead)
+        self.state = "reading"
+
+    def init(self):
+        self.input.init()
+
+    def _check(self, st):
+        if st == _lib.ERR_DUPLICATE:  # UpsertDistinctHelper.MaybeEmitErrorOnDup
+            raise DuplicateError(self.error_on_dup)
+        _lib.check(st)
+
+    def next(self):
+        while True:
+            if self.state == "reading":
+                for _ in range(self.lookahead):
+                    b = self.input.next()
+                    if b.length == 0:
+                        self._check(self.lib.crgpu_distinct_finish(self.h))
+                        self.state = "draining"
+                        break
+                    mb, keep = _marshal_batch(b)
+                    self._check(self.lib.crgpu_distinct_append(self.h, C.byref(mb)))
+            out = self.out.call(self._next_output, self.h)
+            if out.length > 0 or self.state == "draining":
+                return out
+
+    def _next_output(self, h, out):
+        st = self.lib.crgpu_distinct_next_output(h, out)
+        if st == _lib.ERR_DUPLICATE:
+            raise DuplicateError(self.error_on_dup)
+        return st
+
+    def reset(self):
+        _lib.check(self.lib.crgpu_distinct_reset(self.h))
+        if hasattr(self.input, "reset"):
+            self.input.reset()
+        self.state = "reading"
+
+    def close(self):
+        if self.h:
+            self.lib.crgpu_distinct_free(self.h)
+            self.h = None
+
+
+class DuplicateError(Exception):
+    """The plan's errorOnDup message (colexecbase.UpsertDistinctHelper)."""
+
+
 # ---------------------------------------------------------------- hash router
 class _RouterOutput(Operator):
     def __init__(self, router, idx):

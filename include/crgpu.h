@@ -335,6 +335,19 @@ crgpu_status crgpu_route_finish(crgpu_router *r);                          /* ze
 crgpu_status crgpu_route_next_output(crgpu_router *r, int32_t output, crgpu_out_batch *out);
 void crgpu_route_free(crgpu_router *r);
 
+/* colexec.NewUnorderedDistinct + UnorderedDistinct.Next (sql/colexec/unordered_distinct.go:22-40,94-121;
+ * constructed at colbuilder/execplan.go:1207).  The operator streams: next_output pushes whatever is staged through
+ * the device when nothing is queued, so output batches hold the new tuples of the input seen so far, in input order.
+ * CRGPU_ERR_DUPLICATE from append/finish/next_output (error_on_dup plans) => the shell raises the plan's message. */
+typedef struct crgpu_ud crgpu_ud;
+crgpu_status crgpu_distinct_new(const int32_t *types, int32_t n_cols, const int32_t *distinct_cols, int32_t n_distinct,
+                                int32_t nulls_are_distinct, int32_t error_on_dup, crgpu_ud **out);
+crgpu_status crgpu_distinct_append(crgpu_ud *h, const crgpu_batch *in);
+crgpu_status crgpu_distinct_finish(crgpu_ud *h); /* input exhausted */
+crgpu_status crgpu_distinct_next_output(crgpu_ud *h, crgpu_out_batch *out);
+crgpu_status crgpu_distinct_reset(crgpu_ud *h);
+void crgpu_distinct_free(crgpu_ud *h);
+
 #ifdef __cplusplus
 }
 #endif

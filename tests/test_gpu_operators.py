@@ -233,3 +233,49 @@ def test_hash_router_known_answer():
     r.run()
     assert [len(drain(o)) for o in r.outputs] == [273, 252, 287, 212]
     r.close()
+
+
+# ---------------------------------------------------------------- unordered distinct (layer 2)
+from tests.test_oracle_distinct import CASES as DISTINCT_CASES, ordered_equal  # noqa: E402
+
+
+@pytest.mark.parametrize("case", DISTINCT_CASES, ids=[c["id"] for c in DISTINCT_CASES])
+def test_unordered_distinct_golden_cases(case):
+    """distinct_test.go:45-330 through the operator boundary: host batches (with and without selection vectors), small
+    output batches, Reset, and the errorOnDup plans."""
+    rng = np.random.default_rng(3)
+    types = [H.type_id(t) for t in case["types"]]
+    cols = H.tuples_to_vecs(case["tuples"], case["types"])
+    for batch_size, use_sel, capacity, lookahead in ((1, False, 1, 1), (2, True, 3, 2), (1024, False, 1024, 1), (3, True, 2, 1)):
+        src = ops.BatchSource(make_batches(cols, batch_size, use_sel, rng), types)
+        ud = ops.UnorderedDistinct(types, case["distinct_cols"], src, case["nulls_are_distinct"], case["error_on_dup"],
+                                   capacity=capacity, lookahead=lookahead)
+        ud.init()
+        if case["error_on_dup"] and not case["no_error"]:
+            with pytest.raises(ops.DuplicateError) as e:
+                drain(ud)
+            assert str(e.value) == case["error_on_dup"]
+            ud.close()
+            continue
+        rows = drain(ud)
+        ordered_equal(rows, case["expected"], f"{case['id']} bs={batch_size} sel={use_sel}")
+        ud.reset()
+        ordered_equal(drain(ud), case["expected"], f"{case['id']} after Reset")
+        ud.close()
+
+
+def test_unordered_distinct_random_vs_oracle(oracle):
+    rng = np.random.default_rng(17)
+    n = 40_000
+    a = rng.integers(0, 300, size=n, dtype=np.int64)
+    s = [bytes([97 + int(x)]) * int(y) for x, y in zip(rng.integers(0, 3, size=n), rng.integers(0, 45, size=n))]
+    f = rng.choice(np.array([0.0, -0.0, 2.5, float("nan")]), size=n)
+    cols = [cd.Vec.from_numpy(cd.INT64, a, rng.random(n) > 0.1), cd.Vec.from_values(cd.BYTES, s),
+            cd.Vec.from_numpy(cd.FLOAT64, f, rng.random(n) > 0.1), cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64))]
+    types = [v.type for v in cols]
+    want, _ = oracle.unordered_distinct(cols, [0, 1, 2])
+    src = ops.BatchSource(make_batches(cols, 1000, True, rng), types)
+    ud = ops.UnorderedDistinct(types, [0, 1, 2], src, capacity=777, lookahead=5)
+    ud.init()
+    ordered_equal(drain(ud), H.vecs_to_tuples(want), "random")
+    ud.close()
