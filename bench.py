@@ -306,7 +306,8 @@ def other_paths(device_index):
             for r in agg.measure(27, ["q1", "1024", str(1 << 27)], reps=3, cpu_sample=1 << 21, device_index=device_index)]
         dec = load("bench_decode").measure(1 << 21, 4, 10 << 20, device_index)
         out["kv_fetch_decode"] = {k: dec[k] for k in ("rows", "input_bytes", "wall_ms", "kv_walk_ms", "kv_decode_ms", "rows_per_s",
-                                                      "input_GBps_wall", "cpu_baseline")}
+                                                      "input_GBps_wall", "q1_pipeline_decode_plus_agg_ms", "q1_pipeline_rows_per_s",
+                                                      "q1_pipeline_checked", "cpu_baseline")}
         import torch
         torch.cuda.empty_cache()
         misc = load("bench_misc")
