@@ -239,6 +239,68 @@ class Partitioner:
             pass
 
 
+CMP = {"EQ": 0, "NE": 1, "LT": 2, "LE": 3, "GT": 4, "GE": 5}
+BIN = {"+": 0, "-": 1, "*": 2, "*(1-)": 3, "*(1+)": 4}
+
+
+def select_i64_const(cmp, col: DeviceColumn, cst, out=None) -> DeviceColumn:
+    """crgpu_dev_select_i64_const: BOOL column, 1 where `col <cmp> cst` holds (NULL never passes).
+    `out`: a DeviceBuffer of >= n bytes to reuse."""
+    out = out or DeviceBuffer(max(col.n, 1))
+    d = col.dcol()
+    _lib.check(_lib.load().crgpu_dev_select_i64_const(CMP[cmp], C.byref(d), int(cst), col.n, out.ptr))
+    return DeviceColumn(cd.BOOL, col.n, out.ptr, None, None, keep=(out, col))
+
+
+def project_f64(op, a, b, out=None) -> DeviceColumn:
+    """crgpu_dev_project_f64: a <op> b over FLOAT64 columns; either operand may be a Python float (constant).
+    `out`: a DeviceBuffer of >= 8 n bytes to reuse."""
+    cols = [x for x in (a, b) if isinstance(x, DeviceColumn)]
+    n = cols[0].n
+    out = out or DeviceBuffer(max(n, 2) * 8)
+    nullable = any(c.valid_ptr for c in cols)
+    valid = DeviceBuffer((n + 7) // 8 + 1) if nullable else None
+    da = a.dcol() if isinstance(a, DeviceColumn) else None
+    db = b.dcol() if isinstance(b, DeviceColumn) else None
+    _lib.check(_lib.load().crgpu_dev_project_f64(BIN[op], C.byref(da) if da is not None else None, 0.0 if da is not None else float(a),
+                                                 C.byref(db) if db is not None else None, 0.0 if db is not None else float(b),
+                                                 n, out.ptr, valid.ptr if valid else None))
+    return DeviceColumn(cd.FLOAT64, n, out.ptr, valid.ptr if valid else None, None, keep=(out, valid, a, b))
+
+
+class FilteredAgg:
+    """Hash aggregation under a WHERE clause without moving rows: the selection's BOOL column becomes the FILTER of
+    every aggregate (group-key ANY_NOT_NULLs excepted) plus a hidden COUNT_ROWS, and groups that no passing row
+    reached are dropped from the result.  Same result as `sel -> hashAggregator` in the reference's plan."""
+
+    def __init__(self, types, group_cols, aggs):
+        self.where = len(types)
+        self.naggs = len(aggs)
+        rewritten = []
+        for a in aggs:
+            f, c = a[0], a[1]
+            flt = a[2] if len(a) > 2 else -1
+            if flt >= 0:
+                raise _lib.CrgpuError(_lib.ERR_UNSUPPORTED, "FilteredAgg: an aggregate with its own FILTER")
+            rewritten.append((f, c, -1) if (f == 0 and c in group_cols) else (f, c, self.where))
+        rewritten.append((14, -1, self.where))  # hidden COUNT_ROWS of the passing rows
+        self.agg = Agg(list(types) + [cd.BOOL], group_cols, rewritten)
+
+    def consume(self, cols, where_col, n=None):
+        self.agg.consume(list(cols) + [where_col], n)
+
+    def finish_vecs(self):
+        vecs = result_to_vecs(self.agg.finish())
+        keep = np.flatnonzero(vecs[-1].data > 0)
+        return [v.take(keep) for v in vecs[:self.naggs]]
+
+    def reset(self):
+        self.agg.reset()
+
+    def close(self):
+        self.agg.close()
+
+
 class Distinct:
     """crgpu_distinct handle (unordered DISTINCT): consume() returns the first occurrences of new tuples, in input order."""
 

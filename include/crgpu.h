@@ -215,6 +215,26 @@ crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgpu_dcol *col
 crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d);
 void crgpu_dev_distinct_destroy(crgpu_distinct *d);
 
+/* ---- selection and projection between the scan and the aggregator (Q1 is
+ * scan -> sel -> 3 projections -> hashAggregator, tpch_vec:20537-20546).  Whole-column device kernels with
+ * caller-provided outputs; calls are ordered on the library stream with every other crgpu_dev_* call and return
+ * without waiting (crgpu_dev_synchronize, or any later blocking call, completes them).
+ *
+ * crgpu_dev_select_i64_const: replaces colexecsel.sel{EQ,NE,LT,LE,GT,GE}Int64Int64ConstOp.Next
+ * (colexecsel/selection_ops.eg.go:5876,25260,34952,...).  cmp: 0 EQ, 1 NE, 2 LT, 3 LE, 4 GT, 5 GE.  Instead of a
+ * selection vector it writes a BOOL column, out_bool[i] = 1 iff row i passes (NULL never passes), to be used as the
+ * FILTER column of every aggregate: no row is moved.
+ *
+ * crgpu_dev_project_f64: replaces colexecproj.proj{Plus,Minus,Mult}Float64Float64Op.Next
+ * (colexecproj/proj_non_const_ops.eg.go:4922,8126,12196) and the constant forms
+ * colexecprojconst.proj{Plus,Minus,Mult}Float64ConstFloat64Op (proj_const_left_ops.eg.go:4515,7503,11295; right
+ * twins in proj_const_right_ops.eg.go).  op: 0 +, 1 -, 2 *, and two pairs of those operators done in one pass with
+ * the same roundings: 3 a * (1 - b), 4 a * (1 + b).  a or b may be NULL: the operand is then the constant.
+ * out_valid (bitmap, (n+7)/8 bytes) = AND of the operands' bitmaps; required when an operand has one. */
+crgpu_status crgpu_dev_select_i64_const(int32_t cmp, const crgpu_dcol *col, int64_t cst, int64_t n, uint8_t *out_bool);
+crgpu_status crgpu_dev_project_f64(int32_t op, const crgpu_dcol *a, double a_const, const crgpu_dcol *b, double b_const,
+                                   int64_t n, double *out_data, uint8_t *out_valid);
+
 /* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for indexes that store one KV per
  * row (MaxKeysPerRow == 1 fast path, sql/colfetcher/cfetcher.go:758-1093,937-941) together with
  * colencoding.DecodeKeyValsToCols (colencoding/key_encoding.go:43), processValueBytes

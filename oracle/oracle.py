@@ -205,6 +205,30 @@ def unordered_distinct(cols, distinct_cols, nulls_are_distinct=False, batch_size
     return _result_to_vecs(res), bool(dropped.value)
 
 
+def select_i64_const(cmp, vec, cst):
+    """colexecsel.sel<CMP>Int64Int64ConstOp (selection_ops.eg.go:34952 for LE): the indices that stay selected, in
+    order.  A NULL never passes (:34971)."""
+    v = vec.data.astype(np.int64)
+    r = {"EQ": v == cst, "NE": v != cst, "LT": v < cst, "LE": v <= cst, "GT": v > cst, "GE": v >= cst}[cmp]
+    return np.flatnonzero(r & vec.present())
+
+
+def project_f64(op, a, b):
+    """colexecproj.proj{Plus,Minus,Mult}Float64Float64Op and the constant forms (proj_non_const_ops.eg.go:4922,8126,
+    12196; proj_const_left_ops.eg.go:4515,7503,11295): IEEE double arithmetic row by row, NULL if an operand is NULL."""
+    vecs = [x for x in (a, b) if isinstance(x, cd.Vec)]
+    n = len(vecs[0])
+    x = a.data if isinstance(a, cd.Vec) else np.full(n, float(a))
+    y = b.data if isinstance(b, cd.Vec) else np.full(n, float(b))
+    with np.errstate(all="ignore"):
+        r = {"+": lambda: x + y, "-": lambda: x - y, "*": lambda: x * y,
+             "*(1-)": lambda: x * (1.0 - y), "*(1+)": lambda: x * (1.0 + y)}[op]()  # the last two: two operators in a row
+    pres = np.ones(n, dtype=bool)
+    for v in vecs:
+        pres &= v.present()
+    return cd.Vec.from_numpy(cd.FLOAT64, r, None if pres.all() else pres)
+
+
 def set_test_hash(mapping):
     """Inject h(value) for the reference's worked examples; {} resets."""
     vals = np.array(list(mapping.keys()), dtype=np.int64)

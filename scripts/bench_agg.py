@@ -67,6 +67,67 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
             "cpu_baseline": cpu_baseline(cols, group_cols, aggs, n) if CPU_SAMPLE else None}
 
 
+def run_q1_full(n, dv, g, rf, ls, offs, f, reps):
+    """Config Q1 as SURVEY.md 8(d) words it: WHERE l_shipdate <= cutoff (~98.6 % pass), disc_price = price * (1 - disc),
+    charge = disc_price * (1 + tax), GROUP BY (returnflag, linestatus): SUM(qty), SUM(price), SUM(disc_price),
+    SUM(charge), AVG(qty), AVG(price), AVG(disc), COUNT_ROWS.  42 B/row of input.  The selection is a BOOL column used
+    as every aggregate's FILTER (no row moves); two projection kernels (each two reference operators in one pass) write dense columns."""
+    ship = torch.randint(8036, 10562, (n,), generator=g, device=dv, dtype=torch.int64)  # 1992-01-02 .. 1998-12-01 in days
+    cutoff = 10562 - 36  # passes ~98.6 %
+    qty, price, disc, tax = f
+    base = [dev.from_torch(cd.INT64, ship), dev.from_torch(cd.BYTES, rf, offsets=offs), dev.from_torch(cd.BYTES, ls, offsets=offs)] + \
+           [dev.from_torch(cd.FLOAT64, x) for x in (qty, price, disc, tax)]
+    types = [cd.INT64, cd.BYTES, cd.BYTES] + [cd.FLOAT64] * 6 + [cd.BOOL]
+    W = 9
+    aggs = [(0, 1, -1), (0, 2, -1), (10, 3, W), (10, 4, W), (10, 7, W), (10, 8, W), (1, 3, W), (1, 4, W), (1, 5, W), (14, -1, W)]
+    torch.cuda.synchronize()
+    a = dev.Agg(types, [1, 2], aggs)
+
+    bufs = [dev.DeviceBuffer(n), dev.DeviceBuffer(n * 8), dev.DeviceBuffer(n * 8)]  # the operator's output vectors, reused per batch
+
+    def once():
+        where = dev.select_i64_const("LE", base[0], cutoff, out=bufs[0])
+        disc_price = dev.project_f64("*(1-)", base[4], base[5], out=bufs[1])   # price * (1 - disc)
+        charge = dev.project_f64("*(1+)", disc_price, base[6], out=bufs[2])    # disc_price * (1 + tax)
+        a.consume(base + [disc_price, charge, where], n)
+        res = a.finish()
+        ng = int(res.n)
+        a.reset()
+        return ng
+
+    ngroups = once()
+    _lib.load().crgpu_dev_synchronize()
+    dev.prof_enable(True); dev.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    _lib.load().crgpu_dev_synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kern = {}
+    for k in ("expr_select", "expr_project", "agg_fused_lds", "agg_resolve", "agg_fixup", "agg_accum_lds"):
+        ms, cnt = dev.prof_get(k)
+        if cnt:
+            kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
+    a.close()
+    cpu = None
+    if CPU_SAMPLE:
+        from oracle import oracle as O
+        m = min(n, CPU_SAMPLE)
+        host = [to_host_vec(c, m) for c in base]
+        t1 = time.perf_counter()
+        keep = O.select_i64_const("LE", host[0], cutoff)
+        sel = [v.take(keep) for v in host]
+        dp = O.project_f64("*", sel[4], O.project_f64("-", 1.0, sel[5]))
+        ch = O.project_f64("*", dp, O.project_f64("+", 1.0, sel[6]))
+        O.hash_agg(sel + [dp, ch], [1, 2], [(x[0], x[1], -1) for x in aggs])
+        cdt = time.perf_counter() - t1
+        cpu = {"value": m / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"first {m} rows: numpy selection + projections, then oracle/crdb_oracle.c hashAggregator (1 thread)"}
+    return {"case": "Q1 full: WHERE shipdate <= c, 2 projected columns, GROUP BY 2 bytes keys, 4 SUM + 3 AVG + COUNT_ROWS", "rows": n,
+            "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt, "alg_GBps": n * 42.0 / dt / 1e9, "frac_of_8TBps": n * 42.0 / dt / 8e12,
+            "kernels": kern, "cpu_baseline": cpu}
+
+
 def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
     """Yields one result dict per case (bench.py reports a few of them beside the join line)."""
     global CPU_SAMPLE
@@ -87,6 +148,8 @@ def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
     aggs = [(0, 0, -1), (0, 1, -1), (10, 2, -1), (10, 3, -1), (10, 4, -1), (10, 5, -1), (1, 2, -1), (1, 3, -1), (1, 4, -1), (14, -1, -1)]
     if only is None or "q1" in only:
         yield run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0, reps=reps)
+    if only is None or "q1full" in only:
+        yield run_q1_full(n, dv, g, rf, ls, offs, f, reps)
     del cols, f, rf, ls
     for groups in (1 << 10, 1 << 13, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 21, 1 << 22, 1 << 24, n):
         if groups > n or (only is not None and str(groups) not in only):

@@ -1,0 +1,100 @@
+"""Selection / projection kernels (cockroach_amd/csrc/expr.hip) through the C-ABI against the
+oracle's restatement, the one literal case the reference holds for these overloads (selection_ops_test.go:28-41:
+{0},{1},{2},{NULL} < 2 keeps {0},{1}), and the Q1 plan `sel -> projections -> hash aggregation` against the oracle
+run the reference's way (selection first, then aggregation of the surviving rows).  The FLOAT64 +,-,* overloads have
+no literal vectors in the reference (only Div and the integer Plus do): they are IEEE double operations, compared
+bit for bit with numpy."""
+import numpy as np
+import pytest
+
+from cockroach_amd import coldata as cd
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_select_reference_case_and_random(oracle):
+    from cockroach_amd import device as dev
+    v = cd.Vec.from_values(cd.INT64, [0, 1, 2, None])
+    got = dev.select_i64_const("LT", dev.upload(v), 2)
+    assert dev.download(got.data_ptr, np.uint8, 4).tolist() == [1, 1, 0, 0]
+    assert oracle.select_i64_const("LT", v, 2).tolist() == [0, 1]
+    rng = np.random.default_rng(4)
+    n = 100_003
+    x = cd.Vec.from_numpy(cd.INT64, rng.integers(-50, 50, size=n, dtype=np.int64), rng.random(n) > 0.1)
+    for cmp in ("EQ", "NE", "LT", "LE", "GT", "GE"):
+        col = dev.select_i64_const(cmp, dev.upload(x), 7)  # keep the column alive: it owns the device buffer
+        got = dev.download(col.data_ptr, np.uint8, n)
+        assert np.flatnonzero(got).tolist() == oracle.select_i64_const(cmp, x, 7).tolist(), cmp
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 100_001])
+def test_project_f64_bit_exact(oracle, n):
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(n)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e308, -1e308, 5e-324])
+    a = np.where(rng.random(n) < 0.1, rng.choice(special, n), rng.normal(size=n) * 1e3)
+    b = np.where(rng.random(n) < 0.1, rng.choice(special, n), rng.normal(size=n))
+    va = cd.Vec.from_numpy(cd.FLOAT64, a, rng.random(n) > 0.2)
+    vb = cd.Vec.from_numpy(cd.FLOAT64, b)
+    da, db = dev.upload(va), dev.upload(vb)
+    for op in ("+", "-", "*", "*(1-)", "*(1+)"):
+        for x, y, dx, dy in ((va, vb, da, db), (1.0, vb, 1.0, db), (va, 0.25, da, 0.25), (vb, vb, db, db)):
+            got = dev.project_f64(op, dx, dy)
+            want = oracle.project_f64(op, x, y)
+            g = dev.download(got.data_ptr, np.float64, n)
+            pres = want.present()
+            gp, wp = g[pres], want.data[pres]
+            nan = np.isnan(wp)
+            assert np.array_equal(np.isnan(gp), nan), (op, "NaN positions")
+            assert np.array_equal(gp[~nan].view(np.uint64), wp[~nan].view(np.uint64)), (op, "bit patterns")  # incl. -0.0, inf
+            if got.valid_ptr:
+                bm = dev.download(got.valid_ptr, np.uint8, (n + 7) // 8)
+                assert np.array_equal(np.unpackbits(bm, bitorder="little")[:n].astype(bool), pres)
+            else:
+                assert pres.all()
+
+
+def test_q1_plan_select_project_aggregate_vs_oracle(oracle):
+    """tpch_vec:20537-20546: WHERE l_shipdate <= c; disc_price = price * (1 - disc); charge = disc_price * (1 + tax);
+    GROUP BY returnflag, linestatus with SUMs, AVGs and COUNT_ROWS.  A (returnflag, linestatus) pair whose rows all
+    fail the WHERE must not appear."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(8)
+    n = 200_000
+    ship = rng.integers(8000, 10600, size=n, dtype=np.int64)
+    rf = rng.integers(0, 3, size=n)
+    ls = rng.integers(0, 2, size=n)
+    ship[(rf == 2) & (ls == 1)] = 11_000  # this group never passes
+    cols = [cd.Vec.from_numpy(cd.INT64, ship, rng.random(n) > 0.01),
+            cd.Vec.from_values(cd.BYTES, [b"ANR"[i:i + 1] for i in rf]), cd.Vec.from_values(cd.BYTES, [b"FO"[i:i + 1] for i in ls]),
+            cd.Vec.from_numpy(cd.FLOAT64, rng.integers(1, 51, size=n).astype(np.float64)),
+            cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.random(n) * 1e5, 2), rng.random(n) > 0.02),
+            cd.Vec.from_numpy(cd.FLOAT64, rng.integers(0, 11, size=n) / 100.0),
+            cd.Vec.from_numpy(cd.FLOAT64, rng.integers(0, 9, size=n) / 100.0)]
+    cutoff = 10_471
+    aggs = [(0, 1, -1), (0, 2, -1), (10, 3, -1), (10, 4, -1), (10, 7, -1), (10, 8, -1), (1, 3, -1), (1, 4, -1), (1, 5, -1), (14, -1, -1)]
+    # the reference's order of operations, on the CPU
+    keep = oracle.select_i64_const("LE", cols[0], cutoff)
+    sel = [v.take(keep) for v in cols]
+    disc_price = oracle.project_f64("*", sel[4], oracle.project_f64("-", 1.0, sel[5]))
+    charge = oracle.project_f64("*", disc_price, oracle.project_f64("+", 1.0, sel[6]))
+    want = oracle.hash_agg(sel + [disc_price, charge], [1, 2], aggs)
+    # the device plan: nothing is moved, the selection is a FILTER
+    d = [dev.upload(v) for v in cols]
+    where = dev.select_i64_const("LE", d[0], cutoff)
+    g_disc_price = dev.project_f64("*", d[4], dev.project_f64("-", 1.0, d[5]))
+    g_charge = dev.project_f64("*", g_disc_price, dev.project_f64("+", 1.0, d[6]))
+    fa = dev.FilteredAgg([v.type for v in cols] + [cd.FLOAT64, cd.FLOAT64], [1, 2], aggs)
+    half = n // 2
+    for lo, hi in ((0, half), (half, n)):
+        part = [dev.upload(v.slice(lo, hi)) for v in cols]
+        w = dev.select_i64_const("LE", part[0], cutoff)
+        dp = dev.project_f64("*", part[4], dev.project_f64("-", 1.0, part[5]))
+        ch = dev.project_f64("*", dp, dev.project_f64("+", 1.0, part[6]))
+        fa.consume(part + [dp, ch], w, hi - lo)
+    got = fa.finish_vecs()
+    fa.close()
+    assert len(got[0]) == 5, "the group whose rows all fail the WHERE must be dropped"
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "Q1 plan")
+    del where, g_charge
