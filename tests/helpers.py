@@ -92,6 +92,8 @@ def _val_eq(a, b):
         a, b = float(a), float(b)
         if math.isnan(a) or math.isnan(b):
             return math.isnan(a) and math.isnan(b)
+        if math.isinf(a) or math.isinf(b):
+            return a == b
         return abs(a - b) <= max(FLOAT_ABS_TOL, FLOAT_REL_TOL * max(abs(a), abs(b)))
     return a == b
 
