@@ -286,7 +286,7 @@ def main():
 
 
 def other_paths(device_index):
-    """Hash aggregation (Q1 shape, 1024 groups, all-distinct = config G shape; 2^27 rows) and KV fetch decode
+    """Hash aggregation (Q1 shape, Q1 in full with its WHERE and projections, 1024 and 2^20 groups, all-distinct = config G shape; 2^27 rows) and KV fetch decode
     (lineitem-shaped rows, 10 MiB batch responses), inputs resident in HBM, each with the single-threaded CPU port
     timed on a bounded sample; then SURVEY.md 8(d)'s sub-measurements: hash only, build only, the router's repartition
     and the config G variants.  scripts/bench_agg.py, bench_decode.py and bench_misc.py are the standalone forms."""
@@ -303,7 +303,7 @@ def other_paths(device_index):
         agg = load("bench_agg")
         out["hash_aggregation"] = [
             {k: r[k] for k in ("case", "rows", "groups", "ms", "rows_per_s", "frac_of_8TBps", "cpu_baseline")}
-            for r in agg.measure(27, ["q1", "1024", str(1 << 27)], reps=3, cpu_sample=1 << 21, device_index=device_index)]
+            for r in agg.measure(27, ["q1", "q1full", "1024", str(1 << 20), str(1 << 27)], reps=3, cpu_sample=1 << 21, device_index=device_index)]
         dec = load("bench_decode").measure(1 << 21, 4, 10 << 20, device_index)
         out["kv_fetch_decode"] = {k: dec[k] for k in ("rows", "input_bytes", "wall_ms", "kv_walk_ms", "kv_decode_ms", "rows_per_s",
                                                       "input_GBps_wall", "q1_pipeline_decode_plus_agg_ms", "q1_pipeline_rows_per_s",
