@@ -824,41 +824,77 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
 #pragma unroll
       for (int k = 0; k < kAccRows; k++) ok[k] = i0 + k * stride < a.m;
       pack_rows<kAccRows>(a.keys, a.pack, row, ok, k0, k1);
+      // First probe of all rows as straight-line code (unconditional LDS reads, selects): the key table is at most
+      // half full, so nearly every row is decided here; the probe loop runs only behind a wave-uniform test.  (The
+      // per-row loop with its breaks cost more scalar exec-mask instructions than everything else in the pass.)
+      uint32_t idx[kAccRows], g0[kAccRows];
+      unsigned long long q0[kAccRows], q1[kAccRows];
+      bool need[kAccRows], more = false;
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) idx[k] = pk_hash(k0[k], k1[k]) & (a.C - 1);
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) g0[k] = t_gid[idx[k]];
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) q0[k] = t_k0[idx[k]];
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) q1[k] = a.pack.two_words ? t_k1[idx[k]] : k1[k];
 #pragma unroll
       for (int k = 0; k < kAccRows; k++) {
-        if (!ok[k]) continue;
-        uint32_t idx = pk_hash(k0[k], k1[k]) & (a.C - 1);
-        for (;;) {
-          const uint32_t g = t_gid[idx];
-          if (g == kGidDefer) break;
-          if (t_k0[idx] == k0[k] && (!a.pack.two_words || t_k1[idx] == k1[k])) {
-            gid[k] = g;
-            break;
+        const bool occupied = ok[k] && g0[k] != kGidDefer;
+        const bool hit = occupied && q0[k] == k0[k] && q1[k] == k1[k];
+        gid[k] = hit ? g0[k] : kGidDefer;
+        need[k] = occupied && !hit;
+        more |= need[k];
+      }
+      if (__any(more)) {
+#pragma unroll
+        for (int k = 0; k < kAccRows; k++) {
+          if (!need[k]) continue;
+          uint32_t ix = (idx[k] + 1) & (a.C - 1);
+          for (;;) {
+            const uint32_t g = t_gid[ix];
+            if (g == kGidDefer) break;
+            if (t_k0[ix] == k0[k] && (!a.pack.two_words || t_k1[ix] == k1[k])) {
+              gid[k] = g;
+              break;
+            }
+            ix = (ix + 1) & (a.C - 1);
           }
-          idx = (idx + 1) & (a.C - 1);
         }
       }
     }
+    if (FUSED) {
+      // rows the key table did not decide (unpackable key, group not in the table, new key): rare, so the whole
+      // block sits behind one wave-uniform test instead of one divergent region per row
+      bool open_rows = false;
 #pragma unroll
-    for (int k = 0; k < kAccRows; k++) {
-      const bool active = i0 + k * stride < a.m;
-      if (FUSED) {
-        if (active && gid[k] == kGidDefer) gid[k] = index_lookup(a.keys, row[k], store, a.meta, a.mask);
-        const bool miss = active && gid[k] == kGidDefer;
-        const uint64_t mm = a.record_misses ? __ballot(miss) : 0;
-        if (mm) {
-          const int lead = __ffsll(static_cast<long long>(mm)) - 1;
-          unsigned int base = 0;
-          if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(mm)));
-          base = __shfl(base, lead, 64);
-          if (miss) a.miss_list[base + rank_in_mask(mm)] = static_cast<uint32_t>(row[k]);
+      for (int k = 0; k < kAccRows; k++) open_rows |= i0 + k * stride < a.m && gid[k] == kGidDefer;
+      if (__any(open_rows)) {
+#pragma unroll
+        for (int k = 0; k < kAccRows; k++) {
+          const bool active = i0 + k * stride < a.m;
+          if (active && gid[k] == kGidDefer) gid[k] = index_lookup(a.keys, row[k], store, a.meta, a.mask);
+          const bool miss = active && gid[k] == kGidDefer;
+          const uint64_t mm = a.record_misses ? __ballot(miss) : 0;
+          if (mm) {
+            const int lead = __ffsll(static_cast<long long>(mm)) - 1;
+            unsigned int base = 0;
+            if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(mm)));
+            base = __shfl(base, lead, 64);
+            if (miss) a.miss_list[base + rank_in_mask(mm)] = static_cast<uint32_t>(row[k]);
+          }
         }
-      } else if (gid[k] != kGidDefer && (gid[k] & kGidSlotRef)) {
-        gid[k] = static_cast<uint32_t>(a.meta[gid[k] & ~kGidSlotRef]);
       }
-      if (LDS && gid[k] != kGidDefer) {
-        gid[k] -= a.gid_lo;
-        if (gid[k] >= a.G) gid[k] = kGidDefer;  // another sweep's group (unsigned compare covers gid < gid_lo)
+    } else {
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++)
+        if (gid[k] != kGidDefer && (gid[k] & kGidSlotRef)) gid[k] = static_cast<uint32_t>(a.meta[gid[k] & ~kGidSlotRef]);
+    }
+    if (LDS) {
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) {
+        const uint32_t rel = gid[k] - a.gid_lo;  // another sweep's group: the unsigned compare also covers gid < gid_lo
+        gid[k] = gid[k] != kGidDefer && rel < a.G ? rel : kGidDefer;
       }
     }
     uint32_t gr[kAccRows];  // LDS: position of the row's group inside a plane
@@ -2127,7 +2163,10 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, b
     p.G = static_cast<uint32_t>(ngroups);
     size_t table = 0;
     if (fused && a->pack.enabled) {
-      const uint32_t C = static_cast<uint32_t>(next_pow2(static_cast<uint64_t>(ngroups) * 2 < 16 ? 16 : static_cast<uint64_t>(ngroups) * 2));
+      // at most half full; small tables are kept sparser (<= 1/4, >= 64 slots) so that the first probe decides
+      uint64_t want_c = static_cast<uint64_t>(ngroups) * 2;
+      if (ngroups <= 2048) want_c = static_cast<uint64_t>(ngroups) * 4 < 64 ? 64 : static_cast<uint64_t>(ngroups) * 4;
+      const uint32_t C = static_cast<uint32_t>(next_pow2(want_c));
       const size_t bytes = static_cast<size_t>(C) * (a->pack.two_words ? 20 : 12) + 8;
       if (total + bytes <= kLdsMax - 1024) {
         p.pk = true;
