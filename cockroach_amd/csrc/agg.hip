@@ -355,6 +355,16 @@ __device__ __forceinline__ void pack_rows(const KeyCols &keys, const PackSpec &p
           break;
       }
     }
+    if (x.valid == nullptr) {  // no NULLs in this column: no per-row branch at all
+      if (pc.word) {
+#pragma unroll
+        for (int k = 0; k < K; k++) k1[k] |= v[k] << pc.shift;
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; k++) k0[k] |= v[k] << pc.shift;
+      }
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < K; k++) {
       unsigned long long f0 = 0, f1 = 0;
