@@ -12,9 +12,14 @@
 //    output (device-to-device, coalesced).
 //  * The hash index is an open-addressing array of 64-bit entries {tag:23 | null mask:8 | gid:32}, at most half full
 //    (capacity is ensured before a batch, so linear probing always ends).  While a batch is resolved an entry may hold
-//    {claim bit | tag | mask | row position}: rows of the same key compare against the claimant's ROW (inputs are
-//    immutable during the call) and lower the entry to the SMALLEST position with a 64-bit atomicMin, which is what
-//    makes the emitted row the first occurrence without any ordering between workgroups.
+//    {tag | mask | store rows before the batch + row position}: rows of the same key compare against the claimant's ROW
+//    (inputs are immutable during the call) and lower the entry to the SMALLEST position with a 64-bit atomicMin, which
+//    is what makes the emitted row the first occurrence without any ordering between workgroups.
+//  * An entry of the current batch is recognised by its position (>= the store's row count before the batch), so when
+//    most rows of a batch are new the batch's key columns are appended to the store WHOLE and the entries are already
+//    final: no pass rewrites them (the random 8-byte index write per new key was a third of the all-distinct case).
+//    Rows of such a batch that were duplicates occupy store rows nothing points to; batches with few new keys append
+//    only those (compacted) and a small publish pass renumbers their entries.
 //  * nullsAreDistinct (UPSERT plans): a row with a NULL among its distinct columns never matches anything; it is
 //    emitted and not inserted (hashtable.go allowNullEquality=false).
 //
@@ -28,8 +33,8 @@
 namespace crgpu {
 
 static constexpr unsigned long long kDEmpty = ~0ull;
-static constexpr uint32_t kDClaim = 0x80000000u;
 static constexpr uint32_t kDNone = 0xFFFFFFFFu;
+static constexpr uint32_t kDLost = 0xFFFFFFFEu;  // slot_of: the row saw an earlier row of its key in this batch
 static constexpr uint32_t kDMaxCap = 1u << 30;
 
 struct DHash {
@@ -90,8 +95,11 @@ struct DResolveArgs {
   unsigned long long *meta;
   uint32_t mask;
   int32_t nulls_are_distinct;
+  int32_t write_words;  // the batch may join the store whole: every row leaves its hash word (or kDEmpty) at gword[base + i]
+  uint32_t base;      // store rows before this batch: an entry >= base names row (entry - base) of the batch
   uint32_t *slot_of;  // [n] index slot the row ended at (kDNone: repeats a stored key, or bypasses the table)
   uint8_t *flags;     // [n] preset for rows that bypass the table
+  unsigned long long *gword;  // [base + i] hash word of every row (kDEmpty: never indexed); see the mark kernel
 };
 __global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -99,10 +107,13 @@ __global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
     const DHash h = distinct_hash(a.keys, i);
     uint32_t slot = kDNone;
     uint8_t flag = 0;
+    unsigned long long word = (static_cast<unsigned long long>(h.upper) << 32) | h.idx;
     if (a.nulls_are_distinct && (h.upper & 0xFFu) != 0) {
       flag = 1;  // never equal to anything, never looked up
+      word = kDEmpty;
     } else {
-      const unsigned long long claim = (static_cast<unsigned long long>(h.upper | kDClaim) << 32) | static_cast<uint32_t>(i);
+      const uint32_t me = a.base + static_cast<uint32_t>(i);
+      const unsigned long long claim = (static_cast<unsigned long long>(h.upper) << 32) | me;
       uint32_t idx = h.idx & a.mask;
       for (;;) {  // ends: the index is at most half full (ensured by the host before the launch)
         unsigned long long e = __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -112,36 +123,47 @@ __global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
           break;
         }
         const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
-        if ((up & ~kDClaim) == h.upper) {
-          if (up & kDClaim) {
-            if (keys_equal(a.keys, i, a.keys, static_cast<int64_t>(lo), true)) {
+        if (up == h.upper) {
+          if (lo >= a.base) {  // claimed in this batch
+            if (keys_equal(a.keys, i, a.keys, static_cast<int64_t>(lo - a.base), true)) {
               // same upper word: the smallest position wins.  An entry only ever decreases, so a row behind the
               // position it just read has nothing to do (with few distinct keys nearly every row: without this test
               // 2^27 rows over 1024 keys took 26.7 ms in contended atomics)
-              if (static_cast<uint32_t>(i) < lo) atomicMin(&a.meta[idx], claim);
-              slot = idx;
+              if (me < lo) {
+                atomicMin(&a.meta[idx], claim);
+                slot = idx;
+              } else {
+                slot = kDLost;
+                word = kDEmpty;
+              }
               break;
             }
           } else if (row_equals_store(a.keys, i, a.store, lo, h.upper & 0xFFu)) {
+            word = kDEmpty;
             break;  // seen in an earlier batch
           }
         }
         idx = (idx + 1) & a.mask;
       }
     }
+    if (a.write_words) a.gword[a.base + i] = word;
     a.slot_of[i] = slot;
     a.flags[i] = flag;
   }
 }
 
-// a row is emitted iff its entry ended up holding its own position
+// a row is emitted iff its entry ended up holding its own position; the hash words of the rows that are not keep
+// them out of any later index rebuild (this matters when the batch is appended to the store whole)
 __global__ __launch_bounds__(256) void distinct_mark_kernel(const unsigned long long *__restrict__ meta,
-                                                            const uint32_t *__restrict__ slot_of, int64_t n,
-                                                            uint8_t *__restrict__ flags) {
+                                                            const uint32_t *__restrict__ slot_of, int64_t n, uint32_t base,
+                                                            uint8_t *__restrict__ flags, unsigned long long *__restrict__ gword) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint32_t s = slot_of[i];
-    if (s != kDNone) flags[i] = static_cast<uint32_t>(meta[s]) == static_cast<uint32_t>(i) ? 1 : 0;
+    if (s >= kDLost) continue;  // decided in the resolve kernel (flag and hash word already final)
+    const bool mine = static_cast<uint32_t>(meta[s]) == base + static_cast<uint32_t>(i);
+    flags[i] = mine ? 1 : 0;
+    if (!mine && gword != nullptr) gword[base + i] = kDEmpty;  // lost the entry to an earlier row after claiming it
   }
 }
 
@@ -172,11 +194,11 @@ __global__ __launch_bounds__(256) void distinct_reindex_kernel(const unsigned lo
   }
 }
 
-// BYTES key store append: offsets of the output column rebased onto the store's tail
-__global__ __launch_bounds__(256) void distinct_append_offsets_kernel(const uint32_t *__restrict__ out_offsets, int64_t m,
-                                                                      uint32_t base, uint32_t *__restrict__ dst) {
+// BYTES key store append (the output's key column, or the batch's when it is appended whole): dst[j] = tail + (src[j] - src[0])
+__global__ __launch_bounds__(256) void distinct_rebase_offsets_kernel(const uint32_t *__restrict__ src, int64_t n, uint32_t first,
+                                                                      uint32_t tail, uint32_t *__restrict__ dst) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j <= m; j += stride) dst[j] = base + out_offsets[j];
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j <= n; j += stride) dst[j] = tail + (src[j] - first);
 }
 
 static inline int dgrid(int64_t n) {
@@ -193,8 +215,9 @@ using namespace crgpu;
 struct crgpu_distinct {
   std::vector<int> types, dcols;
   bool nulls_are_distinct = false, error_on_dup = false;
+  bool expect_new = true;  // the last batch was mostly new keys (the first one is assumed to be)
   uint32_t cap = 0;      // index entries
-  uint32_t ngroups = 0;  // keys stored
+  uint32_t ngroups = 0;  // rows of the key store (the keys seen so far, plus the duplicates inside batches appended whole)
   size_t gcap = 0;       // key store capacity (keys)
   DevBuf meta, gword, slot_of, flags, idx, scratch;
   struct KS { DevBuf data, offsets; uint64_t tail = 0; };
@@ -274,6 +297,7 @@ extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
   hipStream_t st = stream();
   if (d->cap) CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(d->cap) * 8, st));
   d->ngroups = 0;
+  d->expect_new = true;
   for (auto &k : d->ks) k->tail = 0;
   CRGPU_HIP(hipStreamSynchronize(st));
   return CRGPU_OK;
@@ -296,7 +320,8 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
     }
     in.push_back(x);
   }
-  int64_t m = 0;
+  int64_t m = 0, m_store = 0;
+  bool whole = false;
   if (n > 0) {
     CRGPU_TRY(distinct_ensure(d, static_cast<size_t>(d->ngroups) + static_cast<size_t>(n)));
     CRGPU_TRY(d->slot_of.ensure(static_cast<size_t>(n) * 4));
@@ -313,6 +338,9 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
     a.meta = d->meta.as<unsigned long long>();
     a.mask = d->cap - 1;
     a.nulls_are_distinct = d->nulls_are_distinct ? 1 : 0;
+    a.base = d->ngroups;
+    a.gword = d->gword.as<unsigned long long>();
+    a.write_words = d->expect_new ? 1 : 0;
     a.slot_of = d->slot_of.as<uint32_t>();
     a.flags = d->flags.as<uint8_t>();
     {
@@ -320,11 +348,16 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
       hipLaunchKernelGGL(distinct_resolve_kernel, dim3(dgrid(n)), dim3(256), 0, st, a);
       CRGPU_HIP(hipGetLastError());
       hipLaunchKernelGGL(distinct_mark_kernel, dim3(dgrid(n)), dim3(256), 0, st, d->meta.as<unsigned long long>(),
-                         d->slot_of.as<uint32_t>(), n, d->flags.as<uint8_t>());
+                         d->slot_of.as<uint32_t>(), n, d->ngroups, d->flags.as<uint8_t>(),
+                         d->expect_new ? d->gword.as<unsigned long long>() : nullptr);
       CRGPU_HIP(hipGetLastError());
     }
     CRGPU_TRY(select_flagged(d->flags.as<uint8_t>(), n, d->idx.as<int32_t>(), d->scratch, &m));
-    if (m > 0) {
+    // most rows are new: the batch's key columns join the store as they are and the entries are final -- possible only
+    // if the rows left their hash words, which they do when the previous batch (or nothing yet) suggested it
+    whole = d->expect_new && m * 2 > n;
+    d->expect_new = m * 2 > n;
+    if (m > 0 && !whole) {
       ProfScope prof("distinct_publish");
       hipLaunchKernelGGL(distinct_publish_kernel, dim3(dgrid(m)), dim3(256), 0, st, d->idx.as<int32_t>(), m,
                          d->slot_of.as<uint32_t>(), d->ngroups, a.keys, d->meta.as<unsigned long long>(),
@@ -350,28 +383,36 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
       }
     }
   }
-  // the key store grows by the distinct columns of the output
+  // the key store grows by the distinct columns of the output -- or of the whole batch
   for (size_t k = 0; m > 0 && k < d->dcols.size(); k++) {
     const OutCol &o = d->out[d->dcols[k]];
+    const DCol &x = in[d->dcols[k]];
     crgpu_distinct::KS &s = *d->ks[k];
+    const int64_t rows = whole ? n : m;
     if (o.type == CRGPU_BYTES) {
-      uint32_t total = 0;
-      CRGPU_HIP(hipMemcpyAsync(&total, o.offsets.as<uint32_t>() + m, 4, hipMemcpyDeviceToHost, st));
+      const uint32_t *offs = whole ? x.offsets : o.offsets.as<uint32_t>();
+      const uint8_t *bytes = whole ? static_cast<const uint8_t *>(x.data) : o.data.as<uint8_t>();
+      uint32_t ends[2] = {0, 0};
+      CRGPU_HIP(hipMemcpyAsync(&ends[0], offs, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(&ends[1], offs + rows, 4, hipMemcpyDeviceToHost, st));
       CRGPU_HIP(hipStreamSynchronize(st));
+      const uint32_t total = ends[1] - ends[0];
       if (s.tail + total > 0xFFFFFFFFull) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_consume: more than 4 GiB of BYTES keys");
       CRGPU_TRY(s.data.ensure(static_cast<size_t>(s.tail + total + 16), true));
-      if (total) CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + s.tail, o.data.p, total, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(distinct_append_offsets_kernel, dim3(dgrid(m + 1)), dim3(256), 0, st, o.offsets.as<uint32_t>(), m,
+      if (total) CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + s.tail, bytes + ends[0], total, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(distinct_rebase_offsets_kernel, dim3(dgrid(rows + 1)), dim3(256), 0, st, offs, rows, ends[0],
                          static_cast<uint32_t>(s.tail), s.offsets.as<uint32_t>() + d->ngroups);
       CRGPU_HIP(hipGetLastError());
       s.tail += total;
     } else {
       const size_t w = static_cast<size_t>(type_width(o.type));
-      CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + static_cast<size_t>(d->ngroups) * w, o.data.p, static_cast<size_t>(m) * w,
-                               hipMemcpyDeviceToDevice, st));
+      CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + static_cast<size_t>(d->ngroups) * w, whole ? x.data : o.data.p,
+                               static_cast<size_t>(rows) * w, hipMemcpyDeviceToDevice, st));
     }
   }
-  d->ngroups += static_cast<uint32_t>(m);
+  if (whole) m_store = n;
+  else m_store = m;
+  d->ngroups += static_cast<uint32_t>(m_store);
   CRGPU_HIP(hipStreamSynchronize(st));
   for (int c = 0; c < nc; c++) d->views[c] = d->out[c].view();
   res->n = m;
