@@ -97,6 +97,43 @@ def bench_build(lg, reps, dv, g):
     return _line(f"build only: config J build side, 2^{lg} unique int64 keys + int64 payload", n, dt, n * 16.0, kern, None)
 
 
+def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
+    """The general (chained) join path: duplicate build keys, so the packed / radix tables do not apply.  INNER join,
+    every probe row matches `dup` build rows; rows/s = (build + probe rows) / time for build + probe."""
+    nb, npr = 1 << lg_b, 1 << lg_p
+    bk = torch.randint(0, nb // dup, (nb,), generator=g, device=dv, dtype=torch.int64)
+    bv = torch.arange(nb, device=dv, dtype=torch.int64)
+    pk = torch.randint(0, nb // dup, (npr,), generator=g, device=dv, dtype=torch.int64)
+    pw = torch.arange(npr, device=dv, dtype=torch.int64)
+    build = [dev.from_torch(cd.INT64, bk), dev.from_torch(cd.INT64, bv)]
+    probe = [dev.from_torch(cd.INT64, pk), dev.from_torch(cd.INT64, pw)]
+    j = dev.Join(0, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], False, out_cols=[1, 3])
+    out_rows = [0]
+
+    def go():
+        j.reset()
+        j.build(build, nb)
+        out_rows[0] = int(j.probe(probe, npr).n)
+    dt = _timed(go, reps)
+    kern = _kernels(["join_build", "join_probe", "radix_build_hist", "radix_build_scatter", "radix_build_split", "radix_build_table"], reps)
+    j.close()
+    cpu = None
+    if CPU_SAMPLE:
+        from oracle import oracle as O
+        sb, sp = min(nb, CPU_SAMPLE // 4), min(npr, CPU_SAMPLE)
+        hb = [cd.Vec.from_numpy(cd.INT64, (bk[:sb] % (sb // dup)).cpu().numpy()), cd.Vec.from_numpy(cd.INT64, bv[:sb].cpu().numpy())]
+        hp = [cd.Vec.from_numpy(cd.INT64, (pk[:sp] % (sb // dup)).cpu().numpy()), cd.Vec.from_numpy(cd.INT64, pw[:sp].cpu().numpy())]
+        t0 = time.perf_counter()
+        O.hash_join(0, hp, hb, [0], [0], False)
+        cdt = time.perf_counter() - t0
+        cpu = {"value": (sb + sp) / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"{sb} build x {sp} probe rows of the same shape (keys folded to keep {dup} duplicates per key; oracle hashJoiner, 1 thread)"}
+    r = _line(f"general join (duplicate build keys, chained table): 2^{lg_b} build ({dup} rows per key) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
+              nb + npr, dt, 16.0 * nb + 16.0 * npr + 16.0 * out_rows[0], kern, cpu)
+    r["output_rows"] = out_rows[0]
+    return r
+
+
 def bench_router(lg, reps, dv, g, outputs):
     n = 1 << lg
     k = torch.randint(0, 1 << 40, (n,), generator=g, device=dv, dtype=torch.int64)
@@ -217,6 +254,8 @@ def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_r
         yield bench_hash(lg_hash, reps, dv, g)
     if want("build"):
         yield bench_build(lg_rows, reps, dv, g)
+    if want("general_join"):
+        yield bench_general_join(reps, dv, g)
     if want("router"):
         yield bench_router(lg_rows, reps, dv, g, 8)
     if want("g_distinct"):
