@@ -106,3 +106,44 @@ def test_distinct_full_size_invariants(nkeys):
     first = torch.full((uk.numel(),), n, device=dv, dtype=torch.int64).scatter_reduce(0, inv, w, reduce="amin")
     order = torch.argsort(ok)
     assert torch.equal(ok[order], uk) and torch.equal(ow[order], first)
+
+
+def test_distinct_bytes_keys_whole_batch_append_with_offset_base(oracle):
+    """Mostly-new batches join the key store whole.  Here the BYTES key column's offsets do not start at 0 (a slice of
+    a larger buffer, as a decode or join result can be) and the batches contain duplicates of keys from the same and
+    from earlier batches; a later lookup must still find every stored key (the index is rebuilt on growth)."""
+    import torch
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(123)
+    dv = torch.device("cuda", 0)
+    d = dev.Distinct([cd.BYTES, cd.INT64], [0])
+    seen, want_rows, got_rows = set(), [], []
+    serial = 0
+    for b in range(6):
+        n = 20_000
+        vals = []
+        for i in range(n):
+            if rng.random() < 0.15 and serial > 10:
+                k = int(rng.integers(0, serial))  # a key seen before (this or an earlier batch)
+            else:
+                k = serial
+                serial += 1
+            vals.append(b"key-%d-" % k + b"x" * (k % 9))
+        payload = np.arange(n, dtype=np.int64) + b * n
+        lens = np.array([len(v) for v in vals], dtype=np.int64)
+        junk = 7 + b
+        offs = (np.concatenate([[0], np.cumsum(lens)]) + junk).astype(np.int32)
+        data = np.frombuffer(b"#" * junk + b"".join(vals) + b"#" * 16, dtype=np.uint8).copy()
+        tk = torch.from_numpy(data).to(dv)
+        to = torch.from_numpy(offs).to(dv)
+        tp = torch.from_numpy(payload).to(dv)
+        torch.cuda.synchronize()
+        res = d.consume([dev.from_torch(cd.BYTES, tk, offsets=to), dev.from_torch(cd.INT64, tp)], n)
+        out = dev.result_to_vecs(res)
+        got_rows += list(zip(out[0].to_values(), out[1].to_values()))
+        for v, p in zip(vals, payload.tolist()):
+            if v not in seen:
+                seen.add(v)
+                want_rows.append((v, p))
+    d.close()
+    assert got_rows == want_rows
