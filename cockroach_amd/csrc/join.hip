@@ -271,6 +271,7 @@ struct ChainArgs {
   uint32_t *counts;       // pass 1 output
   const uint64_t *offsets;  // pass 2 input
   int32_t *pair_p, *pair_b;
+  uint4 *mcache;          // [n] or nullptr: the first four matches of every probe row, left by pass 1 for pass 3
 };
 
 // pass 1: number of output rows each probe row produces (and all side effects:
@@ -281,6 +282,10 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
     uint32_t cnt = 0;
     bool found = false;
+    // A chain walk is ~2 random HBM reads per candidate, and pass 3 would repeat it: the first four matches are kept
+    // (one coalesced 16-byte store here, one load there), so only rows with more matches walk twice.  0xFFFFFFFF in
+    // the first field = no match (the NULL build side of a LEFT/FULL OUTER row).
+    uint32_t m0 = 0xFFFFFFFFu, m1 = 0, m2 = 0, m3 = 0;
     if (a.null_eq || !any_key_null(a.probe, i)) {
       uint32_t cand = a.first[hash_row32(a.probe, i, 1u) & a.nb_mask];
       while (cand != 0) {
@@ -293,6 +298,10 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
             }
           } else {
             found = true;
+            if (cnt == 0) m0 = static_cast<uint32_t>(r);
+            else if (cnt == 1) m1 = static_cast<uint32_t>(r);
+            else if (cnt == 2) m2 = static_cast<uint32_t>(r);
+            else if (cnt == 3) m3 = static_cast<uint32_t>(r);
             cnt++;
             if (a.matched != nullptr) a.matched[r] = 1;
             if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
@@ -314,6 +323,7 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
       default: out = 0; break;  // RIGHT SEMI / RIGHT ANTI emit nothing while probing
     }
     a.counts[i] = out;
+    if (a.mcache != nullptr) a.mcache[i] = make_uint4(m0, m1, m2, m3);
   }
 }
 
@@ -328,6 +338,18 @@ __global__ __launch_bounds__(256) void chain_fill_kernel(ChainArgs a) {
     constexpr bool kPairs = JT == CRGPU_INNER || JT == CRGPU_LEFT_OUTER || JT == CRGPU_RIGHT_OUTER || JT == CRGPU_FULL_OUTER;
     if (!kPairs) {
       a.pair_p[o] = static_cast<int32_t>(i);
+      continue;
+    }
+    if (a.mcache != nullptr && cnt <= 4) {  // everything pass 1 found for this row is in the cache
+      const uint4 m = a.mcache[i];
+      const uint32_t mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (uint32_t w = 0; w < 4; w++) {
+        if (w < cnt) {
+          a.pair_p[o + w] = static_cast<int32_t>(i);
+          a.pair_b[o + w] = static_cast<int32_t>(mm[w]);  // 0xFFFFFFFF -> -1: unmatched row of a LEFT/FULL OUTER join
+        }
+      }
       continue;
     }
     uint32_t written = 0;
@@ -394,6 +416,7 @@ struct crgpu_join {
 
   // packed table
   DevBuf slots, special;
+  DevBuf mcache;  // chained probe: first matches of every probe row (pass 1 -> pass 3)
   uint64_t cap = 0;
   bool covering = false;
   int cover_col = -1;
@@ -934,6 +957,11 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     CRGPU_TRY(j->offsets.ensure(static_cast<size_t>(n + 1) * 8));
     a.counts = j->counts.as<uint32_t>();
     a.offsets = j->offsets.as<uint64_t>();
+    const bool pairs = jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER;
+    if (pairs && n <= (int64_t(1) << 29)) {  // 16 bytes per probe row, at most 8 GiB
+      CRGPU_TRY(j->mcache.ensure(static_cast<size_t>(n) * 16));
+      a.mcache = j->mcache.as<uint4>();
+    }
     {
       ProfScope prof("join_probe");
       CRGPU_TRY(launch_chain_jt(jt, a, false));
