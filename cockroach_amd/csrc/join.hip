@@ -246,24 +246,45 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
 }
 
 // ------------------------------------------------------------------ CHAINED build / probe
-__global__ __launch_bounds__(256) void chain_build_kernel(KeyCols keys, int64_t n, bool null_eq, uint32_t nb_mask,
-                                                          uint32_t *__restrict__ first, uint32_t *__restrict__ next) {
+// The chained table is laid out bucket by bucket (a counting sort of the build rows by hash bucket): start[b] .. start[b+1]
+// delimits bucket b in grp[] (build row ids) and, for a single integer key column, gkey[] (the key values themselves).
+// A probe row then reads one start pair, a few CONSECUTIVE gkey entries and the row ids of its matches: ~3 random
+// cache lines, where a linked chain costs two (next[] and the key column) per candidate.
+__global__ __launch_bounds__(256) void chain_hist_kernel(KeyCols keys, int64_t n, bool null_eq, uint32_t nb_mask,
+                                                         uint32_t *__restrict__ cnt, uint32_t *__restrict__ hsave) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
     if (!null_eq && any_key_null(keys, row)) {
-      next[row] = 0;
+      hsave[row] = 0xFFFFFFFFu;  // never matches: not in the table
       continue;
     }
     const uint32_t h = hash_row32(keys, row, 1u) & nb_mask;
-    next[row] = atomicExch(&first[h], static_cast<uint32_t>(row) + 1u);
+    hsave[row] = h;
+    atomicAdd(&cnt[h], 1u);
   }
 }
+__global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_t n, const uint32_t *__restrict__ hsave,
+                                                            const uint64_t *__restrict__ start,
+                                                            uint32_t *__restrict__ cnt, uint32_t *__restrict__ grp,
+                                                            int64_t *__restrict__ gkey) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+    const uint32_t h = hsave[row];
+    if (h == 0xFFFFFFFFu) continue;
+    const uint64_t pos = start[h] + (atomicSub(&cnt[h], 1u) - 1u);  // cnt counts back down to zero
+    grp[pos] = static_cast<uint32_t>(row);
+    if (gkey != nullptr) gkey[pos] = col_get_int(keys.c[0], row);
+  }
+}
+
+static constexpr int kChainCache = 8;  // matches per probe row that pass 1 hands to pass 3
 
 struct ChainArgs {
   KeyCols probe, build;
   int64_t n;
-  const uint32_t *first;
-  const uint32_t *next;
+  const uint64_t *start;  // [nb + 1] bucket boundaries in grp / gkey
+  const uint32_t *grp;    // build row ids, bucket by bucket
+  const int64_t *gkey;    // key values in the same order (single integer key column), else nullptr
   uint32_t nb_mask;
   int32_t null_eq;
   uint8_t *matched;       // build-row matched flags (RIGHT/FULL OUTER, RIGHT SEMI/ANTI)
@@ -271,8 +292,36 @@ struct ChainArgs {
   uint32_t *counts;       // pass 1 output
   const uint64_t *offsets;  // pass 2 input
   int32_t *pair_p, *pair_b;
-  uint4 *mcache;          // [n] or nullptr: the first four matches of every probe row, left by pass 1 for pass 3
+  uint4 *mcache;          // [kChainCache / 4][n] or nullptr: the first matches of every probe row, left by pass 1 for pass 3
 };
+
+// Iteration over the build rows whose key equals probe row i's: `ChainIter it = chain_begin(a, i); while (chain_next(a, i,
+// it, r)) ...`.
+struct ChainIter {
+  uint64_t p, e;
+  int64_t k;
+};
+__device__ __forceinline__ ChainIter chain_begin(const ChainArgs &a, int64_t i) {
+  const uint32_t h = hash_row32(a.probe, i, 1u) & a.nb_mask;
+  ChainIter it;
+  it.p = a.start[h];
+  it.e = a.start[h + 1];
+  it.k = a.gkey != nullptr ? col_get_int(a.probe.c[0], i) : 0;
+  return it;
+}
+__device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainIter &it, int64_t &r) {
+  while (it.p < it.e) {
+    const uint64_t p = it.p++;
+    if (a.gkey != nullptr) {
+      if (a.gkey[p] != it.k) continue;
+      r = static_cast<int64_t>(a.grp[p]);
+      return true;
+    }
+    r = static_cast<int64_t>(a.grp[p]);
+    if (keys_equal(a.probe, i, a.build, r, a.null_eq != 0)) return true;
+  }
+  return false;
+}
 
 // pass 1: number of output rows each probe row produces (and all side effects:
 // matched marks, claims).
@@ -282,32 +331,30 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
     uint32_t cnt = 0;
     bool found = false;
-    // A chain walk is ~2 random HBM reads per candidate, and pass 3 would repeat it: the first four matches are kept
-    // (one coalesced 16-byte store here, one load there), so only rows with more matches walk twice.  0xFFFFFFFF in
-    // the first field = no match (the NULL build side of a LEFT/FULL OUTER row).
-    uint32_t m0 = 0xFFFFFFFFu, m1 = 0, m2 = 0, m3 = 0;
+    // The first kChainCache matches are kept for pass 3 (coalesced 16-byte stores here, loads there), so only rows
+    // with more matches walk their bucket twice.  0xFFFFFFFF in the first field = no match (the NULL build side of a
+    // LEFT/FULL OUTER row).
+    uint32_t m[kChainCache];
+#pragma unroll
+    for (int t = 0; t < kChainCache; t++) m[t] = t == 0 ? 0xFFFFFFFFu : 0u;
     if (a.null_eq || !any_key_null(a.probe, i)) {
-      uint32_t cand = a.first[hash_row32(a.probe, i, 1u) & a.nb_mask];
-      while (cand != 0) {
-        const int64_t r = static_cast<int64_t>(cand) - 1;
-        if (keys_equal(a.probe, i, a.build, r, a.null_eq != 0)) {
-          if (JT == CRGPU_INTERSECT_ALL || JT == CRGPU_EXCEPT_ALL) {
-            if (atomicCAS(&a.claimed[r], 0u, 1u) == 0u) {
-              found = true;
-              break;
-            }
-          } else {
+      ChainIter it = chain_begin(a, i);
+      int64_t r;
+      while (chain_next(a, i, it, r)) {
+        if (JT == CRGPU_INTERSECT_ALL || JT == CRGPU_EXCEPT_ALL) {
+          if (atomicCAS(&a.claimed[r], 0u, 1u) == 0u) {
             found = true;
-            if (cnt == 0) m0 = static_cast<uint32_t>(r);
-            else if (cnt == 1) m1 = static_cast<uint32_t>(r);
-            else if (cnt == 2) m2 = static_cast<uint32_t>(r);
-            else if (cnt == 3) m3 = static_cast<uint32_t>(r);
-            cnt++;
-            if (a.matched != nullptr) a.matched[r] = 1;
-            if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
+            break;
           }
+          continue;
         }
-        cand = a.next[r];
+        found = true;
+#pragma unroll
+        for (int t = 0; t < kChainCache; t++)
+          if (cnt == static_cast<uint32_t>(t)) m[t] = static_cast<uint32_t>(r);
+        cnt++;
+        if (a.matched != nullptr) a.matched[r] = 1;
+        if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
       }
     }
     uint32_t out;
@@ -323,7 +370,11 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
       default: out = 0; break;  // RIGHT SEMI / RIGHT ANTI emit nothing while probing
     }
     a.counts[i] = out;
-    if (a.mcache != nullptr) a.mcache[i] = make_uint4(m0, m1, m2, m3);
+    if (a.mcache != nullptr) {
+#pragma unroll
+      for (int t = 0; t < kChainCache / 4; t++)  // plane t holds matches 4t .. 4t+3 of every row
+        if (t == 0 || cnt > 4u * t) a.mcache[static_cast<int64_t>(t) * a.n + i] = make_uint4(m[4 * t], m[4 * t + 1], m[4 * t + 2], m[4 * t + 3]);
+    }
   }
 }
 
@@ -340,35 +391,74 @@ __global__ __launch_bounds__(256) void chain_fill_kernel(ChainArgs a) {
       a.pair_p[o] = static_cast<int32_t>(i);
       continue;
     }
-    if (a.mcache != nullptr && cnt <= 4) {  // everything pass 1 found for this row is in the cache
-      const uint4 m = a.mcache[i];
-      const uint32_t mm[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-      for (uint32_t w = 0; w < 4; w++) {
-        if (w < cnt) {
-          a.pair_p[o + w] = static_cast<int32_t>(i);
-          a.pair_b[o + w] = static_cast<int32_t>(mm[w]);  // 0xFFFFFFFF -> -1: unmatched row of a LEFT/FULL OUTER join
-        }
-      }
-      continue;
-    }
     uint32_t written = 0;
     if (a.null_eq || !any_key_null(a.probe, i)) {
-      uint32_t cand = a.first[hash_row32(a.probe, i, 1u) & a.nb_mask];
-      while (cand != 0 && written < cnt) {
-        const int64_t r = static_cast<int64_t>(cand) - 1;
-        if (keys_equal(a.probe, i, a.build, r, a.null_eq != 0)) {
-          a.pair_p[o + written] = static_cast<int32_t>(i);
-          a.pair_b[o + written] = static_cast<int32_t>(r);
-          written++;
-        }
-        cand = a.next[r];
+      ChainIter it = chain_begin(a, i);
+      int64_t r;
+      while (written < cnt && chain_next(a, i, it, r)) {
+        a.pair_p[o + written] = static_cast<int32_t>(i);
+        a.pair_b[o + written] = static_cast<int32_t>(r);
+        written++;
       }
     }
     if (written == 0) {  // unmatched row of a LEFT/FULL OUTER join
       a.pair_p[o] = static_cast<int32_t>(i);
       a.pair_b[o] = -1;
     }
+  }
+}
+
+// pass 3 of the pair-producing join types when pass 1 left its match cache: a wave expands its 64 probe rows into their
+// CONSECUTIVE output rows cooperatively - lane q of each round finds the probe row that owns output row q by a binary
+// search over the wave's exclusive counts in LDS - so pair_p / pair_b are written 256 bytes per store instruction
+// whatever the match counts are (one lane writing its own row's 1..4 pairs strides the stores 4..16 bytes apart and
+// instruction).  Rows with more than kChainCache matches walk their bucket again.
+__global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
+  __shared__ uint32_t s_off[4][65];
+  __shared__ __align__(16) uint32_t s_m[4][64 * kChainCache];
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t bbase = static_cast<int64_t>(blockIdx.x) * 256; bbase < a.n; bbase += stride) {
+    const int64_t wbase = bbase + wave * 64;
+    const int64_t i = wbase + lane;
+    const bool in = i < a.n;
+    const uint32_t cnt = in ? a.counts[i] : 0u;
+    const uint64_t o = in ? a.offsets[i] : 0ull;
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    const uint32_t total = __shfl(incl, 63, 64);
+    const uint64_t o0 = (static_cast<uint64_t>(__shfl(static_cast<uint32_t>(o >> 32), 0, 64)) << 32) |
+                        __shfl(static_cast<uint32_t>(o), 0, 64);
+    s_off[wave][lane] = incl - cnt;
+    if (lane == 63) s_off[wave][64] = total;
+    if (cnt != 0 && cnt <= kChainCache) {
+#pragma unroll
+      for (int t = 0; t < kChainCache / 4; t++)
+        if (t == 0 || cnt > 4u * t)
+          *reinterpret_cast<uint4 *>(&s_m[wave][lane * kChainCache + 4 * t]) = a.mcache[static_cast<int64_t>(t) * a.n + i];
+    }
+    __syncthreads();
+    for (uint32_t q = lane; q < total; q += 64) {
+      uint32_t src = 0;
+#pragma unroll
+      for (uint32_t step = 32; step != 0; step >>= 1)
+        if (s_off[wave][src + step] <= q) src += step;  // the last row whose first output row is <= q owns q
+      const uint32_t first = s_off[wave][src];
+      if (s_off[wave][src + 1] - first <= kChainCache) {
+        a.pair_p[o0 + q] = static_cast<int32_t>(wbase + src);
+        a.pair_b[o0 + q] = static_cast<int32_t>(s_m[wave][src * kChainCache + (q - first)]);  // 0xFFFFFFFF -> -1: no match
+      }
+    }
+    if (cnt > kChainCache) {
+      uint32_t written = 0;
+      ChainIter it = chain_begin(a, i);
+      int64_t r;
+      while (written < cnt && chain_next(a, i, it, r)) {
+        a.pair_p[o + written] = static_cast<int32_t>(i);
+        a.pair_b[o + written] = static_cast<int32_t>(r);
+        written++;
+      }
+    }
+    __syncthreads();  // the next round overwrites s_off / s_m
   }
 }
 
@@ -424,7 +514,9 @@ struct crgpu_join {
   RadixTable radix;
   bool use_radix = false;
   // chained table
-  DevBuf first, next;
+  DevBuf first, next;          // chained table: per-bucket counters (zero again once built), per-row bucket numbers
+  DevBuf cstart, grp, gkey;    // bucket boundaries, row ids and (single integer key) key values bucket by bucket
+  bool chain_exact = false;    // gkey is in use: equal gkey <=> equal key
   uint32_t nb = 0;
   // marks
   DevBuf matched, claimed;
@@ -649,10 +741,29 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
       keys.n = static_cast<int>(j->right_eq.size());
       keys._pad = 0;
       for (int k = 0; k < keys.n; k++) keys.c[k] = j->build_cols[j->right_eq[k]];
+      // One integer key column: the bucket-ordered copy of the keys decides equality by itself.  Not with NULL = NULL
+      // semantics (set operations): a NULL row is in the table then, and its stored value is not its key.
+      const DCol &bk = keys.c[0];
+      const bool is_int = bk.type == CRGPU_INT16 || bk.type == CRGPU_INT32 || bk.type == CRGPU_INT64;
+      j->chain_exact = keys.n == 1 && is_int && !j->null_eq;
+      CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 8));
+      CRGPU_TRY(j->grp.ensure(static_cast<size_t>(n) * 4));
+      if (j->chain_exact) CRGPU_TRY(j->gkey.ensure(static_cast<size_t>(n) * 8));
       ProfScope prof("join_build");
-      hipLaunchKernelGGL(chain_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n, j->null_eq,
-                         j->nb - 1, j->first.as<uint32_t>(), j->next.as<uint32_t>());
+      hipLaunchKernelGGL(chain_hist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n, j->null_eq, j->nb - 1,
+                         j->first.as<uint32_t>(), j->next.as<uint32_t>());
       CRGPU_HIP(hipGetLastError());
+      CRGPU_TRY(exclusive_scan_u32(j->first.as<uint32_t>(), static_cast<int64_t>(nb), j->cstart.as<uint64_t>(),
+                                   j->scratch, nullptr));
+      hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n,
+                         j->next.as<uint32_t>(), j->cstart.as<uint64_t>(), j->first.as<uint32_t>(),
+                         j->grp.as<uint32_t>(), j->chain_exact ? j->gkey.as<int64_t>() : nullptr);
+      CRGPU_HIP(hipGetLastError());
+    } else {
+      CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 8));
+      CRGPU_HIP(hipMemsetAsync(j->cstart.p, 0, (static_cast<size_t>(nb) + 1) * 8, st));
+      CRGPU_TRY(j->grp.ensure(4));
+      j->chain_exact = false;
     }
   }
   CRGPU_HIP(hipStreamSynchronize(st));
@@ -913,7 +1024,10 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
 template <int JT>
 static void launch_chain(const ChainArgs &a, bool fill) {
   int grid = grid_for(a.n, 256);
-  if (fill) hipLaunchKernelGGL(chain_fill_kernel<JT>, dim3(grid), dim3(256), 0, stream(), a);
+  constexpr bool kPairs = JT == CRGPU_INNER || JT == CRGPU_LEFT_OUTER || JT == CRGPU_RIGHT_OUTER || JT == CRGPU_FULL_OUTER;
+  if (fill && kPairs && a.mcache != nullptr)
+    hipLaunchKernelGGL(chain_fill_cached_kernel, dim3(grid), dim3(256), 0, stream(), a);
+  else if (fill) hipLaunchKernelGGL(chain_fill_kernel<JT>, dim3(grid), dim3(256), 0, stream(), a);
   else hipLaunchKernelGGL(chain_count_kernel<JT>, dim3(grid), dim3(256), 0, stream(), a);
 }
 static crgpu_status launch_chain_jt(int jt, const ChainArgs &a, bool fill) {
@@ -947,8 +1061,13 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
       a.build.c[k] = j->build_cols[j->right_eq[k]];
     }
     a.n = n;
-    a.first = j->first.as<uint32_t>();
-    a.next = j->next.as<uint32_t>();
+    a.start = j->cstart.as<uint64_t>();
+    a.grp = j->grp.as<uint32_t>();
+    a.gkey = nullptr;
+    if (j->chain_exact) {
+      const int pt = a.probe.c[0].type;
+      if (pt == CRGPU_INT16 || pt == CRGPU_INT32 || pt == CRGPU_INT64) a.gkey = j->gkey.as<int64_t>();
+    }
     a.nb_mask = j->nb - 1;
     a.null_eq = j->null_eq;
     a.matched = j->track_build_matches ? j->matched.as<uint8_t>() : nullptr;
@@ -958,8 +1077,8 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     a.counts = j->counts.as<uint32_t>();
     a.offsets = j->offsets.as<uint64_t>();
     const bool pairs = jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER;
-    if (pairs && n <= (int64_t(1) << 29)) {  // 16 bytes per probe row, at most 8 GiB
-      CRGPU_TRY(j->mcache.ensure(static_cast<size_t>(n) * 16));
+    if (pairs && n <= (int64_t(1) << 28)) {  // 32 bytes per probe row, at most 8 GiB
+      CRGPU_TRY(j->mcache.ensure(static_cast<size_t>(n) * 4 * kChainCache));
       a.mcache = j->mcache.as<uint4>();
     }
     {

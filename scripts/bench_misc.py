@@ -99,7 +99,7 @@ def bench_build(lg, reps, dv, g):
 
 def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
     """The general (chained) join path: duplicate build keys, so the packed / radix tables do not apply.  INNER join,
-    every probe row matches `dup` build rows; rows/s = (build + probe rows) / time for build + probe."""
+    build keys drawn at random from nb/dup values (Poisson(dup) rows per key, `dup` on average); rows/s = (build + probe rows) / time for build + probe."""
     nb, npr = 1 << lg_b, 1 << lg_p
     bk = torch.randint(0, nb // dup, (nb,), generator=g, device=dv, dtype=torch.int64)
     bv = torch.arange(nb, device=dv, dtype=torch.int64)
@@ -128,7 +128,7 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
         cdt = time.perf_counter() - t0
         cpu = {"value": (sb + sp) / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"{sb} build x {sp} probe rows of the same shape (keys folded to keep {dup} duplicates per key; oracle hashJoiner, 1 thread)"}
-    r = _line(f"general join (duplicate build keys, chained table): 2^{lg_b} build ({dup} rows per key) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
+    r = _line(f"general join (duplicate build keys, chained table): 2^{lg_b} build (random keys, {dup} rows per key on average) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
               nb + npr, dt, 16.0 * nb + 16.0 * npr + 16.0 * out_rows[0], kern, cpu)
     r["output_rows"] = out_rows[0]
     return r

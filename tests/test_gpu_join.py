@@ -54,6 +54,31 @@ def test_join_random_int_keys_vs_oracle(oracle, jt, unique_right):
     assert np.array_equal(got, G.rows_as_sorted_array(want)), jt
 
 
+@pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER", "RIGHT_OUTER", "FULL_OUTER"])
+@pytest.mark.parametrize("key_type", ["INT64", "INT32_nullable", "FLOAT64"])
+def test_join_duplicate_counts_around_the_match_cache(oracle, jt, key_type):
+    """Build keys with 0..24 duplicates each: the probe's first pass hands the first 8 matches of a row to the pass that
+    writes the pairs, rows with more walk their bucket again (join.hip, kChainCache); a probe wave mixes all of them."""
+    rng = np.random.default_rng(5)
+    rk = np.repeat(np.arange(1, 25 * 8 + 1), np.tile(np.arange(25), 8)).astype(np.int64)  # key k has (k-1) % 25 rows
+    rng.shuffle(rk)
+    lk = rng.integers(-5, 25 * 8 + 10, size=3000).astype(np.int64)
+    nl, nr = len(lk), len(rk)
+    if key_type == "INT64":
+        lkey, rkey = cd.Vec.from_numpy(cd.INT64, lk), cd.Vec.from_numpy(cd.INT64, rk)
+    elif key_type == "INT32_nullable":
+        lkey = cd.Vec.from_numpy(cd.INT32, lk.astype(np.int32), rng.random(nl) >= 0.05)
+        rkey = cd.Vec.from_numpy(cd.INT32, rk.astype(np.int32), rng.random(nr) >= 0.05)
+    else:
+        lkey, rkey = cd.Vec.from_numpy(cd.FLOAT64, lk * 0.5), cd.Vec.from_numpy(cd.FLOAT64, rk * 0.5)
+    left = [lkey, cd.Vec.from_numpy(cd.INT64, np.arange(nl, dtype=np.int64))]
+    right = [rkey, cd.Vec.from_numpy(cd.INT64, np.arange(nr, dtype=np.int64) + 10_000)]
+    want = H.vecs_to_tuples(oracle.hash_join(H.JOIN_TYPE[jt], left, right, [0], [0], False))
+    for chunks in (1, 2):
+        got = G.gpu_join(jt, left, right, [0], [0], False, probe_chunks=chunks)
+        H.assert_same_multiset(got, want, f"{jt} {key_type} chunks={chunks}")
+
+
 @pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER", "FULL_OUTER", "LEFT_SEMI", "LEFT_ANTI", "RIGHT_SEMI"])
 def test_join_multi_col_bytes_keys_vs_oracle(oracle, jt):
     rng = np.random.default_rng(11)
