@@ -247,9 +247,9 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
 
 // ------------------------------------------------------------------ CHAINED build / probe
 // The chained table is laid out bucket by bucket (a counting sort of the build rows by hash bucket): start[b] .. start[b+1]
-// delimits bucket b in grp[] (build row ids) and, for a single integer key column, gkey[] (the key values themselves).
-// A probe row then reads one start pair, a few CONSECUTIVE gkey entries and the row ids of its matches: ~3 random
-// cache lines, where a linked chain costs two (next[] and the key column) per candidate.
+// delimits bucket b in grp[] (build row ids) and, for a single integer key column, gkey[] ({key value, row id} pairs).
+// A probe row then reads one start pair and a few CONSECUTIVE gkey entries: ~2 random cache lines, where a linked chain
+// costs two (next[] and the key column) per candidate.
 __global__ __launch_bounds__(256) void chain_hist_kernel(KeyCols keys, int64_t n, bool null_eq, uint32_t nb_mask,
                                                          uint32_t *__restrict__ cnt, uint32_t *__restrict__ hsave) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -266,14 +266,14 @@ __global__ __launch_bounds__(256) void chain_hist_kernel(KeyCols keys, int64_t n
 __global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_t n, const uint32_t *__restrict__ hsave,
                                                             const uint64_t *__restrict__ start,
                                                             uint32_t *__restrict__ cnt, uint32_t *__restrict__ grp,
-                                                            int64_t *__restrict__ gkey) {
+                                                            ulonglong2 *__restrict__ gkey) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
     const uint32_t h = hsave[row];
     if (h == 0xFFFFFFFFu) continue;
     const uint64_t pos = start[h] + (atomicSub(&cnt[h], 1u) - 1u);  // cnt counts back down to zero
     grp[pos] = static_cast<uint32_t>(row);
-    if (gkey != nullptr) gkey[pos] = col_get_int(keys.c[0], row);
+    if (gkey != nullptr) gkey[pos] = make_ulonglong2(static_cast<uint64_t>(col_get_int(keys.c[0], row)), static_cast<uint64_t>(row));
   }
 }
 
@@ -284,7 +284,7 @@ struct ChainArgs {
   int64_t n;
   const uint64_t *start;  // [nb + 1] bucket boundaries in grp / gkey
   const uint32_t *grp;    // build row ids, bucket by bucket
-  const int64_t *gkey;    // key values in the same order (single integer key column), else nullptr
+  const ulonglong2 *gkey; // {key value, row id} in the same order (single integer key column), else nullptr
   uint32_t nb_mask;
   int32_t null_eq;
   uint8_t *matched;       // build-row matched flags (RIGHT/FULL OUTER, RIGHT SEMI/ANTI)
@@ -313,8 +313,9 @@ __device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainI
   while (it.p < it.e) {
     const uint64_t p = it.p++;
     if (a.gkey != nullptr) {
-      if (a.gkey[p] != it.k) continue;
-      r = static_cast<int64_t>(a.grp[p]);
+      const ulonglong2 kr = a.gkey[p];  // key and row id in one 16-byte load
+      if (static_cast<int64_t>(kr.x) != it.k) continue;
+      r = static_cast<int64_t>(kr.y);
       return true;
     }
     r = static_cast<int64_t>(a.grp[p]);
@@ -748,7 +749,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
       j->chain_exact = keys.n == 1 && is_int && !j->null_eq;
       CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 8));
       CRGPU_TRY(j->grp.ensure(static_cast<size_t>(n) * 4));
-      if (j->chain_exact) CRGPU_TRY(j->gkey.ensure(static_cast<size_t>(n) * 8));
+      if (j->chain_exact) CRGPU_TRY(j->gkey.ensure(static_cast<size_t>(n) * 16));
       ProfScope prof("join_build");
       hipLaunchKernelGGL(chain_hist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n, j->null_eq, j->nb - 1,
                          j->first.as<uint32_t>(), j->next.as<uint32_t>());
@@ -757,7 +758,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
                                    j->scratch, nullptr));
       hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n,
                          j->next.as<uint32_t>(), j->cstart.as<uint64_t>(), j->first.as<uint32_t>(),
-                         j->grp.as<uint32_t>(), j->chain_exact ? j->gkey.as<int64_t>() : nullptr);
+                         j->grp.as<uint32_t>(), j->chain_exact ? j->gkey.as<ulonglong2>() : nullptr);
       CRGPU_HIP(hipGetLastError());
     } else {
       CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 8));
@@ -1066,7 +1067,7 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     a.gkey = nullptr;
     if (j->chain_exact) {
       const int pt = a.probe.c[0].type;
-      if (pt == CRGPU_INT16 || pt == CRGPU_INT32 || pt == CRGPU_INT64) a.gkey = j->gkey.as<int64_t>();
+      if (pt == CRGPU_INT16 || pt == CRGPU_INT32 || pt == CRGPU_INT64) a.gkey = j->gkey.as<ulonglong2>();
     }
     a.nb_mask = j->nb - 1;
     a.null_eq = j->null_eq;
