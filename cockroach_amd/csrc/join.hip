@@ -1078,7 +1078,8 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     a.counts = j->counts.as<uint32_t>();
     a.offsets = j->offsets.as<uint64_t>();
     const bool pairs = jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER;
-    if (pairs && n <= (int64_t(1) << 28)) {  // 32 bytes per probe row, at most 8 GiB
+    const char *mc_env = getenv("CRGPU_JOIN_MATCH_CACHE");  // "0": both passes walk the buckets (what chunks beyond 2^28 rows do)
+    if (pairs && n <= (int64_t(1) << 28) && !(mc_env != nullptr && mc_env[0] == '0')) {  // 32 bytes per probe row, at most 8 GiB
       CRGPU_TRY(j->mcache.ensure(static_cast<size_t>(n) * 4 * kChainCache));
       a.mcache = j->mcache.as<uint4>();
     }

@@ -56,9 +56,11 @@ def test_join_random_int_keys_vs_oracle(oracle, jt, unique_right):
 
 @pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER", "RIGHT_OUTER", "FULL_OUTER"])
 @pytest.mark.parametrize("key_type", ["INT64", "INT32_nullable", "FLOAT64"])
-def test_join_duplicate_counts_around_the_match_cache(oracle, jt, key_type):
+@pytest.mark.parametrize("match_cache", ["1", "0"])
+def test_join_duplicate_counts_around_the_match_cache(oracle, jt, key_type, match_cache, monkeypatch):
     """Build keys with 0..24 duplicates each: the probe's first pass hands the first 8 matches of a row to the pass that
     writes the pairs, rows with more walk their bucket again (join.hip, kChainCache); a probe wave mixes all of them."""
+    monkeypatch.setenv("CRGPU_JOIN_MATCH_CACHE", match_cache)  # "0": the path probe chunks beyond 2^28 rows take
     rng = np.random.default_rng(5)
     rk = np.repeat(np.arange(1, 25 * 8 + 1), np.tile(np.arange(25), 8)).astype(np.int64)  # key k has (k-1) % 25 rows
     rng.shuffle(rk)
