@@ -325,56 +325,73 @@ __device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainI
 }
 
 // pass 1: number of output rows each probe row produces (and all side effects:
-// matched marks, claims).
+// matched marks, claims).  `it` is the row's started bucket walk (empty for a row whose NULL key matches nothing).
+template <int JT>
+__device__ __forceinline__ void chain_count_row(const ChainArgs &a, int64_t i, ChainIter it) {
+  uint32_t cnt = 0;
+  bool found = false;
+  // The first kChainCache matches are kept for pass 3 (coalesced 16-byte stores here, loads there), so only rows
+  // with more matches walk their bucket twice.  0xFFFFFFFF in the first field = no match (the NULL build side of a
+  // LEFT/FULL OUTER row).
+  uint32_t m[kChainCache];
+#pragma unroll
+  for (int t = 0; t < kChainCache; t++) m[t] = t == 0 ? 0xFFFFFFFFu : 0u;
+  int64_t r;
+  while (chain_next(a, i, it, r)) {
+    if (JT == CRGPU_INTERSECT_ALL || JT == CRGPU_EXCEPT_ALL) {
+      if (atomicCAS(&a.claimed[r], 0u, 1u) == 0u) {
+        found = true;
+        break;
+      }
+      continue;
+    }
+    found = true;
+#pragma unroll
+    for (int t = 0; t < kChainCache; t++)
+      if (cnt == static_cast<uint32_t>(t)) m[t] = static_cast<uint32_t>(r);
+    cnt++;
+    if (a.matched != nullptr) a.matched[r] = 1;
+    if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
+  }
+  uint32_t out;
+  switch (JT) {
+    case CRGPU_INNER:
+    case CRGPU_RIGHT_OUTER: out = cnt; break;
+    case CRGPU_LEFT_OUTER:
+    case CRGPU_FULL_OUTER: out = cnt ? cnt : 1; break;
+    case CRGPU_LEFT_SEMI:
+    case CRGPU_INTERSECT_ALL: out = found; break;
+    case CRGPU_LEFT_ANTI:
+    case CRGPU_EXCEPT_ALL: out = !found; break;
+    default: out = 0; break;  // RIGHT SEMI / RIGHT ANTI emit nothing while probing
+  }
+  a.counts[i] = out;
+  if (a.mcache != nullptr) {
+#pragma unroll
+    for (int t = 0; t < kChainCache / 4; t++)  // plane t holds matches 4t .. 4t+3 of every row
+      if (t == 0 || cnt > 4u * t) a.mcache[static_cast<int64_t>(t) * a.n + i] = make_uint4(m[4 * t], m[4 * t + 1], m[4 * t + 2], m[4 * t + 3]);
+  }
+}
+
+// A bucket walk is a chain of dependent random reads (key -> start pair -> entries), so the kernel is bound by how many
+// of them are in flight: every lane starts the walks of kChainRows rows before it follows any of them.
+static constexpr int kChainRows = 2;
 template <int JT>
 __global__ __launch_bounds__(256) void chain_count_kernel(ChainArgs a) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    uint32_t cnt = 0;
-    bool found = false;
-    // The first kChainCache matches are kept for pass 3 (coalesced 16-byte stores here, loads there), so only rows
-    // with more matches walk their bucket twice.  0xFFFFFFFF in the first field = no match (the NULL build side of a
-    // LEFT/FULL OUTER row).
-    uint32_t m[kChainCache];
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i0 < a.n; i0 += stride * kChainRows) {
+    ChainIter it[kChainRows];
 #pragma unroll
-    for (int t = 0; t < kChainCache; t++) m[t] = t == 0 ? 0xFFFFFFFFu : 0u;
-    if (a.null_eq || !any_key_null(a.probe, i)) {
-      ChainIter it = chain_begin(a, i);
-      int64_t r;
-      while (chain_next(a, i, it, r)) {
-        if (JT == CRGPU_INTERSECT_ALL || JT == CRGPU_EXCEPT_ALL) {
-          if (atomicCAS(&a.claimed[r], 0u, 1u) == 0u) {
-            found = true;
-            break;
-          }
-          continue;
-        }
-        found = true;
-#pragma unroll
-        for (int t = 0; t < kChainCache; t++)
-          if (cnt == static_cast<uint32_t>(t)) m[t] = static_cast<uint32_t>(r);
-        cnt++;
-        if (a.matched != nullptr) a.matched[r] = 1;
-        if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
-      }
+    for (int t = 0; t < kChainRows; t++) {
+      const int64_t i = i0 + t * stride;
+      it[t].p = it[t].e = 0;
+      it[t].k = 0;
+      if (i < a.n && (a.null_eq || !any_key_null(a.probe, i))) it[t] = chain_begin(a, i);
     }
-    uint32_t out;
-    switch (JT) {
-      case CRGPU_INNER:
-      case CRGPU_RIGHT_OUTER: out = cnt; break;
-      case CRGPU_LEFT_OUTER:
-      case CRGPU_FULL_OUTER: out = cnt ? cnt : 1; break;
-      case CRGPU_LEFT_SEMI:
-      case CRGPU_INTERSECT_ALL: out = found; break;
-      case CRGPU_LEFT_ANTI:
-      case CRGPU_EXCEPT_ALL: out = !found; break;
-      default: out = 0; break;  // RIGHT SEMI / RIGHT ANTI emit nothing while probing
-    }
-    a.counts[i] = out;
-    if (a.mcache != nullptr) {
 #pragma unroll
-      for (int t = 0; t < kChainCache / 4; t++)  // plane t holds matches 4t .. 4t+3 of every row
-        if (t == 0 || cnt > 4u * t) a.mcache[static_cast<int64_t>(t) * a.n + i] = make_uint4(m[4 * t], m[4 * t + 1], m[4 * t + 2], m[4 * t + 3]);
+    for (int t = 0; t < kChainRows; t++) {
+      const int64_t i = i0 + t * stride;
+      if (i < a.n) chain_count_row<JT>(a, i, it[t]);
     }
   }
 }
@@ -431,11 +448,10 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
                         __shfl(static_cast<uint32_t>(o), 0, 64);
     s_off[wave][lane] = incl - cnt;
     if (lane == 63) s_off[wave][64] = total;
-    if (cnt != 0 && cnt <= kChainCache) {
+    if (in) {  // not conditional on cnt: these loads go out together with the two above (a plane the row did not write is never used)
 #pragma unroll
       for (int t = 0; t < kChainCache / 4; t++)
-        if (t == 0 || cnt > 4u * t)
-          *reinterpret_cast<uint4 *>(&s_m[wave][lane * kChainCache + 4 * t]) = a.mcache[static_cast<int64_t>(t) * a.n + i];
+        *reinterpret_cast<uint4 *>(&s_m[wave][lane * kChainCache + 4 * t]) = a.mcache[static_cast<int64_t>(t) * a.n + i];
     }
     __syncthreads();
     for (uint32_t q = lane; q < total; q += 64) {
