@@ -263,15 +263,21 @@ __global__ __launch_bounds__(256) void chain_hist_kernel(KeyCols keys, int64_t n
     atomicAdd(&cnt[h], 1u);
   }
 }
+__global__ __launch_bounds__(256) void chain_narrow_kernel(const uint64_t *__restrict__ in, int64_t n,
+                                                          uint32_t *__restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = static_cast<uint32_t>(in[i]);
+}
 __global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_t n, const uint32_t *__restrict__ hsave,
-                                                            const uint64_t *__restrict__ start,
+                                                            const uint32_t *__restrict__ start,
                                                             uint32_t *__restrict__ cnt, uint32_t *__restrict__ grp,
                                                             ulonglong2 *__restrict__ gkey) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
     const uint32_t h = hsave[row];
     if (h == 0xFFFFFFFFu) continue;
-    const uint64_t pos = start[h] + (atomicSub(&cnt[h], 1u) - 1u);  // cnt counts back down to zero
+    const uint32_t pos = start[h] + (atomicSub(&cnt[h], 1u) - 1u);  // cnt counts back down to zero
     grp[pos] = static_cast<uint32_t>(row);
     if (gkey != nullptr) gkey[pos] = make_ulonglong2(static_cast<uint64_t>(col_get_int(keys.c[0], row)), static_cast<uint64_t>(row));
   }
@@ -282,7 +288,7 @@ static constexpr int kChainCache = 8;  // matches per probe row that pass 1 hand
 struct ChainArgs {
   KeyCols probe, build;
   int64_t n;
-  const uint64_t *start;  // [nb + 1] bucket boundaries in grp / gkey
+  const uint32_t *start;  // [nb + 1] bucket boundaries in grp / gkey (row ids are 32-bit, so are these)
   const uint32_t *grp;    // build row ids, bucket by bucket
   const ulonglong2 *gkey; // {key value, row id} in the same order (single integer key column), else nullptr
   uint32_t nb_mask;
@@ -298,7 +304,7 @@ struct ChainArgs {
 // Iteration over the build rows whose key equals probe row i's: `ChainIter it = chain_begin(a, i); while (chain_next(a, i,
 // it, r)) ...`.
 struct ChainIter {
-  uint64_t p, e;
+  uint32_t p, e;
   int64_t k;
 };
 __device__ __forceinline__ ChainIter chain_begin(const ChainArgs &a, int64_t i) {
@@ -311,7 +317,7 @@ __device__ __forceinline__ ChainIter chain_begin(const ChainArgs &a, int64_t i) 
 }
 __device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainIter &it, int64_t &r) {
   while (it.p < it.e) {
-    const uint64_t p = it.p++;
+    const uint32_t p = it.p++;
     if (a.gkey != nullptr) {
       const ulonglong2 kr = a.gkey[p];  // key and row id in one 16-byte load
       if (static_cast<int64_t>(kr.x) != it.k) continue;
@@ -763,22 +769,26 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
       const DCol &bk = keys.c[0];
       const bool is_int = bk.type == CRGPU_INT16 || bk.type == CRGPU_INT32 || bk.type == CRGPU_INT64;
       j->chain_exact = keys.n == 1 && is_int && !j->null_eq;
-      CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 8));
+      CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 4));
+      CRGPU_TRY(j->offsets.ensure((static_cast<size_t>(nb) + 1) * 8));  // scan output before narrowing; the probe reuses it
       CRGPU_TRY(j->grp.ensure(static_cast<size_t>(n) * 4));
       if (j->chain_exact) CRGPU_TRY(j->gkey.ensure(static_cast<size_t>(n) * 16));
       ProfScope prof("join_build");
       hipLaunchKernelGGL(chain_hist_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n, j->null_eq, j->nb - 1,
                          j->first.as<uint32_t>(), j->next.as<uint32_t>());
       CRGPU_HIP(hipGetLastError());
-      CRGPU_TRY(exclusive_scan_u32(j->first.as<uint32_t>(), static_cast<int64_t>(nb), j->cstart.as<uint64_t>(),
+      CRGPU_TRY(exclusive_scan_u32(j->first.as<uint32_t>(), static_cast<int64_t>(nb), j->offsets.as<uint64_t>(),
                                    j->scratch, nullptr));
+      // half the footprint of the array every probe row reads at random
+      hipLaunchKernelGGL(chain_narrow_kernel, dim3(grid_for(static_cast<int64_t>(nb) + 1, 256)), dim3(256), 0, st,
+                         j->offsets.as<uint64_t>(), static_cast<int64_t>(nb) + 1, j->cstart.as<uint32_t>());
       hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n,
-                         j->next.as<uint32_t>(), j->cstart.as<uint64_t>(), j->first.as<uint32_t>(),
+                         j->next.as<uint32_t>(), j->cstart.as<uint32_t>(), j->first.as<uint32_t>(),
                          j->grp.as<uint32_t>(), j->chain_exact ? j->gkey.as<ulonglong2>() : nullptr);
       CRGPU_HIP(hipGetLastError());
     } else {
-      CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 8));
-      CRGPU_HIP(hipMemsetAsync(j->cstart.p, 0, (static_cast<size_t>(nb) + 1) * 8, st));
+      CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 4));
+      CRGPU_HIP(hipMemsetAsync(j->cstart.p, 0, (static_cast<size_t>(nb) + 1) * 4, st));
       CRGPU_TRY(j->grp.ensure(4));
       j->chain_exact = false;
     }
@@ -1078,7 +1088,7 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
       a.build.c[k] = j->build_cols[j->right_eq[k]];
     }
     a.n = n;
-    a.start = j->cstart.as<uint64_t>();
+    a.start = j->cstart.as<uint32_t>();
     a.grp = j->grp.as<uint32_t>();
     a.gkey = nullptr;
     if (j->chain_exact) {
