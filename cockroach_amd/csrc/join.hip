@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_
 }
 
 static constexpr int kChainCache = 8;  // matches per probe row that pass 1 hands to pass 3
+static constexpr int kChainChunk = 4;  // bucket entries requested per round trip
 
 struct ChainArgs {
   KeyCols probe, build;
@@ -342,14 +343,14 @@ __device__ __forceinline__ void chain_count_row(const ChainArgs &a, int64_t i, C
   uint32_t m[kChainCache];
 #pragma unroll
   for (int t = 0; t < kChainCache; t++) m[t] = t == 0 ? 0xFFFFFFFFu : 0u;
-  int64_t r;
-  while (chain_next(a, i, it, r)) {
+  // one match; false = this row needs no more
+  auto on_match = [&](int64_t r) -> bool {
     if (JT == CRGPU_INTERSECT_ALL || JT == CRGPU_EXCEPT_ALL) {
       if (atomicCAS(&a.claimed[r], 0u, 1u) == 0u) {
         found = true;
-        break;
+        return false;
       }
-      continue;
+      return true;
     }
     found = true;
 #pragma unroll
@@ -357,7 +358,24 @@ __device__ __forceinline__ void chain_count_row(const ChainArgs &a, int64_t i, C
       if (cnt == static_cast<uint32_t>(t)) m[t] = static_cast<uint32_t>(r);
     cnt++;
     if (a.matched != nullptr) a.matched[r] = 1;
-    if (JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI) break;
+    return !(JT == CRGPU_LEFT_SEMI || JT == CRGPU_LEFT_ANTI);
+  };
+  if (a.gkey != nullptr) {
+    // The entries of a bucket sit in one or two cache lines, but a load per entry, each waited for, still costs a
+    // cache round trip apiece: kChainChunk entries are requested at once.
+    bool go = true;
+    for (uint32_t p = it.p; go && p < it.e; p += kChainChunk) {
+      ulonglong2 e[kChainChunk];
+#pragma unroll
+      for (int t = 0; t < kChainChunk; t++) e[t] = a.gkey[p + t < it.e ? p + t : it.e - 1];
+#pragma unroll
+      for (int t = 0; t < kChainChunk; t++)
+        if (go && p + t < it.e && static_cast<int64_t>(e[t].x) == it.k) go = on_match(static_cast<int64_t>(e[t].y));
+    }
+  } else {
+    int64_t r;
+    while (chain_next(a, i, it, r))
+      if (!on_match(r)) break;
   }
   uint32_t out;
   switch (JT) {
@@ -474,11 +492,27 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
     if (cnt > kChainCache) {
       uint32_t written = 0;
       ChainIter it = chain_begin(a, i);
-      int64_t r;
-      while (written < cnt && chain_next(a, i, it, r)) {
-        a.pair_p[o + written] = static_cast<int32_t>(i);
-        a.pair_b[o + written] = static_cast<int32_t>(r);
-        written++;
+      if (a.gkey != nullptr) {
+        for (uint32_t p = it.p; written < cnt && p < it.e; p += kChainChunk) {
+          ulonglong2 e[kChainChunk];
+#pragma unroll
+          for (int t = 0; t < kChainChunk; t++) e[t] = a.gkey[p + t < it.e ? p + t : it.e - 1];
+#pragma unroll
+          for (int t = 0; t < kChainChunk; t++) {
+            if (written < cnt && p + t < it.e && static_cast<int64_t>(e[t].x) == it.k) {
+              a.pair_p[o + written] = static_cast<int32_t>(i);
+              a.pair_b[o + written] = static_cast<int32_t>(e[t].y);
+              written++;
+            }
+          }
+        }
+      } else {
+        int64_t r;
+        while (written < cnt && chain_next(a, i, it, r)) {
+          a.pair_p[o + written] = static_cast<int32_t>(i);
+          a.pair_b[o + written] = static_cast<int32_t>(r);
+          written++;
+        }
       }
     }
     __syncthreads();  // the next round overwrites s_off / s_m
