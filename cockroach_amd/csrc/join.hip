@@ -450,6 +450,14 @@ __global__ __launch_bounds__(256) void chain_fill_kernel(ChainArgs a) {
   }
 }
 
+// Orders a wave's LDS writes before its later LDS reads by other lanes of the SAME wave (a wave's LDS instructions execute
+// in order; the fences keep the compiler from moving them across this point).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // pass 3 of the pair-producing join types when pass 1 left its match cache: a wave expands its 64 probe rows into their
 // CONSECUTIVE output rows cooperatively - lane q of each round finds the probe row that owns output row q by a binary
 // search over the wave's exclusive counts in LDS - so pair_p / pair_b are written 256 bytes per store instruction
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
       for (int t = 0; t < kChainCache / 4; t++)
         *reinterpret_cast<uint4 *>(&s_m[wave][lane * kChainCache + 4 * t]) = a.mcache[static_cast<int64_t>(t) * a.n + i];
     }
-    __syncthreads();
+    wave_lds_sync();  // s_off / s_m rows are private to the wave: no block barrier, a wave with a long walk holds up nobody
     for (uint32_t q = lane; q < total; q += 64) {
       uint32_t src = 0;
 #pragma unroll
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
         }
       }
     }
-    __syncthreads();  // the next round overwrites s_off / s_m
+    wave_lds_sync();  // the next round overwrites s_off / s_m
   }
 }
 
