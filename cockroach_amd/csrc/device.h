@@ -174,6 +174,84 @@ __device__ inline bool keys_equal(const KeyCols &a, int64_t i, const KeyCols &b,
   }
   return true;
 }
+// keys_equal of probe row i against K build rows at once, column by column: the K loads of a column go out together
+// (branch-free per candidate), where K calls of keys_equal wait for each candidate's columns in turn.  eq[t] must come
+// in as "candidate t is to be tested".
+template <int K>
+__device__ __forceinline__ void keys_equal_chunk(const KeyCols &a, int64_t i, const KeyCols &b, const uint32_t (&rr)[K],
+                                                 bool null_eq, bool (&eq)[K]) {
+  for (int c = 0; c < a.n; c++) {
+    const DCol &x = a.c[c];
+    const DCol &y = b.c[c];
+    const bool xn = col_is_null(x, i);
+    bool yn[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) yn[t] = col_is_null(y, rr[t]);
+    bool same[K];
+    switch (x.type) {
+      case CRGPU_BOOL: {
+        const uint32_t pv = col_get_bool(x, i);
+#pragma unroll
+        for (int t = 0; t < K; t++) same[t] = pv == col_get_bool(y, rr[t]);
+        break;
+      }
+      case CRGPU_INT16:
+      case CRGPU_INT32:
+      case CRGPU_INT64: {
+        const int64_t pv = col_get_int(x, i);
+        int64_t bv[K];
+        switch (y.type) {  // hoisted out of the candidate loop so that its loads are issued back to back
+          case CRGPU_INT16:
+#pragma unroll
+            for (int t = 0; t < K; t++) bv[t] = reinterpret_cast<const int16_t *>(y.data)[rr[t]];
+            break;
+          case CRGPU_INT32:
+#pragma unroll
+            for (int t = 0; t < K; t++) bv[t] = reinterpret_cast<const int32_t *>(y.data)[rr[t]];
+            break;
+          default:
+#pragma unroll
+            for (int t = 0; t < K; t++) bv[t] = reinterpret_cast<const int64_t *>(y.data)[rr[t]];
+            break;
+        }
+#pragma unroll
+        for (int t = 0; t < K; t++) same[t] = pv == bv[t];
+        break;
+      }
+      case CRGPU_FLOAT64: {
+        const double pv = col_get_f64(x, i);
+#pragma unroll
+        for (int t = 0; t < K; t++) {
+          const double q = col_get_f64(y, rr[t]);
+          same[t] = pv == q || (pv != pv && q != q);
+        }
+        break;
+      }
+      case CRGPU_BYTES: {
+#pragma unroll
+        for (int t = 0; t < K; t++) {
+          same[t] = false;
+          if (eq[t] && !xn && !yn[t]) {
+            const uint32_t xa = x.offsets[i], xl = x.offsets[i + 1] - xa;
+            const uint32_t ya = y.offsets[rr[t]], yl = y.offsets[rr[t] + 1] - ya;
+            bool s = xl == yl;
+            const uint8_t *px = reinterpret_cast<const uint8_t *>(x.data) + xa;
+            const uint8_t *py = reinterpret_cast<const uint8_t *>(y.data) + ya;
+            for (uint32_t u = 0; s && u < xl; u++) s = px[u] == py[u];
+            same[t] = s;
+          }
+        }
+        break;
+      }
+      default:
+#pragma unroll
+        for (int t = 0; t < K; t++) same[t] = false;
+        break;
+    }
+#pragma unroll
+    for (int t = 0; t < K; t++) eq[t] = eq[t] && ((xn || yn[t]) ? (null_eq && xn && yn[t]) : same[t]);
+  }
+}
 __device__ __forceinline__ bool any_key_null(const KeyCols &k, int64_t i) {
   for (int c = 0; c < k.n; c++)
     if (col_is_null(k.c[c], i)) return true;

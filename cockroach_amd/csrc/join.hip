@@ -373,9 +373,19 @@ __device__ __forceinline__ void chain_count_row(const ChainArgs &a, int64_t i, C
         if (go && p + t < it.e && static_cast<int64_t>(e[t].x) == it.k) go = on_match(static_cast<int64_t>(e[t].y));
     }
   } else {
-    int64_t r;
-    while (chain_next(a, i, it, r))
-      if (!on_match(r)) break;
+    bool go = true;
+    for (uint32_t p = it.p; go && p < it.e; p += kChainChunk) {
+      uint32_t rr[kChainChunk];
+#pragma unroll
+      for (int t = 0; t < kChainChunk; t++) rr[t] = a.grp[p + t < it.e ? p + t : it.e - 1];
+      bool eq[kChainChunk];
+#pragma unroll
+      for (int t = 0; t < kChainChunk; t++) eq[t] = p + t < it.e;
+      keys_equal_chunk<kChainChunk>(a.probe, i, a.build, rr, a.null_eq != 0, eq);
+#pragma unroll
+      for (int t = 0; t < kChainChunk; t++)
+        if (go && eq[t]) go = on_match(static_cast<int64_t>(rr[t]));
+    }
   }
   uint32_t out;
   switch (JT) {
@@ -515,11 +525,22 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
           }
         }
       } else {
-        int64_t r;
-        while (written < cnt && chain_next(a, i, it, r)) {
-          a.pair_p[o + written] = static_cast<int32_t>(i);
-          a.pair_b[o + written] = static_cast<int32_t>(r);
-          written++;
+        for (uint32_t p = it.p; written < cnt && p < it.e; p += kChainChunk) {
+          uint32_t rr[kChainChunk];
+#pragma unroll
+          for (int t = 0; t < kChainChunk; t++) rr[t] = a.grp[p + t < it.e ? p + t : it.e - 1];
+          bool eq[kChainChunk];
+#pragma unroll
+          for (int t = 0; t < kChainChunk; t++) eq[t] = p + t < it.e;
+          keys_equal_chunk<kChainChunk>(a.probe, i, a.build, rr, a.null_eq != 0, eq);
+#pragma unroll
+          for (int t = 0; t < kChainChunk; t++) {
+            if (written < cnt && eq[t]) {
+              a.pair_p[o + written] = static_cast<int32_t>(i);
+              a.pair_b[o + written] = static_cast<int32_t>(rr[t]);
+              written++;
+            }
+          }
         }
       }
     }

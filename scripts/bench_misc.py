@@ -97,7 +97,7 @@ def bench_build(lg, reps, dv, g):
     return _line(f"build only: config J build side, 2^{lg} unique int64 keys + int64 payload", n, dt, n * 16.0, kern, None)
 
 
-def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
+def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4, two_cols=False):
     """The general (chained) join path: duplicate build keys, so the packed / radix tables do not apply.  INNER join,
     build keys drawn at random from nb/dup values (Poisson(dup) rows per key, `dup` on average); rows/s = (build + probe rows) / time for build + probe."""
     nb, npr = 1 << lg_b, 1 << lg_p
@@ -105,9 +105,14 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
     bv = torch.arange(nb, device=dv, dtype=torch.int64)
     pk = torch.randint(0, nb // dup, (npr,), generator=g, device=dv, dtype=torch.int64)
     pw = torch.arange(npr, device=dv, dtype=torch.int64)
-    build = [dev.from_torch(cd.INT64, bk), dev.from_torch(cd.INT64, bv)]
-    probe = [dev.from_torch(cd.INT64, pk), dev.from_torch(cd.INT64, pw)]
-    j = dev.Join(0, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], False, out_cols=[1, 3])
+    if two_cols:  # the same keys as two equality columns: equality is decided on the build columns, not in the table
+        build = [dev.from_torch(cd.INT64, bk >> 8), dev.from_torch(cd.INT64, bv), dev.from_torch(cd.INT64, bk & 255)]
+        probe = [dev.from_torch(cd.INT64, pk >> 8), dev.from_torch(cd.INT64, pw), dev.from_torch(cd.INT64, pk & 255)]
+        j = dev.Join(0, [cd.INT64] * 3, [cd.INT64] * 3, [0, 2], [0, 2], False, out_cols=[1, 4])
+    else:
+        build = [dev.from_torch(cd.INT64, bk), dev.from_torch(cd.INT64, bv)]
+        probe = [dev.from_torch(cd.INT64, pk), dev.from_torch(cd.INT64, pw)]
+        j = dev.Join(0, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], False, out_cols=[1, 3])
     out_rows = [0]
 
     def go():
@@ -118,7 +123,7 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
     kern = _kernels(["join_build", "join_probe", "radix_build_hist", "radix_build_scatter", "radix_build_split", "radix_build_table"], reps)
     j.close()
     cpu = None
-    if CPU_SAMPLE:
+    if CPU_SAMPLE and not two_cols:
         from oracle import oracle as O
         sb, sp = min(nb, CPU_SAMPLE // 4), min(npr, CPU_SAMPLE)
         hb = [cd.Vec.from_numpy(cd.INT64, (bk[:sb] % (sb // dup)).cpu().numpy()), cd.Vec.from_numpy(cd.INT64, bv[:sb].cpu().numpy())]
@@ -128,7 +133,7 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4):
         cdt = time.perf_counter() - t0
         cpu = {"value": (sb + sp) / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"{sb} build x {sp} probe rows of the same shape (keys folded to keep {dup} duplicates per key; oracle hashJoiner, 1 thread)"}
-    r = _line(f"general join (duplicate build keys, chained table): 2^{lg_b} build (random keys, {dup} rows per key on average) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
+    r = _line(f"general join (duplicate build keys, chained table{', two int64 key columns' if two_cols else ''}): 2^{lg_b} build (random keys, {dup} rows per key on average) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
               nb + npr, dt, 16.0 * nb + 16.0 * npr + 16.0 * out_rows[0], kern, cpu)
     r["output_rows"] = out_rows[0]
     return r
@@ -310,6 +315,8 @@ def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_r
         yield bench_join_then_agg(reps, dv, g)
     if want("general_join"):
         yield bench_general_join(reps, dv, g)
+    if want("general_join2"):
+        yield bench_general_join(reps, dv, g, two_cols=True)
     if want("router"):
         yield bench_router(lg_rows, reps, dv, g, 8)
     if want("g_distinct"):
