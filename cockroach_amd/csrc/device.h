@@ -175,8 +175,8 @@ __device__ inline bool keys_equal(const KeyCols &a, int64_t i, const KeyCols &b,
   return true;
 }
 // keys_equal of probe row i against K build rows at once, column by column: the K loads of a column go out together
-// (branch-free per candidate), where K calls of keys_equal wait for each candidate's columns in turn.  eq[t] must come
-// in as "candidate t is to be tested".
+// where K calls of keys_equal wait for each candidate's columns in turn.  eq[t] must come in as "candidate t is to be
+// tested"; nothing is loaded for the others.
 template <int K>
 __device__ __forceinline__ void keys_equal_chunk(const KeyCols &a, int64_t i, const KeyCols &b, const uint32_t (&rr)[K],
                                                  bool null_eq, bool (&eq)[K]) {
@@ -186,13 +186,13 @@ __device__ __forceinline__ void keys_equal_chunk(const KeyCols &a, int64_t i, co
     const bool xn = col_is_null(x, i);
     bool yn[K];
 #pragma unroll
-    for (int t = 0; t < K; t++) yn[t] = col_is_null(y, rr[t]);
+    for (int t = 0; t < K; t++) yn[t] = eq[t] && col_is_null(y, rr[t]);
     bool same[K];
     switch (x.type) {
       case CRGPU_BOOL: {
         const uint32_t pv = col_get_bool(x, i);
 #pragma unroll
-        for (int t = 0; t < K; t++) same[t] = pv == col_get_bool(y, rr[t]);
+        for (int t = 0; t < K; t++) same[t] = eq[t] && pv == col_get_bool(y, rr[t]);
         break;
       }
       case CRGPU_INT16:
@@ -203,15 +203,15 @@ __device__ __forceinline__ void keys_equal_chunk(const KeyCols &a, int64_t i, co
         switch (y.type) {  // hoisted out of the candidate loop so that its loads are issued back to back
           case CRGPU_INT16:
 #pragma unroll
-            for (int t = 0; t < K; t++) bv[t] = reinterpret_cast<const int16_t *>(y.data)[rr[t]];
+            for (int t = 0; t < K; t++) bv[t] = eq[t] ? reinterpret_cast<const int16_t *>(y.data)[rr[t]] : 0;
             break;
           case CRGPU_INT32:
 #pragma unroll
-            for (int t = 0; t < K; t++) bv[t] = reinterpret_cast<const int32_t *>(y.data)[rr[t]];
+            for (int t = 0; t < K; t++) bv[t] = eq[t] ? reinterpret_cast<const int32_t *>(y.data)[rr[t]] : 0;
             break;
           default:
 #pragma unroll
-            for (int t = 0; t < K; t++) bv[t] = reinterpret_cast<const int64_t *>(y.data)[rr[t]];
+            for (int t = 0; t < K; t++) bv[t] = eq[t] ? reinterpret_cast<const int64_t *>(y.data)[rr[t]] : 0;
             break;
         }
 #pragma unroll
@@ -222,7 +222,7 @@ __device__ __forceinline__ void keys_equal_chunk(const KeyCols &a, int64_t i, co
         const double pv = col_get_f64(x, i);
 #pragma unroll
         for (int t = 0; t < K; t++) {
-          const double q = col_get_f64(y, rr[t]);
+          const double q = eq[t] ? col_get_f64(y, rr[t]) : 0.0;
           same[t] = pv == q || (pv != pv && q != q);
         }
         break;

@@ -286,11 +286,47 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_
 static constexpr int kChainCache = 8;  // matches per probe row that pass 1 hands to pass 3
 static constexpr int kChainChunk = 4;  // bucket entries requested per round trip
 
+// Generic keys (several columns, BYTES, floats): equality is decided on the build columns, a random read per column and
+// candidate - and most candidates of a bucket are duplicates of one key.  Once per build, every bucket entry among the
+// first kRepSpan of its bucket learns the offset of the FIRST entry with an equal key (its representative; itself if
+// there is none); a probe row then verifies representatives only and lets the others follow them.  kRepSelf = verify
+// this entry itself (entries beyond the span).
+static constexpr uint32_t kRepSpan = 64;
+static constexpr uint8_t kRepSelf = 255;
+__global__ __launch_bounds__(256) void chain_mark_kernel(KeyCols keys, int64_t nb, bool null_eq,
+                                                         const uint32_t *__restrict__ start,
+                                                         const uint32_t *__restrict__ grp, uint8_t *__restrict__ rep8) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nb; b += stride) {
+    const uint32_t s = start[b], e = start[b + 1];
+    uint64_t reps = 0;  // offsets (< kRepSpan) that are representatives
+    for (uint32_t j = s; j < e; j++) {
+      const uint32_t off = j - s;
+      if (off >= kRepSpan) {
+        rep8[j] = kRepSelf;
+        continue;
+      }
+      uint32_t rep = off;
+      const int64_t rj = grp[j];
+      for (uint64_t m = reps; m != 0; m &= m - 1) {
+        const uint32_t q = static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(m))) - 1u;
+        if (keys_equal(keys, rj, keys, static_cast<int64_t>(grp[s + q]), null_eq)) {
+          rep = q;
+          break;
+        }
+      }
+      if (rep == off) reps |= 1ull << off;
+      rep8[j] = static_cast<uint8_t>(rep);
+    }
+  }
+}
+
 struct ChainArgs {
   KeyCols probe, build;
   int64_t n;
   const uint32_t *start;  // [nb + 1] bucket boundaries in grp / gkey (row ids are 32-bit, so are these)
   const uint32_t *grp;    // build row ids, bucket by bucket
+  const uint8_t *rep8;    // generic keys: offset in the bucket of each entry's representative (chain_mark_kernel), or nullptr
   const ulonglong2 *gkey; // {key value, row id} in the same order (single integer key column), else nullptr
   uint32_t nb_mask;
   int32_t null_eq;
@@ -330,6 +366,31 @@ __device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainI
   }
   return false;
 }
+
+// One chunk of a generic-key bucket walk: loads kChainChunk row ids (rr) and their representative offsets, verifies the
+// entries that stand for themselves against probe row i (keys_equal_chunk) and lets the others take their
+// representative's verdict from `okmask`; leaves eq[t] = "entry p + t matches".  Expects a, i, rr, eq, okmask in scope.
+#define CHAIN_GENERIC_CHUNK(P, S0, E)                                                                              \
+  {                                                                                                                \
+    uint32_t rp_[kChainChunk];                                                                                     \
+    bool self_[kChainChunk];                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < kChainChunk; t++) {                                                      \
+      const uint32_t q_ = (P) + t < (E) ? (P) + t : (E)-1;                                                         \
+      rr[t] = a.grp[q_];                                                                                           \
+      rp_[t] = a.rep8 != nullptr ? a.rep8[q_] : kRepSelf;                                                          \
+    }                                                                                                              \
+    _Pragma("unroll") for (int t = 0; t < kChainChunk; t++) {                                                      \
+      self_[t] = rp_[t] == kRepSelf || rp_[t] == (P) + t - (S0);                                                   \
+      eq[t] = (P) + t < (E) && self_[t];                                                                           \
+    }                                                                                                              \
+    keys_equal_chunk<kChainChunk>(a.probe, i, a.build, rr, a.null_eq != 0, eq);                                    \
+    _Pragma("unroll") for (int t = 0; t < kChainChunk; t++) {                                                      \
+      if ((P) + t < (E)) {                                                                                         \
+        if (!self_[t]) eq[t] = (okmask >> rp_[t]) & 1ull;                                                          \
+        else if (eq[t] && rp_[t] != kRepSelf) okmask |= 1ull << rp_[t];                                            \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
 
 // pass 1: number of output rows each probe row produces (and all side effects:
 // matched marks, claims).  `it` is the row's started bucket walk (empty for a row whose NULL key matches nothing).
@@ -374,14 +435,11 @@ __device__ __forceinline__ void chain_count_row(const ChainArgs &a, int64_t i, C
     }
   } else {
     bool go = true;
+    uint64_t okmask = 0;  // representatives (by offset in the bucket) that equal this row's key
     for (uint32_t p = it.p; go && p < it.e; p += kChainChunk) {
       uint32_t rr[kChainChunk];
-#pragma unroll
-      for (int t = 0; t < kChainChunk; t++) rr[t] = a.grp[p + t < it.e ? p + t : it.e - 1];
       bool eq[kChainChunk];
-#pragma unroll
-      for (int t = 0; t < kChainChunk; t++) eq[t] = p + t < it.e;
-      keys_equal_chunk<kChainChunk>(a.probe, i, a.build, rr, a.null_eq != 0, eq);
+      CHAIN_GENERIC_CHUNK(p, it.p, it.e)
 #pragma unroll
       for (int t = 0; t < kChainChunk; t++)
         if (go && eq[t]) go = on_match(static_cast<int64_t>(rr[t]));
@@ -525,14 +583,11 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
           }
         }
       } else {
+        uint64_t okmask = 0;
         for (uint32_t p = it.p; written < cnt && p < it.e; p += kChainChunk) {
           uint32_t rr[kChainChunk];
-#pragma unroll
-          for (int t = 0; t < kChainChunk; t++) rr[t] = a.grp[p + t < it.e ? p + t : it.e - 1];
           bool eq[kChainChunk];
-#pragma unroll
-          for (int t = 0; t < kChainChunk; t++) eq[t] = p + t < it.e;
-          keys_equal_chunk<kChainChunk>(a.probe, i, a.build, rr, a.null_eq != 0, eq);
+          CHAIN_GENERIC_CHUNK(p, it.p, it.e)
 #pragma unroll
           for (int t = 0; t < kChainChunk; t++) {
             if (written < cnt && eq[t]) {
@@ -601,7 +656,7 @@ struct crgpu_join {
   bool use_radix = false;
   // chained table
   DevBuf first, next;          // chained table: per-bucket counters (zero again once built), per-row bucket numbers
-  DevBuf cstart, grp, gkey;    // bucket boundaries, row ids and (single integer key) key values bucket by bucket
+  DevBuf cstart, grp, gkey, rep8;    // bucket boundaries, row ids and (single integer key) key values bucket by bucket
   bool chain_exact = false;    // gkey is in use: equal gkey <=> equal key
   uint32_t nb = 0;
   // marks
@@ -849,6 +904,13 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
                          j->next.as<uint32_t>(), j->cstart.as<uint32_t>(), j->first.as<uint32_t>(),
                          j->grp.as<uint32_t>(), j->chain_exact ? j->gkey.as<ulonglong2>() : nullptr);
       CRGPU_HIP(hipGetLastError());
+      if (!j->chain_exact) {
+        CRGPU_TRY(j->rep8.ensure(static_cast<size_t>(n)));
+        hipLaunchKernelGGL(chain_mark_kernel, dim3(grid_for(static_cast<int64_t>(nb), 256)), dim3(256), 0, st, keys,
+                           static_cast<int64_t>(nb), j->null_eq, j->cstart.as<uint32_t>(), j->grp.as<uint32_t>(),
+                           j->rep8.as<uint8_t>());
+        CRGPU_HIP(hipGetLastError());
+      }
     } else {
       CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 4));
       CRGPU_HIP(hipMemsetAsync(j->cstart.p, 0, (static_cast<size_t>(nb) + 1) * 4, st));
@@ -1154,6 +1216,7 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     a.start = j->cstart.as<uint32_t>();
     a.grp = j->grp.as<uint32_t>();
     a.gkey = nullptr;
+    a.rep8 = j->chain_exact ? nullptr : j->rep8.as<uint8_t>();
     if (j->chain_exact) {
       const int pt = a.probe.c[0].type;
       if (pt == CRGPU_INT16 || pt == CRGPU_INT32 || pt == CRGPU_INT64) a.gkey = j->gkey.as<ulonglong2>();
