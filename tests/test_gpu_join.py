@@ -59,10 +59,12 @@ def test_join_random_int_keys_vs_oracle(oracle, jt, unique_right):
 @pytest.mark.parametrize("match_cache", ["1", "0"])
 def test_join_duplicate_counts_around_the_match_cache(oracle, jt, key_type, match_cache, monkeypatch):
     """Build keys with 0..24 duplicates each: the probe's first pass hands the first 8 matches of a row to the pass that
-    writes the pairs, rows with more walk their bucket again (join.hip, kChainCache); a probe wave mixes all of them."""
+    writes the pairs, rows with more walk their bucket again (join.hip, kChainCache); a probe wave mixes all of them.
+    FLOAT64 keys take the generic walk (representative marks, chain_mark_kernel), one key has 156 rows."""
     monkeypatch.setenv("CRGPU_JOIN_MATCH_CACHE", match_cache)  # "0": the path probe chunks beyond 2^28 rows take
     rng = np.random.default_rng(5)
     rk = np.repeat(np.arange(1, 25 * 8 + 1), np.tile(np.arange(25), 8)).astype(np.int64)  # key k has (k-1) % 25 rows
+    rk = np.concatenate([rk, np.full(150, 7, dtype=np.int64)])  # one bucket beyond the 64 entries that carry representative marks
     rng.shuffle(rk)
     lk = rng.integers(-5, 25 * 8 + 10, size=3000).astype(np.int64)
     nl, nr = len(lk), len(rk)
