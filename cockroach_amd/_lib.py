@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrgpu.so")
 
-OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM, ERR_INT_OUT_OF_RANGE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_DUPLICATE = range(9)
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_OOM, ERR_INT_OUT_OF_RANGE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_DUPLICATE, ERR_CANCELLED = range(10)
 
 
 class CrgpuError(RuntimeError):
@@ -82,6 +82,8 @@ SYMBOLS = [
     ("crgpu_shutdown", None, []),
     ("crgpu_last_error", C.c_char_p, []),
     ("crgpu_mem_usage", _I64, []),
+    ("crgpu_live_handles", _I64, []),
+    ("crgpu_cancel", _I32, [_VP]),
     ("crgpu_prof_enable", None, [_I32]),
     ("crgpu_prof_reset", None, []),
     ("crgpu_prof_get", _I32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_I64)]),

@@ -1837,7 +1837,7 @@ struct AggOpHost {
   uint64_t any_tail = 0;
 };
 
-struct crgpu_agg {
+struct crgpu_agg : crgpu::Handle {
   std::vector<int> types, group_cols;
   std::vector<AggOpHost> ops;
   bool need_any_fix = false;
@@ -2029,6 +2029,11 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
   if (spec->n_group < 0 || spec->n_group > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: at most 8 grouping columns");
   if (spec->n_aggs < 1 || spec->n_aggs > kMaxAggs) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: between 1 and 64 aggregations");
   std::unique_ptr<crgpu_agg> a(new crgpu_agg());
+  {
+    crgpu_status _os = a->open();
+    if (_os != CRGPU_OK) {  return _os; }
+  }
+  CRGPU_ENTER(a.get());
   for (int i = 0; i < spec->n_cols; i++) {
     if (!valid_type(spec->types[i])) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: unsupported column type");
     a->types.push_back(spec->types[i]);
@@ -2131,12 +2136,13 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
 
 extern "C" void crgpu_dev_agg_destroy(crgpu_agg *a) {
   if (a == nullptr) return;
-  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
   delete a;
 }
 
 extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   if (a == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_reset: null handle");
+  CRGPU_ENTER(a);
+  a->cancelled = 0;
   a->ngroups = 0;
   a->seq = 0;
   a->new_ratio = 1.0;
@@ -2807,6 +2813,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
 
 extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
   if (a == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null handle");
+  CRGPU_ENTER(a);
+  CRGPU_CHECK_CANCEL(a);
   if (n < 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: negative row count");
   if (n == 0) return CRGPU_OK;
   if (cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null columns");
@@ -2876,6 +2884,8 @@ static bool alias_source(crgpu_agg *a, const AggOpHost &op, const AggOpDev &dev,
 
 extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res) {
   if (a == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_finish: null argument");
+  CRGPU_ENTER(a);
+  CRGPU_CHECK_CANCEL(a);
   hipStream_t st = stream();
   const int64_t ng = a->ngroups;
   CRGPU_TRY(upload_descriptors(a, nullptr));

@@ -29,9 +29,58 @@ crgpu_status hip_fail(hipError_t e, const char *what, const char *file, int line
   } while (0)
 
 // ------------------------------------------------------------------ runtime
-hipStream_t stream();        // the library stream (created by crgpu_init)
-crgpu_status ensure_init();  // lazily crgpu_init(current device)
+// One library context per HIP device (crgpu_init): a default stream for the handle-less calls, the CU count, the
+// no-allocation scratch pointer.  Every OS thread has a "library device" (the last crgpu_init on that thread, else the
+// first device the process initialised); every handle remembers the device it was created on and owns a HIP stream, so
+// two operator chains on two goroutines do not serialise on each other and one process can drive several GPUs.
+static constexpr int kMaxDevices = 16;
+hipStream_t stream();        // the calling thread's current stream: the handle's inside a handle call, else the device's default stream
+crgpu_status ensure_init();  // binds the calling thread to its library device (lazily crgpu_init); cheap when already bound
 int num_cus();
+int current_device();        // the calling thread's library device (-1 before any init)
+void mark_default_work();    // a handle-less call queued asynchronous work on the default stream: handle calls order themselves after it
+
+static constexpr uint32_t kHandleMagic = 0x43524748u;  // "CRGH"
+// First base of every handle struct (crgpu_join, crgpu_agg, ...): crgpu_cancel() accepts any of them.
+struct Handle {
+  uint32_t magic = kHandleMagic;
+  int device = -1;
+  hipStream_t st = nullptr;
+  hipEvent_t ev = nullptr;      // orders st after the work queued so far on the device's default stream
+  uint64_t seen_epoch = 0;
+  volatile int32_t cancelled = 0;  // set by crgpu_cancel from any thread; sticky until reset
+  Handle() = default;
+  Handle(const Handle &) = delete;
+  Handle &operator=(const Handle &) = delete;
+  crgpu_status open();  // binds to the calling thread's library device and creates the stream
+  void close();
+  ~Handle() { close(); }
+};
+// First base of the layer-2 shells (crgpu_hj, crgpu_ha, crgpu_ud, crgpu_router): they run on their device handle's
+// stream and are cancelled through it.
+static constexpr uint32_t kShellMagic = 0x43524753u;  // "CRGS"
+struct Shell {
+  uint32_t magic = kShellMagic;
+  Handle *inner = nullptr;
+  ~Shell() { magic = 0; }
+};
+// RAII for one extern "C" call: binds the thread to the handle's device (or, without a handle, to its library device),
+// makes the handle's stream the thread's current stream() and restores both on exit.  Nests (layer 2 calls layer 1).
+struct CallScope {
+  hipStream_t prev_stream;
+  int prev_device;
+  bool prev_in_call;
+  crgpu_status st;
+  explicit CallScope(Handle *h);
+  ~CallScope();
+};
+#define CRGPU_ENTER(h)            \
+  ::crgpu::CallScope _scope(h);   \
+  if (_scope.st != CRGPU_OK) return _scope.st
+#define CRGPU_CHECK_CANCEL(h)                                                                         \
+  do {                                                                                                \
+    if ((h)->cancelled) return ::crgpu::fail(CRGPU_ERR_CANCELLED, "operation cancelled (crgpu_cancel)"); \
+  } while (0)
 
 // Grow-only device buffer; every byte is accounted in crgpu_mem_usage().
 struct DevBuf {
@@ -121,6 +170,10 @@ crgpu_status materialize(const DCol &src, const int32_t *idx, int64_t n, bool fo
 // Exclusive prefix sum of uint32 counts into uint64 offsets[n+1] (offsets[n] = total); returns total on host.
 crgpu_status exclusive_scan_u32(const uint32_t *counts, int64_t n, uint64_t *offsets, DevBuf &scratch,
                                 uint64_t *total_host);
+// Same with caller-provided tile-sum scratch of scan_scratch_words(n) uint64 words (allocates nothing).
+size_t scan_scratch_words(int64_t n);
+crgpu_status exclusive_scan_u32_ws(const uint32_t *counts, int64_t n, uint64_t *offsets, uint64_t *tile_sums,
+                                   uint64_t *total_host);
 // idx_out[k] = i for every i in [0,n) with flags[i] != 0 (stable order); *count_host = number selected.
 crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, DevBuf &scratch,
                             int64_t *count_host);

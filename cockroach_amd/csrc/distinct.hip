@@ -212,7 +212,7 @@ static inline int dgrid(int64_t n) {
 
 using namespace crgpu;
 
-struct crgpu_distinct {
+struct crgpu_distinct : crgpu::Handle {
   std::vector<int> types, dcols;
   bool nulls_are_distinct = false, error_on_dup = false;
   bool expect_new = true;  // the last batch was mostly new keys (the first one is assumed to be)
@@ -269,6 +269,11 @@ extern "C" crgpu_status crgpu_dev_distinct_create(const int32_t *types, int32_t 
   if (n_cols < 1 || n_cols > kMaxCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_create: column count out of range");
   if (n_distinct < 1 || n_distinct > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_create: between 1 and 8 distinct columns");
   std::unique_ptr<crgpu_distinct> d(new crgpu_distinct());
+  {
+    crgpu_status _os = d->open();
+    if (_os != CRGPU_OK) {  return _os; }
+  }
+  CRGPU_ENTER(d.get());
   for (int i = 0; i < n_cols; i++) {
     if (!valid_type(types[i])) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_create: unsupported column type");
     d->types.push_back(types[i]);
@@ -288,12 +293,13 @@ extern "C" crgpu_status crgpu_dev_distinct_create(const int32_t *types, int32_t 
 
 extern "C" void crgpu_dev_distinct_destroy(crgpu_distinct *d) {
   if (d == nullptr) return;
-  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
   delete d;
 }
 
 extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
   if (d == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_reset: null handle");
+  CRGPU_ENTER(d);
+  d->cancelled = 0;
   hipStream_t st = stream();
   if (d->cap) CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(d->cap) * 8, st));
   d->ngroups = 0;
@@ -305,6 +311,8 @@ extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
 
 extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *res) {
   if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null argument");
+  CRGPU_ENTER(d);
+  CRGPU_CHECK_CANCEL(d);
   if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_consume: at most 2^31 rows per call");
   if (n > 0 && cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null columns");
   const int nc = static_cast<int>(d->types.size());

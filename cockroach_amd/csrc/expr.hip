@@ -16,6 +16,8 @@
 // are unspecified as in the reference.  Outputs are caller-provided device buffers.
 //
 // Roofline: HBM streaming, 8-24 B read and 1-8 B written per row.
+#include <cstring>
+
 #include "device.h"
 
 namespace crgpu {
@@ -77,6 +79,60 @@ __global__ __launch_bounds__(256) void and_bitmaps_kernel(const uint8_t *__restr
     out[i] = static_cast<uint8_t>((a ? a[i] : 0xFF) & (b ? b[i] : 0xFF));
 }
 
+// BYTES column against a constant: EQ / NE (selEQBytesBytesConstOp, selNEBytesBytesConstOp) and LIKE '%c%'
+// (selContainsBytesBytesConstOp, case-sensitive form).  The constant travels in the kernel arguments (<= 64 bytes).
+static constexpr int kMaxBytesConst = 64;
+struct BytesConst {
+  uint8_t b[kMaxBytesConst];
+  uint32_t len;
+};
+enum { BCMP_EQ = 0, BCMP_NE = 1, BCMP_CONTAINS = 6, BCMP_NOT_CONTAINS = 7 };
+__global__ __launch_bounds__(256) void select_bytes_const_kernel(int op, const uint8_t *__restrict__ data,
+                                                                 const uint32_t *__restrict__ offsets,
+                                                                 const uint8_t *__restrict__ valid, BytesConst c, int64_t n,
+                                                                 uint8_t *__restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t o = offsets[i], len = offsets[i + 1] - o;
+    const uint8_t *p = data + o;
+    bool r;
+    if (op == BCMP_EQ || op == BCMP_NE) {
+      bool eq = len == c.len;
+      for (uint32_t t = 0; eq && t < c.len; t++) eq = p[t] == c.b[t];
+      r = (op == BCMP_EQ) == eq;
+    } else {
+      bool found = c.len == 0;  // bytes.Contains(x, "") is true
+      for (uint32_t s0 = 0; !found && s0 + c.len <= len; s0++) {
+        bool m = true;
+        for (uint32_t t = 0; m && t < c.len; t++) m = p[s0 + t] == c.b[t];
+        found = m;
+      }
+      r = (op == BCMP_CONTAINS) == found;
+    }
+    if (valid != nullptr && !((valid[i >> 3] >> (i & 7)) & 1)) r = false;  // a NULL never passes
+    out[i] = r ? 1 : 0;
+  }
+}
+
+// EXTRACT(year FROM date): the year of a DATE (int64 days since 1970-01-01, coldata canonical family Int) as FLOAT64.
+// Proleptic Gregorian calendar, the same as Go's time.Time.Year() that the reference's builtin returns
+// (sem/builtins/builtins.go:11946 via colexecbuiltins.defaultBuiltinFuncOperator, builtin_funcs.go:44).
+__device__ __forceinline__ long long year_of_days(long long z) {
+  z += 719468;  // days from 0000-03-01
+  const long long era = (z >= 0 ? z : z - 146096) / 146097;
+  const unsigned long long doe = static_cast<unsigned long long>(z - era * 146097);             // [0, 146096]
+  const unsigned long long yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;         // [0, 399]
+  const long long y = static_cast<long long>(yoe) + era * 400;
+  const unsigned long long doy = doe - (365 * yoe + yoe / 4 - yoe / 100);                       // [0, 365]
+  const unsigned long long mp = (5 * doy + 2) / 153;                                            // [0, 11]
+  return y + (mp >= 10 ? 1 : 0);  // January and February belong to the next civil year
+}
+__global__ __launch_bounds__(256) void extract_year_kernel(const long long *__restrict__ days, int64_t n, double *__restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = static_cast<double>(year_of_days(days[i]));
+}
+
 static inline int egrid(int64_t n) {
   int64_t want = (n + 255) / 256;
   const int64_t cap = static_cast<int64_t>(num_cus()) * 16;
@@ -89,7 +145,7 @@ static inline int egrid(int64_t n) {
 using namespace crgpu;
 
 extern "C" crgpu_status crgpu_dev_select_i64_const(int32_t cmp, const crgpu_dcol *col, int64_t cst, int64_t n, uint8_t *out_bool) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (col == nullptr || (n > 0 && (col->data == nullptr || out_bool == nullptr)))
     return fail(CRGPU_ERR_INVALID, "crgpu_dev_select_i64_const: null argument");
   if (col->type != CRGPU_INT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_select_i64_const: INT64 columns only");
@@ -105,12 +161,13 @@ extern "C" crgpu_status crgpu_dev_select_i64_const(int32_t cmp, const crgpu_dcol
   }
 #undef CRGPU_SEL
   CRGPU_HIP(hipGetLastError());
+  mark_default_work();
   return CRGPU_OK;
 }
 
 extern "C" crgpu_status crgpu_dev_project_f64(int32_t op, const crgpu_dcol *a, double a_const, const crgpu_dcol *b, double b_const,
                                               int64_t n, double *out_data, uint8_t *out_valid) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (a == nullptr && b == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_project_f64: two constants");
   if (op < BIN_PLUS || op > BIN_MULT_ONE_PLUS) return fail(CRGPU_ERR_INVALID, "crgpu_dev_project_f64: unknown operator");
   for (const crgpu_dcol *c : {a, b}) {
@@ -141,5 +198,41 @@ extern "C" crgpu_status crgpu_dev_project_f64(int32_t op, const crgpu_dcol *a, d
     hipLaunchKernelGGL(and_bitmaps_kernel, dim3(egrid((n + 7) / 8)), dim3(256), 0, st, av, bv, (n + 7) / 8, out_valid);
     CRGPU_HIP(hipGetLastError());
   }
+  mark_default_work();
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_select_bytes_const(int32_t cmp, const crgpu_dcol *col, const uint8_t *cst, int32_t cst_len,
+                                                     int64_t n, uint8_t *out_bool) {
+  CRGPU_ENTER(nullptr);
+  if (col == nullptr || cst_len < 0 || (cst_len > 0 && cst == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_select_bytes_const: null argument");
+  if (col->type != CRGPU_BYTES) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_select_bytes_const: BYTES columns only");
+  if (!(cmp == BCMP_EQ || cmp == BCMP_NE || cmp == BCMP_CONTAINS || cmp == BCMP_NOT_CONTAINS))
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_select_bytes_const: EQ (0), NE (1), CONTAINS (6) and NOT CONTAINS (7) only");
+  if (cst_len > kMaxBytesConst) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_select_bytes_const: constants of up to 64 bytes");
+  if (n <= 0) return CRGPU_OK;
+  if (col->offsets == nullptr || out_bool == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_select_bytes_const: null offsets / output");
+  BytesConst c;
+  std::memset(&c, 0, sizeof(c));
+  c.len = static_cast<uint32_t>(cst_len);
+  if (cst_len) std::memcpy(c.b, cst, static_cast<size_t>(cst_len));
+  ProfScope prof("expr_select");
+  hipLaunchKernelGGL(select_bytes_const_kernel, dim3(egrid(n)), dim3(256), 0, stream(), static_cast<int>(cmp),
+                     static_cast<const uint8_t *>(col->data), col->offsets, col->valid, c, n, out_bool);
+  CRGPU_HIP(hipGetLastError());
+  mark_default_work();
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_extract_year(const crgpu_dcol *days, int64_t n, double *out_data) {
+  CRGPU_ENTER(nullptr);
+  if (days == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_extract_year: null argument");
+  if (days->type != CRGPU_INT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_extract_year: DATE columns are INT64 days since the epoch");
+  if (n <= 0) return CRGPU_OK;
+  if (days->data == nullptr || out_data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_extract_year: null data pointer");
+  ProfScope prof("expr_project");
+  hipLaunchKernelGGL(extract_year_kernel, dim3(egrid(n)), dim3(256), 0, stream(), static_cast<const long long *>(days->data), n, out_data);
+  CRGPU_HIP(hipGetLastError());
+  mark_default_work();
   return CRGPU_OK;
 }

@@ -180,16 +180,15 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_u32_kernel(const uint32
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = tile_sums[gridDim.x];
 }
 
-crgpu_status exclusive_scan_u32(const uint32_t *counts, int64_t n, uint64_t *offsets, DevBuf &scratch,
-                                uint64_t *total_host) {
+size_t scan_scratch_words(int64_t n) { return static_cast<size_t>((n > 0 ? (n + kScanTile - 1) / kScanTile : 0) + 1); }
+
+crgpu_status exclusive_scan_u32_ws(const uint32_t *counts, int64_t n, uint64_t *offsets, uint64_t *ts, uint64_t *total_host) {
   if (n <= 0) {
     if (total_host) *total_host = 0;
     if (offsets) CRGPU_HIP(hipMemsetAsync(offsets, 0, 8, stream()));
     return CRGPU_OK;
   }
   int64_t ntiles = (n + kScanTile - 1) / kScanTile;
-  CRGPU_TRY(scratch.ensure(static_cast<size_t>(ntiles + 1) * 8));
-  uint64_t *ts = scratch.as<uint64_t>();
   hipLaunchKernelGGL(tile_sum_kernel<uint32_t>, dim3(ntiles), dim3(kScanBlock), 0, stream(), counts, n, ts);
   hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream(), ts, ntiles);
   hipLaunchKernelGGL(scan_apply_u32_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), counts, n, ts, offsets);
@@ -199,6 +198,12 @@ crgpu_status exclusive_scan_u32(const uint32_t *counts, int64_t n, uint64_t *off
     CRGPU_HIP(hipStreamSynchronize(stream()));
   }
   return CRGPU_OK;
+}
+
+crgpu_status exclusive_scan_u32(const uint32_t *counts, int64_t n, uint64_t *offsets, DevBuf &scratch,
+                                uint64_t *total_host) {
+  if (n > 0) CRGPU_TRY(scratch.ensure(scan_scratch_words(n) * 8));
+  return exclusive_scan_u32_ws(counts, n, offsets, scratch.as<uint64_t>(), total_host);
 }
 
 __global__ __launch_bounds__(kScanBlock) void select_apply_kernel(const uint8_t *__restrict__ flags, int64_t n,

@@ -49,7 +49,7 @@ using namespace crgpu;
 
 extern "C" crgpu_status crgpu_dev_hash_cols(const crgpu_dcol *cols, int32_t ncols, int64_t n, uint64_t init,
                                             int32_t width, uint64_t nbuckets, void *out_dev) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (ncols < 0 || ncols > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_hash_cols: more than 8 key columns");
   if (width != 32 && width != 64) return fail(CRGPU_ERR_INVALID, "crgpu_dev_hash_cols: width must be 32 or 64");
   if (n < 0 || (n > 0 && out_dev == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_hash_cols: bad n/out");

@@ -286,7 +286,7 @@ using namespace crgpu;
 // ====================================================================== crgpu_hash_cols
 extern "C" crgpu_status crgpu_hash_cols(const crgpu_col *cols, int32_t ncols, int64_t n, const int64_t *sel,
                                         uint64_t init, int32_t width, uint64_t nbuckets, void *out_host) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (n < 0 || ncols < 0 || ncols > kMaxKeyCols) return fail(CRGPU_ERR_INVALID, "crgpu_hash_cols: bad n / ncols");
   if (width != 32 && width != 64) return fail(CRGPU_ERR_INVALID, "crgpu_hash_cols: width must be 32 or 64");
   if (n == 0) return CRGPU_OK;
@@ -310,7 +310,7 @@ extern "C" crgpu_status crgpu_hash_cols(const crgpu_col *cols, int32_t ncols, in
 }
 
 // ====================================================================== hash joiner shell
-struct crgpu_hj {
+struct crgpu_hj : crgpu::Shell {
   crgpu_join *dev = nullptr;
   std::vector<int> left_types, right_types;
   std::vector<HostCol> build_stage, probe_stage;
@@ -328,6 +328,7 @@ extern "C" crgpu_status crgpu_hj_new(const crgpu_join_spec *spec, crgpu_hj **out
   CRGPU_TRY(crgpu_dev_join_create(spec, &dev));
   auto h = new crgpu_hj();
   h->dev = dev;
+  h->inner = reinterpret_cast<Handle *>(dev);
   for (int i = 0; i < spec->n_left_cols; i++) h->left_types.push_back(spec->left_types[i]);
   for (int i = 0; i < spec->n_right_cols; i++) h->right_types.push_back(spec->right_types[i]);
   init_cols(h->build_stage, h->right_types);
@@ -344,6 +345,7 @@ extern "C" void crgpu_hj_free(crgpu_hj *h) {
 
 extern "C" crgpu_status crgpu_hj_reset(crgpu_hj *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_reset: null handle");
+  CRGPU_ENTER(h->inner);
   CRGPU_TRY(crgpu_dev_join_reset(h->dev));
   clear_cols(h->build_stage);
   clear_cols(h->probe_stage);
@@ -357,12 +359,15 @@ extern "C" crgpu_status crgpu_hj_reset(crgpu_hj *h) {
 
 extern "C" crgpu_status crgpu_hj_build_append(crgpu_hj *h, const crgpu_batch *right) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_build_append: null handle");
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->state != crgpu_hj::BUILDING) return fail(CRGPU_ERR_STATE, "crgpu_hj_build_append: the build side is already finished");
   return stage_batch(h->build_stage, right);
 }
 
 extern "C" crgpu_status crgpu_hj_build_finish(crgpu_hj *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_build_finish: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->state != crgpu_hj::BUILDING) return fail(CRGPU_ERR_STATE, "crgpu_hj_build_finish: called twice");
   CRGPU_TRY(upload_table(h->build_stage, h->build_dev));
   CRGPU_TRY(crgpu_dev_join_build(h->dev, h->build_dev.cols.data(), h->build_dev.n));
@@ -391,6 +396,8 @@ static crgpu_status hj_flush_probe(crgpu_hj *h) {
 
 extern "C" crgpu_status crgpu_hj_probe_append(crgpu_hj *h, const crgpu_batch *left) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_probe_append: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->state != crgpu_hj::PROBING) return fail(CRGPU_ERR_STATE, "crgpu_hj_probe_append: build side not finished or probe side already finished");
   CRGPU_TRY(stage_batch(h->probe_stage, left));
   if (!h->probe_stage.empty() && h->probe_stage[0].n >= kFlushRows) CRGPU_TRY(hj_flush_probe(h));
@@ -399,6 +406,8 @@ extern "C" crgpu_status crgpu_hj_probe_append(crgpu_hj *h, const crgpu_batch *le
 
 extern "C" crgpu_status crgpu_hj_probe_finish(crgpu_hj *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_probe_finish: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->state != crgpu_hj::PROBING) return fail(CRGPU_ERR_STATE, "crgpu_hj_probe_finish: not probing");
   CRGPU_TRY(hj_flush_probe(h));
   crgpu_dev_result r;
@@ -414,6 +423,8 @@ extern "C" crgpu_status crgpu_hj_probe_finish(crgpu_hj *h) {
 
 extern "C" crgpu_status crgpu_hj_next_output(crgpu_hj *h, crgpu_out_batch *out) {
   if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_next_output: null argument");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   out->length = 0;
   while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
   if (h->outq.empty() && h->state == crgpu_hj::PROBING) CRGPU_TRY(hj_flush_probe(h));
@@ -422,6 +433,7 @@ extern "C" crgpu_status crgpu_hj_next_output(crgpu_hj *h, crgpu_out_batch *out) 
 
 extern "C" crgpu_status crgpu_hj_export_buffered(crgpu_hj *h, crgpu_out_batch *out) {
   if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_export_buffered: null argument");
+  CRGPU_ENTER(h->inner);
   out->length = 0;
   if (!h->export_copy) {
     h->export_copy.reset(new HostResult());
@@ -444,7 +456,7 @@ extern "C" crgpu_status crgpu_hj_export_buffered(crgpu_hj *h, crgpu_out_batch *o
 }
 
 // ====================================================================== hash aggregator shell
-struct crgpu_ha {
+struct crgpu_ha : crgpu::Shell {
   crgpu_agg *dev = nullptr;
   std::vector<int> types;
   std::vector<HostCol> stage;
@@ -459,6 +471,7 @@ extern "C" crgpu_status crgpu_agg_new(const crgpu_agg_spec *spec, crgpu_ha **out
   CRGPU_TRY(crgpu_dev_agg_create(spec, &dev));
   auto h = new crgpu_ha();
   h->dev = dev;
+  h->inner = reinterpret_cast<Handle *>(dev);
   for (int i = 0; i < spec->n_cols; i++) h->types.push_back(spec->types[i]);
   init_cols(h->stage, h->types);
   *out = h;
@@ -473,6 +486,7 @@ extern "C" void crgpu_agg_free(crgpu_ha *h) {
 
 extern "C" crgpu_status crgpu_agg_reset(crgpu_ha *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_reset: null handle");
+  CRGPU_ENTER(h->inner);
   CRGPU_TRY(crgpu_dev_agg_reset(h->dev));
   clear_cols(h->stage);
   h->outq.clear();
@@ -491,6 +505,8 @@ static crgpu_status ha_flush(crgpu_ha *h) {
 
 extern "C" crgpu_status crgpu_agg_append(crgpu_ha *h, const crgpu_batch *in) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_append: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->finished) return fail(CRGPU_ERR_STATE, "crgpu_agg_append: input already finished");
   if (h->types.empty()) {
     // no input columns at all (COUNT_ROWS only): nothing to stage but the row count matters
@@ -503,6 +519,8 @@ extern "C" crgpu_status crgpu_agg_append(crgpu_ha *h, const crgpu_batch *in) {
 
 extern "C" crgpu_status crgpu_agg_finish(crgpu_ha *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_finish: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->finished) return fail(CRGPU_ERR_STATE, "crgpu_agg_finish: called twice");
   CRGPU_TRY(ha_flush(h));
   crgpu_dev_result r;
@@ -518,13 +536,15 @@ extern "C" crgpu_status crgpu_agg_finish(crgpu_ha *h) {
 
 extern "C" crgpu_status crgpu_agg_next_output(crgpu_ha *h, crgpu_out_batch *out) {
   if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_next_output: null argument");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   out->length = 0;
   if (!h->finished) return CRGPU_OK;  // the hash aggregator emits only after its input is exhausted
   return emit_from_queue(h->outq, out);
 }
 
 // ====================================================================== unordered distinct shell
-struct crgpu_ud {
+struct crgpu_ud : crgpu::Shell {
   crgpu_distinct *dev = nullptr;
   std::vector<int> types;
   std::vector<HostCol> stage;
@@ -541,6 +561,7 @@ extern "C" crgpu_status crgpu_distinct_new(const int32_t *types, int32_t n_cols,
   CRGPU_TRY(crgpu_dev_distinct_create(types, n_cols, distinct_cols, n_distinct, nulls_are_distinct, error_on_dup, &dev));
   auto h = new crgpu_ud();
   h->dev = dev;
+  h->inner = reinterpret_cast<Handle *>(dev);
   for (int i = 0; i < n_cols; i++) h->types.push_back(types[i]);
   init_cols(h->stage, h->types);
   *out = h;
@@ -555,6 +576,7 @@ extern "C" void crgpu_distinct_free(crgpu_ud *h) {
 
 extern "C" crgpu_status crgpu_distinct_reset(crgpu_ud *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_reset: null handle");
+  CRGPU_ENTER(h->inner);
   CRGPU_TRY(crgpu_dev_distinct_reset(h->dev));
   clear_cols(h->stage);
   h->outq.clear();
@@ -581,6 +603,8 @@ static crgpu_status ud_flush(crgpu_ud *h) {
 
 extern "C" crgpu_status crgpu_distinct_append(crgpu_ud *h, const crgpu_batch *in) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_append: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   if (h->finished) return fail(CRGPU_ERR_STATE, "crgpu_distinct_append: input already finished");
   CRGPU_TRY(stage_batch(h->stage, in));
   if (!h->stage.empty() && h->stage[0].n >= kFlushRows) CRGPU_TRY(ud_flush(h));
@@ -589,12 +613,16 @@ extern "C" crgpu_status crgpu_distinct_append(crgpu_ud *h, const crgpu_batch *in
 
 extern "C" crgpu_status crgpu_distinct_finish(crgpu_ud *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_finish: null handle");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   h->finished = true;
   return ud_flush(h);
 }
 
 extern "C" crgpu_status crgpu_distinct_next_output(crgpu_ud *h, crgpu_out_batch *out) {
   if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_next_output: null argument");
+  CRGPU_ENTER(h->inner);
+  CRGPU_CHECK_CANCEL(h->inner);
   out->length = 0;
   while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
   // the operator streams (unordered_distinct.go:113-119): nothing queued => push what is staged through the device
@@ -603,7 +631,7 @@ extern "C" crgpu_status crgpu_distinct_next_output(crgpu_ud *h, crgpu_out_batch 
 }
 
 // ====================================================================== hash router shell
-struct crgpu_router {
+struct crgpu_router : crgpu::Shell {
   crgpu_partitioner *dev = nullptr;
   std::vector<int> types;
   int num_outputs = 0;
@@ -621,6 +649,7 @@ extern "C" crgpu_status crgpu_route_new(const int32_t *types, int32_t n_cols, co
   CRGPU_TRY(crgpu_dev_partitioner_create(types, n_cols, hash_cols, n_hash, 1, num_outputs, &dev));
   auto r = new crgpu_router();
   r->dev = dev;
+  r->inner = reinterpret_cast<Handle *>(dev);
   r->num_outputs = num_outputs;
   for (int i = 0; i < n_cols; i++) r->types.push_back(types[i]);
   init_cols(r->stage, r->types);
@@ -678,6 +707,8 @@ static crgpu_status route_flush(crgpu_router *r) {
 extern "C" crgpu_status crgpu_route_partition(crgpu_router *r, const crgpu_batch *in) {
   if (r == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_partition: null handle");
   std::lock_guard<std::mutex> lk(r->mu);
+  CRGPU_ENTER(r->inner);
+  CRGPU_CHECK_CANCEL(r->inner);
   CRGPU_TRY(stage_batch(r->stage, in));
   if (!r->stage.empty() && r->stage[0].n >= kFlushRows) CRGPU_TRY(route_flush(r));
   return CRGPU_OK;
@@ -686,6 +717,8 @@ extern "C" crgpu_status crgpu_route_partition(crgpu_router *r, const crgpu_batch
 extern "C" crgpu_status crgpu_route_finish(crgpu_router *r) {
   if (r == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_finish: null handle");
   std::lock_guard<std::mutex> lk(r->mu);
+  CRGPU_ENTER(r->inner);
+  CRGPU_CHECK_CANCEL(r->inner);
   return route_flush(r);
 }
 
@@ -693,6 +726,8 @@ extern "C" crgpu_status crgpu_route_next_output(crgpu_router *r, int32_t output,
   if (r == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_route_next_output: null argument");
   if (output < 0 || output >= r->num_outputs) return fail(CRGPU_ERR_INVALID, "crgpu_route_next_output: output index out of range");
   std::lock_guard<std::mutex> lk(r->mu);
+  CRGPU_ENTER(r->inner);
+  CRGPU_CHECK_CANCEL(r->inner);
   out->length = 0;
   auto &q = r->outq[output];
   while (!q.empty() && q.front()->cursor >= q.front()->n) q.pop_front();

@@ -627,7 +627,7 @@ static inline uint64_t next_pow2(uint64_t x) {
 using namespace crgpu;
 
 // ====================================================================== handle
-struct crgpu_join {
+struct crgpu_join : crgpu::Handle {
   int join_type = 0;
   bool right_distinct = false;      // after the MakeHashJoinerSpec overrides
   bool track_build_matches = false;
@@ -689,6 +689,11 @@ extern "C" crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu
   if (spec->n_left_cols < 0 || spec->n_right_cols < 1 || spec->n_left_cols > kMaxCols || spec->n_right_cols > kMaxCols)
     return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_create: column count out of range");
   auto j = new crgpu_join();
+  {
+    crgpu_status _os = j->open();
+    if (_os != CRGPU_OK) { delete j; return _os; }
+  }
+  CRGPU_ENTER(j);
   j->join_type = spec->join_type;
   for (int i = 0; i < spec->n_left_cols; i++) j->left_types.push_back(spec->left_types[i]);
   for (int i = 0; i < spec->n_right_cols; i++) j->right_types.push_back(spec->right_types[i]);
@@ -754,12 +759,13 @@ extern "C" crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu
 
 extern "C" void crgpu_dev_join_destroy(crgpu_join *j) {
   if (j == nullptr) return;
-  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
   delete j;
 }
 
 extern "C" crgpu_status crgpu_dev_join_reset(crgpu_join *j) {
   if (j == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_reset: null handle");
+  CRGPU_ENTER(j);
+  j->cancelled = 0;
   j->built = false;
   j->n_build = 0;
   j->build_cols.clear();
@@ -792,6 +798,8 @@ static RadixSrc radix_src(const DCol &key, const DCol *pay) {
 
 extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
   if (j == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null handle");
+  CRGPU_ENTER(j);
+  CRGPU_CHECK_CANCEL(j);
   if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_build: build side limited to 2^31 rows per table");
   if (n > 0 && right_cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null columns");
   const int nr = static_cast<int>(j->right_types.size());
@@ -1273,6 +1281,8 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
 extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
                                              crgpu_dev_result *res) {
   if (j == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: null argument");
+  CRGPU_ENTER(j);
+  CRGPU_CHECK_CANCEL(j);
   if (!j->built) return fail(CRGPU_ERR_STATE, "crgpu_dev_join_probe: build side not built");
   if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_probe: at most 2^31 rows per probe chunk");
   if (n > 0 && left_cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: null columns");
@@ -1300,6 +1310,8 @@ extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *le
 
 extern "C" crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_result *res) {
   if (j == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_emit_right: null argument");
+  CRGPU_ENTER(j);
+  CRGPU_CHECK_CANCEL(j);
   if (!j->built) return fail(CRGPU_ERR_STATE, "crgpu_dev_join_emit_right: build side not built");
   join_setup_outputs(j);
   const int jt = j->join_type;

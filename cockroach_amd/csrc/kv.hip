@@ -619,7 +619,7 @@ static inline int kv_grid(int64_t n, int block) {
 
 using namespace crgpu;
 
-struct crgpu_decoder {
+struct crgpu_decoder : crgpu::Handle {
   FetchSpec spec;
   DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
   std::vector<OutCol> out;
@@ -634,6 +634,11 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
       s->n_out_cols < 0 || s->n_out_cols > kMaxOutFetch || s->key_prefix_len < 0)
     return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decoder_create: at most 8 key columns, 32 value columns, 32 outputs");
   auto d = new crgpu_decoder();
+  {
+    crgpu_status _os = d->open();
+    if (_os != CRGPU_OK) { delete d; return _os; }
+  }
+  CRGPU_ENTER(d);
   FetchSpec &f = d->spec;
   std::memset(&f, 0, sizeof(f));
   f.key_prefix_len = s->key_prefix_len;
@@ -683,7 +688,6 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
 
 extern "C" void crgpu_dev_decoder_destroy(crgpu_decoder *d) {
   if (d == nullptr) return;
-  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
   delete d;
 }
 
@@ -701,6 +705,8 @@ static crgpu_status kv_check_error(crgpu_decoder *d, const char *phase) {
 extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
                                             int64_t n_batches, crgpu_dev_result *res) {
   if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: null argument");
+  CRGPU_ENTER(d);
+  CRGPU_CHECK_CANCEL(d);
   if (n_batches < 0 || (n_batches > 0 && (batch_offsets_host == nullptr || repr_dev == nullptr)))
     return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: null batches");
   if (n_batches > 0x7FFFFFFF) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: too many batches");

@@ -115,7 +115,7 @@ __global__ void part_counts_kernel(const uint64_t *__restrict__ bases, int64_t n
 
 using namespace crgpu;
 
-struct crgpu_partitioner {
+struct crgpu_partitioner : crgpu::Handle {
   std::vector<int> types, hash_cols;
   uint64_t init = 1;
   int P = 1;
@@ -137,6 +137,11 @@ extern "C" crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32
     return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partitioner_create: between 1 and 1024 outputs");
   if (init == 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partitioner_create: init hash value must be non-zero (hash_utils.go:64)");
   auto p = new crgpu_partitioner();
+  {
+    crgpu_status _os = p->open();
+    if (_os != CRGPU_OK) { delete p; return _os; }
+  }
+  CRGPU_ENTER(p);
   for (int i = 0; i < n_cols; i++) {
     if (!valid_type(types[i])) { delete p; return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partitioner_create: unsupported column type"); }
     p->types.push_back(types[i]);
@@ -156,13 +161,14 @@ extern "C" crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32
 
 extern "C" void crgpu_dev_partitioner_destroy(crgpu_partitioner *p) {
   if (p == nullptr) return;
-  if (stream() != nullptr) (void)hipStreamSynchronize(stream());
   delete p;
 }
 
 extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n,
                                             crgpu_dev_result *res, int64_t *counts_host) {
   if (p == nullptr || res == nullptr || counts_host == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: null argument");
+  CRGPU_ENTER(p);
+  CRGPU_CHECK_CANCEL(p);
   if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition: at most 2^31 rows per call");
   if (n > 0 && cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: null columns");
   const int nc = static_cast<int>(p->types.size());

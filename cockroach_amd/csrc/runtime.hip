@@ -1,4 +1,5 @@
-// runtime.hip -- library lifecycle, error reporting, memory accounting, HIP-event profiling.
+// runtime.hip -- library lifecycle, per-device contexts, per-handle streams, error reporting, memory accounting,
+// HIP-event profiling, cancellation.
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -9,11 +10,21 @@
 
 namespace crgpu {
 
+struct DeviceCtx {
+  std::atomic<bool> ready{false};
+  hipStream_t stream = nullptr;  // default stream: handle-less calls (hash, select, project, raw copies)
+  int cus = 256;
+  std::atomic<uint64_t> epoch{0};  // bumped by every asynchronous handle-less call
+};
+
 static thread_local std::string t_err;
+static thread_local int t_device = -1;            // this thread's library device
+static thread_local hipStream_t t_stream = nullptr;  // current handle stream inside a handle call
+static thread_local bool t_in_call = false;
 static std::atomic<int64_t> g_mem{0};
-static hipStream_t g_stream = nullptr;
-static int g_device = -1;
-static int g_cus = 256;
+static std::atomic<int64_t> g_handles{0};
+static std::atomic<int> g_default_device{-1};
+static DeviceCtx g_dev[kMaxDevices];
 static std::mutex g_mu;
 
 void set_error(const std::string &msg) { t_err = msg; }
@@ -29,14 +40,119 @@ crgpu_status hip_fail(hipError_t e, const char *what, const char *file, int line
   return e == hipErrorOutOfMemory ? CRGPU_ERR_OOM : CRGPU_ERR_HIP;
 }
 
-hipStream_t stream() { return g_stream; }
-int num_cus() { return g_cus; }
+int current_device() { return t_device; }
+hipStream_t stream() {
+  if (t_stream != nullptr) return t_stream;
+  return t_device >= 0 ? g_dev[t_device].stream : nullptr;
+}
+int num_cus() { return t_device >= 0 ? g_dev[t_device].cus : 256; }
+void mark_default_work() {
+  if (t_device >= 0) g_dev[t_device].epoch.fetch_add(1, std::memory_order_release);
+}
+
+// hipSetDevice only affects the calling OS thread, and cgo calls arrive on arbitrary threads: every entry point
+// re-binds (one hipGetDevice when nothing changed).
+static crgpu_status bind_thread(int device) {
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device) CRGPU_HIP(hipSetDevice(device));
+  t_device = device;
+  return CRGPU_OK;
+}
+
+static crgpu_status init_device(int device) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(CRGPU_ERR_NO_DEVICE, "crgpu_init: no HIP device visible (the GPU path has no CPU fallback)");
+  if (device < 0 || device >= count || device >= kMaxDevices)
+    return fail(CRGPU_ERR_INVALID, "crgpu_init: device ordinal out of range");
+  CRGPU_TRY(bind_thread(device));
+  DeviceCtx &d = g_dev[device];
+  if (d.ready.load(std::memory_order_acquire)) return CRGPU_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (d.ready.load(std::memory_order_acquire)) return CRGPU_OK;
+  hipDeviceProp_t prop;
+  CRGPU_HIP(hipGetDeviceProperties(&prop, device));
+  d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  CRGPU_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  int none = -1;
+  g_default_device.compare_exchange_strong(none, device);
+  d.ready.store(true, std::memory_order_release);
+  return CRGPU_OK;
+}
 
 crgpu_status ensure_init() {
-  if (g_stream != nullptr) return CRGPU_OK;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  return crgpu_init(dev);
+  int device = t_device;
+  if (device < 0) device = g_default_device.load();
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (!g_dev[device < kMaxDevices && device >= 0 ? device : 0].ready.load(std::memory_order_acquire)) return init_device(device);
+  return bind_thread(device);
+}
+
+crgpu_status Handle::open() {
+  CRGPU_TRY(ensure_init());
+  device = t_device;
+  CRGPU_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  CRGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  g_handles.fetch_add(1);
+  return CRGPU_OK;
+}
+void Handle::close() {
+  if (st != nullptr) {
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    st = nullptr;
+    g_handles.fetch_sub(1);
+  }
+  if (ev != nullptr) {
+    (void)hipEventDestroy(ev);
+    ev = nullptr;
+  }
+  magic = 0;
+}
+
+CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_device(t_device), prev_in_call(t_in_call), st(CRGPU_OK) {
+  if (h == nullptr) {
+    if (!t_in_call) {  // a handle-less call nested in a handle call keeps the handle's stream
+      st = ensure_init();
+      t_stream = nullptr;
+    }
+    t_in_call = true;
+    return;
+  }
+  if (h->magic != kHandleMagic || h->st == nullptr) {
+    st = fail(CRGPU_ERR_INVALID, "invalid or destroyed handle");
+    return;
+  }
+  if (!g_dev[h->device].ready.load(std::memory_order_acquire)) {
+    st = fail(CRGPU_ERR_STATE, "the handle's device was shut down (crgpu_shutdown)");
+    return;
+  }
+  st = bind_thread(h->device);
+  if (st != CRGPU_OK) return;
+  if (!t_in_call || t_stream == nullptr) {
+    t_stream = h->st;
+    // results of handle-less calls queued on the default stream (projections, selections, hashes) feed handle calls
+    DeviceCtx &d = g_dev[h->device];
+    const uint64_t ep = d.epoch.load(std::memory_order_acquire);
+    if (ep != h->seen_epoch) {
+      hipError_t e = hipEventRecord(h->ev, d.stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(h->st, h->ev, 0);
+      if (e != hipSuccess) {
+        st = hip_fail(e, "order after the default stream", __FILE__, __LINE__);
+        return;
+      }
+      h->seen_epoch = ep;
+    }
+  }  // else: a layer-2 shell already made ITS device handle current; nested device handles run on that stream
+  t_in_call = true;
+}
+CallScope::~CallScope() {
+  t_stream = prev_stream;
+  t_in_call = prev_in_call;
+  if (prev_device >= 0 && prev_device != t_device && g_dev[prev_device].ready.load()) (void)bind_thread(prev_device);
 }
 
 crgpu_status DevBuf::ensure(size_t bytes, bool keep) {
@@ -84,7 +200,7 @@ struct ProfEntry {
   double ms = 0;
   int64_t launches = 0;
 };
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static std::map<std::string, ProfEntry> g_prof;
 struct Pending {
   std::string name;
@@ -92,7 +208,7 @@ struct Pending {
 };
 static std::vector<Pending> g_pending;
 
-static void drain_pending() {
+static void drain_pending() {  // g_mu held
   for (auto &p : g_pending) {
     float ms = 0;
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
@@ -105,7 +221,7 @@ static void drain_pending() {
   g_pending.clear();
 }
 
-ProfScope::ProfScope(const char *n) : name(n), on(g_prof_on) {
+ProfScope::ProfScope(const char *n) : name(n), on(g_prof_on.load(std::memory_order_relaxed)) {
   if (!on) return;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
     on = false;
@@ -126,43 +242,45 @@ using namespace crgpu;
 
 extern "C" {
 
-crgpu_status crgpu_init(int32_t device) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (g_stream != nullptr && g_device == device) return CRGPU_OK;
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0)
-    return fail(CRGPU_ERR_NO_DEVICE, "crgpu_init: no HIP device visible (the GPU path has no CPU fallback)");
-  if (device < 0 || device >= count) return fail(CRGPU_ERR_INVALID, "crgpu_init: device ordinal out of range");
-  CRGPU_HIP(hipSetDevice(device));
-  hipDeviceProp_t prop;
-  CRGPU_HIP(hipGetDeviceProperties(&prop, device));
-  g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (g_stream != nullptr) {
-    (void)hipStreamDestroy(g_stream);
-    g_stream = nullptr;
-  }
-  CRGPU_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  g_device = device;
-  return CRGPU_OK;
-}
+crgpu_status crgpu_init(int32_t device) { return init_device(device); }
 
 void crgpu_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   drain_pending();
-  if (g_stream != nullptr) {
-    (void)hipStreamSynchronize(g_stream);
-    (void)hipStreamDestroy(g_stream);
-    g_stream = nullptr;
+  if (g_handles.load() > 0) {
+    // live handles own streams and buffers on these devices: tearing the contexts down under them would leave them
+    // launching on destroyed streams.  Free the handles first.
+    set_error("crgpu_shutdown: handles are still alive; nothing was torn down");
+    return;
   }
-  g_device = -1;
+  for (int i = 0; i < kMaxDevices; i++) {
+    DeviceCtx &d = g_dev[i];
+    if (!d.ready.load()) continue;
+    d.ready.store(false);
+    if (d.stream != nullptr) {
+      (void)hipStreamSynchronize(d.stream);
+      (void)hipStreamDestroy(d.stream);
+      d.stream = nullptr;
+    }
+  }
+  g_default_device.store(-1);
+  t_device = -1;
 }
 
 const char *crgpu_last_error(void) { return t_err.c_str(); }
 int64_t crgpu_mem_usage(void) { return g_mem.load(); }
+int64_t crgpu_live_handles(void) { return g_handles.load(); }
+
+crgpu_status crgpu_cancel(void *handle) {
+  Handle *h = static_cast<Handle *>(handle);
+  if (h != nullptr && h->magic == kShellMagic) h = static_cast<Shell *>(handle)->inner;  // layer-2 shell: cancel its device handle
+  if (h == nullptr || h->magic != kHandleMagic) return fail(CRGPU_ERR_INVALID, "crgpu_cancel: not a live handle");
+  h->cancelled = 1;
+  return CRGPU_OK;
+}
 
 crgpu_status crgpu_dev_malloc(void **out, size_t bytes) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_malloc: null out");
   *out = nullptr;
   CRGPU_HIP(hipMalloc(out, bytes ? bytes : 1));
@@ -172,25 +290,25 @@ void crgpu_dev_free(void *p) {
   if (p != nullptr) (void)hipFree(p);
 }
 crgpu_status crgpu_dev_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (bytes == 0) return CRGPU_OK;
   CRGPU_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
   return CRGPU_OK;
 }
 crgpu_status crgpu_dev_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes) {
-  CRGPU_TRY(ensure_init());
+  CRGPU_ENTER(nullptr);
   if (bytes == 0) return CRGPU_OK;
-  CRGPU_HIP(hipStreamSynchronize(stream()));
+  CRGPU_HIP(hipDeviceSynchronize());  // whichever handle's stream produced src_dev
   CRGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
   return CRGPU_OK;
 }
 crgpu_status crgpu_dev_synchronize(void) {
-  CRGPU_TRY(ensure_init());
-  CRGPU_HIP(hipStreamSynchronize(stream()));
+  CRGPU_ENTER(nullptr);
+  CRGPU_HIP(hipDeviceSynchronize());
   return CRGPU_OK;
 }
 
-void crgpu_prof_enable(int32_t on) { g_prof_on = on != 0; }
+void crgpu_prof_enable(int32_t on) { g_prof_on.store(on != 0); }
 void crgpu_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   drain_pending();

@@ -48,6 +48,8 @@ typedef int32_t crgpu_status;
 #define CRGPU_ERR_STATE 7            /* call made in the wrong operator state */
 #define CRGPU_ERR_DUPLICATE 8        /* unordered DISTINCT with errorOnDup saw a duplicate: the shell raises the plan's message
                                         (colexecbase.UpsertDistinctHelper.MaybeEmitErrorOnDup) */
+#define CRGPU_ERR_CANCELLED 9        /* crgpu_cancel was called on the handle: the shell returns the context's error
+                                        (colexecutils.CancelChecker, sql/colexec/colexecutils/cancel_checker.go:68) */
 
 /* canonical type families: col/typeconv/typeconv.go:30 */
 typedef enum {
@@ -67,10 +69,25 @@ typedef enum {
 } crgpu_agg_func;
 
 /* ------------------------------------------------------------ lifecycle */
-/* Selects HIP device `device` for the calling process (one process per GPU)
- * and creates the library stream.  Idempotent. */
+/* Initialises HIP device `device` for the library (default stream, CU count) and makes it the CALLING THREAD's
+ * library device; the first device a process initialises is also the default for threads that never called
+ * crgpu_init.  Idempotent per device; a process may initialise several devices (one Go process, 8 GPUs).
+ * hipSetDevice is per OS thread and cgo calls arrive on arbitrary threads, so EVERY entry point re-binds the
+ * calling thread: handle calls to the device the handle was created on, handle-less calls to the thread's library
+ * device.  Every handle owns its own HIP stream: calls on different handles from different threads run
+ * concurrently; calls on ONE handle stay single-threaded (operator.go:36,54) except crgpu_route_* and crgpu_cancel. */
 crgpu_status crgpu_init(int32_t device);
+/* Tears the device contexts down.  Refused (no-op, message in crgpu_last_error) while any handle is alive: free
+ * the handles first. */
 void crgpu_shutdown(void);
+/* Handles currently alive (every crgpu_*_create / crgpu_*_new not yet destroyed / freed). */
+int64_t crgpu_live_handles(void);
+/* Asks the operation running (or about to run) on `handle` -- any handle type of this header -- to stop: the flag
+ * is checked at entry and between the device passes / staged chunks of a call, which then returns
+ * CRGPU_ERR_CANCELLED.  Callable from any thread (the Go shell calls it when ctx.Done() fires, the way
+ * colexecutils.CancelChecker polls ctx in the reference, cancel_checker.go:68; hash loops check it at
+ * hash_utils_tmpl.go:151, hashtable.go:816).  Sticky until the handle's reset. */
+crgpu_status crgpu_cancel(void *handle);
 /* Message of the last failing call on this thread ("" if none). */
 const char *crgpu_last_error(void);
 /* Device bytes currently held by the library; the Go shell reports the delta
@@ -87,7 +104,8 @@ crgpu_status crgpu_prof_get(const char *name, double *total_ms, int64_t *launche
 
 /* Raw device memory helpers for callers that do not bring their own allocator
  * (the Go shell stages coldata batches through these; torch callers pass
- * tensor.data_ptr() instead).  Copies are synchronous. */
+ * tensor.data_ptr() instead).  Copies are synchronous; crgpu_dev_memcpy_d2h and
+ * crgpu_dev_synchronize wait for every stream of the thread's library device. */
 crgpu_status crgpu_dev_malloc(void **out, size_t bytes);
 void crgpu_dev_free(void *p);
 crgpu_status crgpu_dev_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
