@@ -268,6 +268,51 @@ def project_f64(op, a, b, out=None) -> DeviceColumn:
     return DeviceColumn(cd.FLOAT64, n, out.ptr, valid.ptr if valid else None, None, keep=(out, valid, a, b))
 
 
+BCMP = {"EQ": 0, "NE": 1, "CONTAINS": 6, "NOT CONTAINS": 7}
+
+
+def select_bytes_const(cmp, col: DeviceColumn, cst: bytes, out=None) -> DeviceColumn:
+    """crgpu_dev_select_bytes_const: BOOL column, 1 where `col <cmp> cst` holds (EQ, NE, CONTAINS = LIKE '%cst%')."""
+    out = out or DeviceBuffer(max(col.n, 1))
+    d = col.dcol()
+    _lib.check(_lib.load().crgpu_dev_select_bytes_const(BCMP[cmp], C.byref(d), bytes(cst), len(cst), col.n, out.ptr))
+    return DeviceColumn(cd.BOOL, col.n, out.ptr, None, None, keep=(out, col))
+
+
+def extract_year(col: DeviceColumn, out=None) -> DeviceColumn:
+    """crgpu_dev_extract_year: EXTRACT(year FROM date) as FLOAT64."""
+    out = out or DeviceBuffer(max(col.n, 2) * 8)
+    d = col.dcol()
+    _lib.check(_lib.load().crgpu_dev_extract_year(C.byref(d), col.n, out.ptr))
+    return DeviceColumn(cd.FLOAT64, col.n, out.ptr, col.valid_ptr, None, keep=(out, col))
+
+
+class Deselector:
+    """crgpu_deselector handle: the rows a BOOL column keeps, as dense device columns (deselectorOp)."""
+
+    def __init__(self, types):
+        self._types = _i32arr(types)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_deselector_create(self._types, len(types), C.byref(self.h)))
+
+    def deselect(self, cols, keep: DeviceColumn, n=None) -> _lib.DevResult:
+        n = (cols[0].n if cols else 0) if n is None else n
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_deselect(self.h, dcol_array(cols), n, keep.data_ptr, C.byref(res)))
+        return res
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_deselector_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FilteredAgg:
     """Hash aggregation under a WHERE clause without moving rows: the selection's BOOL column becomes the FILTER of
     every aggregate (group-key ANY_NOT_NULLs excepted) plus a hidden COUNT_ROWS, and groups that no passing row

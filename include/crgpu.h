@@ -253,6 +253,31 @@ crgpu_status crgpu_dev_select_i64_const(int32_t cmp, const crgpu_dcol *col, int6
 crgpu_status crgpu_dev_project_f64(int32_t op, const crgpu_dcol *a, double a_const, const crgpu_dcol *b, double b_const,
                                    int64_t n, double *out_data, uint8_t *out_valid);
 
+/* crgpu_dev_select_bytes_const: replaces colexecsel.selEQBytesBytesConstOp.Next / selNEBytesBytesConstOp.Next
+ * (colexecsel/selection_ops.eg.go:358,10050) and, for LIKE '%c%' patterns, selContainsBytesBytesConstOp.Next
+ * (colexecsel/sel_like_ops.eg.go:229; case-sensitive form).  cmp: 0 EQ, 1 NE, 6 CONTAINS, 7 NOT CONTAINS; the
+ * constant is at most 64 bytes.  Writes a BOOL column like crgpu_dev_select_i64_const (NULL never passes).
+ * Q3: c_mktsegment = 'BUILDING' (tpch_vec:20588); Q9: p_name LIKE '%green%' (tpch_vec:20731). */
+crgpu_status crgpu_dev_select_bytes_const(int32_t cmp, const crgpu_dcol *col, const uint8_t *cst, int32_t cst_len,
+                                          int64_t n, uint8_t *out_bool);
+
+/* crgpu_dev_extract_year: EXTRACT(year FROM d) of a DATE column (INT64 days since 1970-01-01, typeconv.go:46-47) as
+ * FLOAT64 -- what the reference evaluates row by row through colexecbuiltins.defaultBuiltinFuncOperator.Next
+ * (colexecbuiltins/builtin_funcs.go:44) and sem/builtins extractTimeSpanFromTimestamp (builtins.go:11946:
+ * tree.DFloat(fromTime.Year())).  Q9's o_year group key (tpch_vec:20715-20720).  The column must not hold NULLs
+ * (pass its validity bitmap on to the consumer otherwise; values under a NULL are unspecified). */
+crgpu_status crgpu_dev_extract_year(const crgpu_dcol *days, int64_t n, double *out_data);
+
+/* ---- deselection: replaces colexecutils.deselectorOp.Next (sql/colexec/colexecutils/deselector.go:48-80): the rows
+ * whose keep_bool byte (a BOOL column produced by crgpu_dev_select_*, device memory) is non-zero, in input order,
+ * as dense library-owned columns (valid until the next call on the handle).  Used in front of a join input; in
+ * front of an aggregator pass the BOOL column as the aggregates' FILTER instead (no row moves). */
+typedef struct crgpu_deselector crgpu_deselector;
+crgpu_status crgpu_dev_deselector_create(const int32_t *types, int32_t n_cols, crgpu_deselector **out);
+crgpu_status crgpu_dev_deselect(crgpu_deselector *d, const crgpu_dcol *cols, int64_t n, const uint8_t *keep_bool,
+                                crgpu_dev_result *out);
+void crgpu_dev_deselector_destroy(crgpu_deselector *d);
+
 /* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for indexes that store one KV per
  * row (MaxKeysPerRow == 1 fast path, sql/colfetcher/cfetcher.go:758-1093,937-941) together with
  * colencoding.DecodeKeyValsToCols (colencoding/key_encoding.go:43), processValueBytes

@@ -229,6 +229,29 @@ def project_f64(op, a, b):
     return cd.Vec.from_numpy(cd.FLOAT64, r, None if pres.all() else pres)
 
 
+def select_bytes_const(cmp, vec, cst: bytes):
+    """colexecsel.selEQBytesBytesConstOp / selNEBytesBytesConstOp (selection_ops.eg.go:358,10050: bytes.Compare with
+    the constant) and selContainsBytesBytesConstOp (sel_like_ops.eg.go:229: bytes.Contains(arg, constArg) != negate):
+    the indices that stay selected, in order.  A NULL never passes."""
+    vals = vec.to_values()
+    test = {"EQ": lambda v: v == cst, "NE": lambda v: v != cst, "CONTAINS": lambda v: cst in v,
+            "NOT CONTAINS": lambda v: cst not in v}[cmp]
+    return np.array([i for i, v in enumerate(vals) if v is not None and test(v)], dtype=np.int64)
+
+
+def extract_year(vec):
+    """EXTRACT(year FROM date) (sem/builtins/builtins.go:11946: tree.DFloat(fromTime.Year())) over a DATE column held
+    as int64 days since the epoch (pgdate), evaluated row by row by colexecbuiltins.defaultBuiltinFuncOperator
+    (builtin_funcs.go:44).  Proleptic Gregorian, like Go's time.Time and numpy's datetime64."""
+    years = vec.data.astype("datetime64[D]").astype("datetime64[Y]").astype(np.int64) + 1970
+    return cd.Vec.from_numpy(cd.FLOAT64, years.astype(np.float64), vec.valid)
+
+
+def deselect(vecs, idx):
+    """colexecutils.deselectorOp (deselector.go:48-80): the selected tuples as dense vectors."""
+    return [v.take(np.asarray(idx, dtype=np.int64)) for v in vecs]
+
+
 def set_test_hash(mapping):
     """Inject h(value) for the reference's worked examples; {} resets."""
     vals = np.array(list(mapping.keys()), dtype=np.int64)

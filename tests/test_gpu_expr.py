@@ -98,3 +98,66 @@ def test_q1_plan_select_project_aggregate_vs_oracle(oracle):
     assert len(got[0]) == 5, "the group whose rows all fail the WHERE must be dropped"
     H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "Q1 plan")
     del where, g_charge
+
+
+def test_select_bytes_const_vs_oracle(oracle):
+    """selEQBytesBytesConstOp / selNEBytesBytesConstOp / selContainsBytesBytesConstOp (Q3: c_mktsegment = 'BUILDING',
+    Q9: p_name LIKE '%green%').  The reference holds no literal vectors for the BYTES overloads (its selection tests
+    are int64 only, selection_ops_test.go:28-41): byte-string equality / containment are compared with Python's."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(11)
+    segs = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"MACHINERY", b"HOUSEHOLD", b"", b"BUILDIN", b"BUILDINGS", b"xBUILDING"]
+    n = 50_021
+    vals = [segs[i] for i in rng.integers(0, len(segs), size=n)]
+    for i in rng.integers(0, n, size=n // 20):
+        vals[i] = None
+    v = cd.Vec.from_values(cd.BYTES, vals)
+    d = dev.upload(v)
+    for cmp, cst in (("EQ", b"BUILDING"), ("NE", b"BUILDING"), ("CONTAINS", b"BUILD"), ("NOT CONTAINS", b"INGS"), ("EQ", b""), ("CONTAINS", b"")):
+        col = dev.select_bytes_const(cmp, d, cst)
+        got = dev.download(col.data_ptr, np.uint8, n)
+        assert np.flatnonzero(got).tolist() == oracle.select_bytes_const(cmp, v, cst).tolist(), (cmp, cst)
+    colors = [b"green", b"red", b"forest green", b"gree", b"reen", b"dark greenish lime", b"grEen", b"g r e e n"]
+    names = cd.Vec.from_values(cd.BYTES, [b" ".join(colors[j] for j in rng.integers(0, len(colors), size=3)) for _ in range(5000)])
+    col = dev.select_bytes_const("CONTAINS", dev.upload(names), b"green")
+    assert np.flatnonzero(dev.download(col.data_ptr, np.uint8, 5000)).tolist() == oracle.select_bytes_const("CONTAINS", names, b"green").tolist()
+
+
+def test_extract_year_vs_calendar(oracle):
+    """EXTRACT(year FROM date): every day of 1968..2004 (leap years, century rule at 2000), far dates, negative days."""
+    from cockroach_amd import device as dev
+    days = np.concatenate([np.arange(-800, 13000, dtype=np.int64),
+                           np.array([-719162, -719163, -1, 0, 365, 366, 10957, 11016, 11322, 11323, 47482, 2932896, -141427], dtype=np.int64)])
+    v = cd.Vec.from_numpy(cd.INT64, days)
+    got = dev.extract_year(dev.upload(v))
+    g = dev.download(got.data_ptr, np.float64, len(days))
+    want = oracle.extract_year(v)
+    assert np.array_equal(g, want.data)
+    # known answers: 1970-01-01 = day 0; 2000-02-29 = day 11016; 1992-01-01 = day 8035; 1998-12-01 = day 10561
+    probe = cd.Vec.from_numpy(cd.INT64, np.array([0, 11016, 8035, 10561, -1], dtype=np.int64))
+    col = dev.extract_year(dev.upload(probe))  # keep the column alive: it owns the device buffer
+    g = dev.download(col.data_ptr, np.float64, 5)
+    assert g.tolist() == [1970.0, 2000.0, 1992.0, 1998.0, 1969.0]
+
+
+def test_deselect_vs_oracle(oracle):
+    """deselectorOp: the rows a BOOL column keeps, all column families, NULLs preserved, input order kept."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 4097, 60_001):
+        k = cd.Vec.from_numpy(cd.INT64, rng.integers(-9, 9, size=n, dtype=np.int64), rng.random(n) > 0.1)
+        s = cd.Vec.from_values(cd.BYTES, [None if i % 13 == 5 else b"row%d" % i * (i % 3) for i in range(n)])
+        f = cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(n))
+        b = cd.Vec.from_numpy(cd.BOOL, rng.random(n) > 0.5)
+        i32 = cd.Vec.from_numpy(cd.INT32, rng.integers(-5, 5, size=n).astype(np.int32))
+        cols = [k, s, f, b, i32]
+        keep = (rng.random(n) < 0.3).astype(np.uint8)
+        ds = dev.Deselector([c.type for c in cols])
+        flags = dev.upload(cd.Vec.from_numpy(cd.BOOL, keep))
+        res = ds.deselect([dev.upload(c) for c in cols], flags, n)
+        got = dev.result_to_vecs(res)
+        want = oracle.deselect(cols, np.flatnonzero(keep))
+        assert int(res.n) == int(keep.sum())
+        for gv, wv in zip(got, want):
+            assert gv.to_values() == wv.to_values()
+        ds.close()
