@@ -107,6 +107,8 @@ SYMBOLS = [
     ("crgpu_dev_partitioner_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(_VP)]),
     ("crgpu_dev_partition", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult), C.POINTER(_I64)]),
     ("crgpu_dev_partitioner_destroy", None, [_VP]),
+    ("crgpu_dev_partition_noalloc", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(DCol), _I64,
+                                           C.POINTER(_VP), _VP]),
     ("crgpu_dev_select_i64_const", _I32, [_I32, C.POINTER(DCol), _I64, _I64, _VP]),
     ("crgpu_dev_project_f64", _I32, [_I32, C.POINTER(DCol), C.c_double, C.POINTER(DCol), C.c_double, _I64, _VP, _VP]),
     ("crgpu_dev_select_bytes_const", _I32, [_I32, C.POINTER(DCol), C.c_char_p, _I32, _I64, _VP]),

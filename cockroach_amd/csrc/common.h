@@ -39,6 +39,7 @@ crgpu_status ensure_init();  // binds the calling thread to its library device (
 int num_cus();
 int current_device();        // the calling thread's library device (-1 before any init)
 void mark_default_work();    // a handle-less call queued asynchronous work on the default stream: handle calls order themselves after it
+crgpu_status noalloc_setup_device(int device);  // partition.hip: resolves this device's copy of the static scratch array (called by crgpu_init with the device current)
 
 static constexpr uint32_t kHandleMagic = 0x43524748u;  // "CRGH"
 // First base of every handle struct (crgpu_join, crgpu_agg, ...): crgpu_cancel() accepts any of them.

@@ -105,6 +105,30 @@ __global__ __launch_bounds__(kPartBlock) void part_scatter_kernel(ScatterArgs a)
   }
 }
 
+// ---- no-allocation variant (crgpu_dev_partition_noalloc): its scratch -- destination codes, per-tile histograms,
+// scanned bases, scan tile sums -- lives in this file-scope array, one copy per GPU the library runs on, held until
+// the process ends.  `scratch` itself is a host-side stand-in for the symbol, never a device address: host code only
+// ever uses the per-device pointer hipGetSymbolAddress returned (noalloc_setup_device, called by crgpu_init).
+static constexpr int64_t kNoAllocMaxRows = int64_t(1) << 22;
+static constexpr int kNoAllocMaxOutputs = 64;
+static constexpr size_t kNoAllocMaxTiles = static_cast<size_t>(kNoAllocMaxRows / kPartTile);
+static constexpr size_t kNoAllocDestBytes = static_cast<size_t>(kNoAllocMaxRows) * 2;                       // uint16 per row
+static constexpr size_t kNoAllocHistBytes = kNoAllocMaxTiles * kNoAllocMaxOutputs * 4;                      // uint32 per (output, tile)
+static constexpr size_t kNoAllocBasesBytes = (kNoAllocMaxTiles * kNoAllocMaxOutputs + 1 + 31) / 32 * 32 * 8;  // uint64 per (output, tile) + total
+static constexpr size_t kNoAllocScanBytes = 4096;                                                           // tile sums of the scan (<= 66 words)
+static constexpr size_t kNoAllocScratchBytes = kNoAllocDestBytes + kNoAllocHistBytes + kNoAllocBasesBytes + kNoAllocScanBytes;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+static void *g_scratch_ptr[kMaxDevices];  // each GPU holds its own copy of the array at its own address
+
+crgpu_status noalloc_setup_device(int device) {  // with `device` current (crgpu_init)
+  if (device < 0 || device >= kMaxDevices) return fail(CRGPU_ERR_INVALID, "noalloc_setup_device: device ordinal out of range");
+  void *ptr = nullptr;
+  CRGPU_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  if (ptr == nullptr) return fail(CRGPU_ERR_HIP, "noalloc_setup_device: hipGetSymbolAddress returned a null address");
+  g_scratch_ptr[device] = ptr;
+  return CRGPU_OK;
+}
+
 __global__ void part_counts_kernel(const uint64_t *__restrict__ bases, int64_t ntiles, uint32_t P,
                                    uint64_t *__restrict__ counts) {
   for (uint32_t p = threadIdx.x; p < P; p += blockDim.x)
@@ -273,5 +297,79 @@ extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dc
   res->ncols = nc;
   res->_pad = 0;
   res->cols = p->views.data();
+  return CRGPU_OK;
+}
+
+// The one entry point that allocates nothing (include/crgpu.h): same kernels as crgpu_dev_partition, scratch from the
+// per-device static array, outputs and counts in caller-owned device memory, queued on the device's default stream.
+extern "C" crgpu_status crgpu_dev_partition_noalloc(const int32_t *types, int32_t n_cols, const int32_t *hash_cols,
+                                                    int32_t n_hash, uint64_t init, int32_t num_outputs,
+                                                    const crgpu_dcol *cols, int64_t n, void *const *out_data,
+                                                    int64_t *counts_dev) {
+  CRGPU_ENTER(nullptr);
+  if (types == nullptr || cols == nullptr || out_data == nullptr || counts_dev == nullptr || (n_hash > 0 && hash_cols == nullptr))
+    return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition_noalloc: null argument");
+  if (n_cols < 1 || n_cols > kMaxScatter)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition_noalloc: between 1 and 16 columns");
+  if (n_hash < 0 || n_hash > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition_noalloc: at most 8 hash columns");
+  if (num_outputs < 1 || num_outputs > kNoAllocMaxOutputs)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition_noalloc: between 1 and 64 outputs (the static scratch is sized for that)");
+  if (n < 0 || n > kNoAllocMaxRows)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition_noalloc: at most 2^22 rows per call (the static scratch is sized for that); "
+                                       "use crgpu_dev_partition for larger inputs");
+  if (init == 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition_noalloc: init hash value must be non-zero (hash_utils.go:64)");
+  for (int c = 0; c < n_cols; c++) {
+    if (!valid_type(types[c]) || types[c] == CRGPU_BYTES)
+      return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition_noalloc: fixed-width columns only");
+    if (cols[c].type != types[c]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition_noalloc: column type differs from the spec");
+    if (cols[c].valid != nullptr) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_partition_noalloc: columns with NULLs take crgpu_dev_partition");
+    if (n > 0 && (cols[c].data == nullptr || out_data[c] == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition_noalloc: null data pointer");
+  }
+  for (int k = 0; k < n_hash; k++)
+    if (hash_cols[k] < 0 || hash_cols[k] >= n_cols) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition_noalloc: hash column ordinal out of range");
+  const int dev = current_device();
+  uint8_t *base = dev >= 0 ? static_cast<uint8_t *>(g_scratch_ptr[dev]) : nullptr;
+  if (base == nullptr) return fail(CRGPU_ERR_STATE, "crgpu_dev_partition_noalloc: the device's scratch was not resolved (crgpu_init)");
+  hipStream_t st = stream();
+  const uint32_t P = static_cast<uint32_t>(num_outputs);
+  if (n == 0) {
+    CRGPU_HIP(hipMemsetAsync(counts_dev, 0, static_cast<size_t>(P) * 8, st));
+    mark_default_work();
+    return CRGPU_OK;
+  }
+  const int64_t ntiles = (n + kPartTile - 1) / kPartTile;  // <= kNoAllocMaxTiles by the row limit above
+  uint16_t *dest = reinterpret_cast<uint16_t *>(base);
+  uint32_t *tile_hist = reinterpret_cast<uint32_t *>(base + kNoAllocDestBytes);
+  uint64_t *bases = reinterpret_cast<uint64_t *>(base + kNoAllocDestBytes + kNoAllocHistBytes);
+  uint64_t *scan_ts = reinterpret_cast<uint64_t *>(base + kNoAllocDestBytes + kNoAllocHistBytes + kNoAllocBasesBytes);
+  if (scan_scratch_words(ntiles * P) * 8 > kNoAllocScanBytes) return fail(CRGPU_ERR_STATE, "crgpu_dev_partition_noalloc: scan scratch too small");
+  KeyCols keys;
+  keys.n = n_hash;
+  keys._pad = 0;
+  for (int k = 0; k < n_hash; k++) keys.c[k] = to_dcol(cols[hash_cols[k]]);
+  ScatterArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.n = n;
+  a.ntiles = ntiles;
+  a.P = P;
+  a.dest = dest;
+  a.bases = bases;
+  a.ncols = n_cols;
+  for (int c = 0; c < n_cols; c++) {
+    a.cols[c].src = static_cast<const uint8_t *>(cols[c].data);
+    a.cols[c].dst = static_cast<uint8_t *>(out_data[c]);
+    a.cols[c].width = type_width(types[c]);
+  }
+  // nothing in the scratch has to start at zero: every (output, tile) histogram entry, every destination code and every
+  // scanned base this call reads is written by this call first; what an earlier, larger call left beyond them is never read
+  // (no ProfScope here: creating its events would be an allocation)
+  hipLaunchKernelGGL(part_hist_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, keys, n, init, P, ntiles, dest, tile_hist);
+  CRGPU_HIP(hipGetLastError());
+  CRGPU_TRY(exclusive_scan_u32_ws(tile_hist, ntiles * P, bases, scan_ts, nullptr));
+  hipLaunchKernelGGL(part_scatter_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, a);
+  CRGPU_HIP(hipGetLastError());
+  hipLaunchKernelGGL(part_counts_kernel, dim3(1), dim3(256), 0, st, bases, ntiles, P, reinterpret_cast<uint64_t *>(counts_dev));
+  CRGPU_HIP(hipGetLastError());
+  mark_default_work();
   return CRGPU_OK;
 }

@@ -75,6 +75,7 @@ static crgpu_status init_device(int device) {
   CRGPU_HIP(hipGetDeviceProperties(&prop, device));
   d.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   CRGPU_HIP(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  CRGPU_TRY(noalloc_setup_device(device));
   int none = -1;
   g_default_device.compare_exchange_strong(none, device);
   d.ready.store(true, std::memory_order_release);

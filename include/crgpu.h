@@ -219,6 +219,22 @@ crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, i
                                  int64_t *counts_host);
 void crgpu_dev_partitioner_destroy(crgpu_partitioner *p);
 
+/* ---- the one entry point that allocates nothing.  It has NO counterpart in the reference: it exists for callers
+ * that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
+ * Same repartition as crgpu_dev_partition (same kernels, same destinations), without a handle: the spec travels in
+ * the arguments, the regrouped columns go to CALLER-OWNED device buffers out_data[c] (room for n values each,
+ * destination order, one contiguous region per destination) and the per-destination row counts to the caller's
+ * DEVICE array counts_dev[num_outputs].  The kernels' scratch (destination codes, per-tile histograms, scanned
+ * bases) is a static device array of 9.3 MiB that every GPU the library runs on holds until the process ends;
+ * no hipMalloc / hipFree / allocating routine is called.  Limits, rejected with CRGPU_ERR_UNSUPPORTED beyond:
+ * n <= 2^22 rows per call, num_outputs <= 64, <= 16 fixed-width columns (no BYTES), no validity bitmaps.
+ * The work is queued on the default stream of the thread's library device and the call returns without waiting
+ * (crgpu_dev_synchronize, or any later handle call, orders after it).  Every call on a GPU shares that GPU's
+ * scratch array: calls that overlap on one GPU race -- issue them from one thread at a time. */
+crgpu_status crgpu_dev_partition_noalloc(const int32_t *types, int32_t n_cols, const int32_t *hash_cols, int32_t n_hash,
+                                         uint64_t init, int32_t num_outputs, const crgpu_dcol *cols, int64_t n,
+                                         void *const *out_data, int64_t *counts_dev);
+
 /* ---- unordered DISTINCT: replaces colexec.UnorderedDistinct.Next (sql/colexec/unordered_distinct.go:94-121) and
  * colexechash.HashTable.DistinctBuild (sql/colexec/colexechash/hashtable.go:628-649).  Every call takes one input
  * batch and returns, in input order, all columns of the rows whose `distinct_cols` tuple was not seen before (in an
