@@ -83,6 +83,8 @@ SYMBOLS = [
     ("crgpu_last_error", C.c_char_p, []),
     ("crgpu_mem_usage", _I64, []),
     ("crgpu_live_handles", _I64, []),
+    ("crgpu_mem_cached", _I64, []),
+    ("crgpu_mem_trim", None, []),
     ("crgpu_cancel", _I32, [_VP]),
     ("crgpu_prof_enable", None, [_I32]),
     ("crgpu_prof_reset", None, []),

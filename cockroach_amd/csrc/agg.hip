@@ -1972,6 +1972,7 @@ static crgpu_status reindex(crgpu_agg *a, uint32_t new_cap) {
   CRGPU_HIP(hipStreamSynchronize(stream()));
   std::swap(a->meta.p, fresh.p);
   std::swap(a->meta.cap, fresh.cap);
+  std::swap(a->meta.device, fresh.device);
   a->cap = new_cap;
   return CRGPU_OK;
 }
@@ -2136,6 +2137,7 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
 
 extern "C" void crgpu_dev_agg_destroy(crgpu_agg *a) {
   if (a == nullptr) return;
+  if (a->st != nullptr) (void)hipStreamSynchronize(a->st);  // its buffers return to the pool: no kernel may still use them
   delete a;
 }
 

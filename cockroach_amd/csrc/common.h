@@ -87,6 +87,7 @@ struct CallScope {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  int device = -1;  // the device the block lives on (its pool)
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;

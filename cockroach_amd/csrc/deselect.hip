@@ -39,7 +39,11 @@ extern "C" crgpu_status crgpu_dev_deselector_create(const int32_t *types, int32_
   return CRGPU_OK;
 }
 
-extern "C" void crgpu_dev_deselector_destroy(crgpu_deselector *d) { delete d; }
+extern "C" void crgpu_dev_deselector_destroy(crgpu_deselector *d) {
+  if (d == nullptr) return;
+  if (d->st != nullptr) (void)hipStreamSynchronize(d->st);  // its buffers return to the pool: no kernel may still use them
+  delete d;
+}
 
 extern "C" crgpu_status crgpu_dev_deselect(crgpu_deselector *d, const crgpu_dcol *cols, int64_t n, const uint8_t *keep_bool,
                                            crgpu_dev_result *res) {

@@ -293,6 +293,7 @@ extern "C" crgpu_status crgpu_dev_distinct_create(const int32_t *types, int32_t 
 
 extern "C" void crgpu_dev_distinct_destroy(crgpu_distinct *d) {
   if (d == nullptr) return;
+  if (d->st != nullptr) (void)hipStreamSynchronize(d->st);  // its buffers return to the pool: no kernel may still use them
   delete d;
 }
 

@@ -759,6 +759,7 @@ extern "C" crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu
 
 extern "C" void crgpu_dev_join_destroy(crgpu_join *j) {
   if (j == nullptr) return;
+  if (j->st != nullptr) (void)hipStreamSynchronize(j->st);  // its buffers return to the pool: no kernel may still use them
   delete j;
 }
 

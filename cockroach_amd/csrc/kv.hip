@@ -688,6 +688,7 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
 
 extern "C" void crgpu_dev_decoder_destroy(crgpu_decoder *d) {
   if (d == nullptr) return;
+  if (d->st != nullptr) (void)hipStreamSynchronize(d->st);  // its buffers return to the pool: no kernel may still use them
   delete d;
 }
 

@@ -185,6 +185,7 @@ extern "C" crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32
 
 extern "C" void crgpu_dev_partitioner_destroy(crgpu_partitioner *p) {
   if (p == nullptr) return;
+  if (p->st != nullptr) (void)hipStreamSynchronize(p->st);  // its buffers return to the pool: no kernel may still use them
   delete p;
 }
 

@@ -2,6 +2,7 @@
 // HIP-event profiling, cancellation.
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -156,18 +157,77 @@ CallScope::~CallScope() {
   if (prev_device >= 0 && prev_device != t_device && g_dev[prev_device].ready.load()) (void)bind_thread(prev_device);
 }
 
+// ------------------------------------------------------------------ device memory pool
+// A query builds fresh operators (fresh handles) every time it runs, as the reference does; hipMalloc / hipFree cost
+// 0.1-1 ms apiece and hipFree synchronises the whole device, which at SF10 was most of a TPC-H query's wall time.
+// Freed DevBuf blocks are therefore kept per device in a size-ordered free list and handed out again (best fit within
+// 1.25 x); crgpu_mem_usage() counts blocks in use, crgpu_mem_cached() the idle ones, crgpu_mem_trim() returns them to
+// the driver, and an allocation failure trims before it gives up.  CRGPU_POOL_MAX_BYTES (default 96 GiB) bounds the
+// idle bytes per device; blocks are only pooled once the stream that used them has been synchronised (DevBuf::ensure
+// and the destroy entry points do that before releasing).
+static std::multimap<size_t, void *> g_pool[kMaxDevices];
+static int64_t g_pool_bytes[kMaxDevices];
+static std::mutex g_pool_mu;
+static int64_t pool_limit() {
+  static const int64_t lim = [] {
+    const char *v = getenv("CRGPU_POOL_MAX_BYTES");
+    return (v != nullptr && *v != 0) ? atoll(v) : (int64_t(96) << 30);
+  }();
+  return lim;
+}
+static void *pool_take(int dev, size_t want, size_t *got) {
+  if (dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool[dev].lower_bound(want);
+  if (it == g_pool[dev].end() || it->first > want + want / 4) return nullptr;
+  void *p = it->second;
+  *got = it->first;
+  g_pool_bytes[dev] -= static_cast<int64_t>(it->first);
+  g_pool[dev].erase(it);
+  return p;
+}
+static bool pool_put(int dev, void *p, size_t cap) {
+  if (dev < 0 || dev >= kMaxDevices) return false;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool_bytes[dev] + static_cast<int64_t>(cap) > pool_limit()) return false;
+  g_pool[dev].emplace(cap, p);
+  g_pool_bytes[dev] += static_cast<int64_t>(cap);
+  return true;
+}
+static void pool_trim(int dev) {
+  std::multimap<size_t, void *> take;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    take.swap(g_pool[dev]);
+    g_pool_bytes[dev] = 0;
+  }
+  for (auto &kv : take) (void)hipFree(kv.second);
+}
+
 crgpu_status DevBuf::ensure(size_t bytes, bool keep) {
   if (bytes <= cap) return CRGPU_OK;
   size_t ncap = cap ? cap : 256;
   while (ncap < bytes) ncap = ncap < (size_t(1) << 30) ? ncap * 2 : ncap + (ncap >> 1);
   ncap = (ncap + 255) & ~size_t(255);
-  void *np = nullptr;
-  hipError_t e = hipMalloc(&np, ncap);
-  if (e != hipSuccess && ncap > bytes) {  // retry with the exact size before giving up
-    ncap = (bytes + 255) & ~size_t(255);
-    e = hipMalloc(&np, ncap);
+  const int dev = t_device;
+  size_t got = 0;
+  void *np = pool_take(dev, ncap, &got);
+  if (np != nullptr) {
+    ncap = got;
+  } else {
+    hipError_t e = hipMalloc(&np, ncap);
+    if (e != hipSuccess) {  // give the idle blocks back to the driver, then retry (with the exact size last)
+      (void)hipGetLastError();
+      if (dev >= 0) pool_trim(dev);
+      e = hipMalloc(&np, ncap);
+      if (e != hipSuccess && ncap > bytes) {
+        (void)hipGetLastError();
+        ncap = (bytes + 255) & ~size_t(255);
+        e = hipMalloc(&np, ncap);
+      }
+    }
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
   }
-  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
   if (keep && p != nullptr && cap > 0) {
     hipError_t c = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, stream());
     if (c == hipSuccess) c = hipStreamSynchronize(stream());
@@ -177,19 +237,21 @@ crgpu_status DevBuf::ensure(size_t bytes, bool keep) {
     }
   }
   if (p != nullptr) {
-    (void)hipStreamSynchronize(stream());
-    (void)hipFree(p);
+    (void)hipStreamSynchronize(stream());  // kernels that still read the old block
+    device = device >= 0 ? device : dev;
+    if (!pool_put(device, p, cap)) (void)hipFree(p);
     g_mem -= static_cast<int64_t>(cap);
   }
   p = np;
   cap = ncap;
+  device = dev;
   g_mem += static_cast<int64_t>(cap);
   return CRGPU_OK;
 }
 
 void DevBuf::release() {
   if (p != nullptr) {
-    (void)hipFree(p);
+    if (!pool_put(device, p, cap)) (void)hipFree(p);
     g_mem -= static_cast<int64_t>(cap);
   }
   p = nullptr;
@@ -257,6 +319,7 @@ void crgpu_shutdown(void) {
   for (int i = 0; i < kMaxDevices; i++) {
     DeviceCtx &d = g_dev[i];
     if (!d.ready.load()) continue;
+    pool_trim(i);
     d.ready.store(false);
     if (d.stream != nullptr) {
       (void)hipStreamSynchronize(d.stream);
@@ -271,6 +334,16 @@ void crgpu_shutdown(void) {
 const char *crgpu_last_error(void) { return t_err.c_str(); }
 int64_t crgpu_mem_usage(void) { return g_mem.load(); }
 int64_t crgpu_live_handles(void) { return g_handles.load(); }
+int64_t crgpu_mem_cached(void) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  int64_t t = 0;
+  for (int i = 0; i < kMaxDevices; i++) t += g_pool_bytes[i];
+  return t;
+}
+void crgpu_mem_trim(void) {
+  for (int i = 0; i < kMaxDevices; i++)
+    if (g_dev[i].ready.load()) pool_trim(i);
+}
 
 crgpu_status crgpu_cancel(void *handle) {
   Handle *h = static_cast<Handle *>(handle);

@@ -93,6 +93,13 @@ const char *crgpu_last_error(void);
 /* Device bytes currently held by the library; the Go shell reports the delta
  * through colmem.Allocator.AdjustMemoryUsage (sql/colmem/allocator.go:526). */
 int64_t crgpu_mem_usage(void);
+/* Freed library buffers are kept in a per-device pool and reused by later handles (a query builds fresh operators on
+ * every execution; hipMalloc/hipFree per operator would dominate).  crgpu_mem_cached: idle bytes held by the pool
+ * (not part of crgpu_mem_usage); crgpu_mem_trim returns them to the driver -- call it under memory pressure from
+ * other users of the GPU (the library trims by itself before reporting CRGPU_ERR_OOM).  CRGPU_POOL_MAX_BYTES
+ * (environment, default 96 GiB) bounds the idle bytes per device. */
+int64_t crgpu_mem_cached(void);
+void crgpu_mem_trim(void);
 
 /* Kernel timing with HIP events on the library stream (for bench.py's roofline
  * object; batchInfoCollector-style stats, sql/colflow/stats.go:41-137).

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: TPC-H Q3 / Q9 multi-way hash joins + aggregation on one MI355X, synthetic SF10 tables
+resident in HBM (workloads/tpch_synth.py), every operator through the C-ABI (workloads/tpch_plans.py).
+
+Per query: wall ms per execution of the whole chain (selections, deselections, joins, projections, aggregation),
+input rows/s (rows of every base table the plan scans), algorithmic bytes per SURVEY.md 8(d) ("every base column once +
+every intermediate written once and read once", accounted operator by operator on an untimed pass) and their fraction
+of 8 TB/s, the per-family HIP-event kernel times, a result check against the independent dense-lookup evaluation
+(tests/tpch_check.py), and the CPU baseline: the SAME plan on the oracle's executor (reference operators restated,
+1 thread) at a bounded scale factor."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FAMILIES = ["expr_select", "expr_project", "deselect", "join_build", "join_probe", "radix_build_hist", "radix_build_scatter",
+            "radix_build_split", "radix_build_table", "radix_probe_hist", "radix_probe_scatter", "agg"]
+
+
+def measure(sf=10.0, reps=3, cpu_sf=0.05, device_index=0, queries=("q3", "q3_dupbuild", "q9"), check=True):
+    import torch
+    from cockroach_amd import _lib, device as dev
+    from workloads import tpch_plans as P, tpch_synth as T
+    torch.cuda.set_device(device_index)
+    _lib.check(_lib.load().crgpu_init(device_index))
+    t, rows = T.generate(sf, f"cuda:{device_index}", 42)
+    torch.cuda.synchronize()
+    aux = rows["_aux"]
+    plans = {"q3": (lambda ex, tb: P.q3(ex, tb), ["customer", "orders", "lineitem"]),
+             "q3_dupbuild": (lambda ex, tb: P.q3(ex, tb, True), ["customer", "orders", "lineitem"]),
+             "q9": (lambda ex, tb: P.q9(ex, tb), ["part", "partsupp", "lineitem", "supplier", "nation", "orders"])}
+    out = []
+    for q in queries:
+        plan, scanned = plans[q]
+        ex = P.GpuExec(account=True)  # untimed: accounting + warm-up
+        tabs = {k: ex.table(v) for k, v in t.items()}
+        res = ex.to_host(plan(ex, tabs))
+        alg, ops = ex.alg_bytes, ex.ops
+        ex.close()
+        ok = None
+        if check:
+            sys.path.insert(0, os.path.join(ROOT))
+            from tests import tpch_check as K
+            import numpy as np
+            if q == "q9":
+                nat, year, profit = K.q9_expected(t, aux)
+                got = sorted(zip(res[0].to_values(), res[1].to_values(), res[2].to_values()))
+                want = sorted(zip([T.NATIONS[i] for i in nat.tolist()], [float(y) for y in year.tolist()], profit.tolist()))
+                ok = len(got) == len(want) and all(g[:2] == w[:2] and abs(g[2] - w[2]) <= 1e-9 * abs(w[2]) + 1e-6 for g, w in zip(got, want))
+            else:
+                keys, rev, _od = K.q3_expected(t, aux)
+                order = np.argsort(res[0].data)
+                ok = len(res[0]) == keys.numel() and np.array_equal(res[0].data[order], keys.cpu().numpy()) and \
+                    bool(np.allclose(res[3].data[order], rev.cpu().numpy(), rtol=1e-9, atol=1e-6))
+        groups = len(res[0])
+        dev.prof_enable(True)
+        dev.prof_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ex = P.GpuExec()
+            tabs = {k: ex.table(v) for k, v in t.items()}
+            r = plan(ex, tabs)
+            _lib.check(_lib.load().crgpu_dev_synchronize())
+            ex.close()
+        dt = (time.perf_counter() - t0) / reps
+        dev.prof_enable(False)
+        kern = {}
+        for f in FAMILIES:
+            ms, cnt = dev.prof_get(f)
+            if cnt:
+                kern[f] = round(ms / reps, 3)
+        in_rows = sum(rows[k] for k in scanned)
+        rec = {"case": f"tpch_{q}_sf{sf:g}", "rows": in_rows, "groups": groups, "ms": dt * 1e3, "rows_per_s": in_rows / dt,
+               "algorithmic_bytes": alg, "frac_of_8TBps": alg / dt / 8e12, "kernels_ms": kern,
+               "operators": [list(o) for o in ops], "result_check": "ok" if ok else ("MISMATCH" if ok is not None else "skipped")}
+        out.append(rec)
+    del t
+    torch.cuda.empty_cache()
+    if cpu_sf:
+        from oracle.plan_exec import OracleExec
+        tc, rc = T.generate(cpu_sf, "cpu", 42)
+        oex = OracleExec()
+        otabs = {k: oex.table(v) for k, v in tc.items()}
+        for rec, q in zip(out, queries):
+            plan, scanned = plans[q]
+            t0 = time.perf_counter()
+            plan(oex, otabs)
+            dtc = time.perf_counter() - t0
+            n = sum(rc[k] for k in scanned)
+            rec["cpu_baseline"] = {"value": n / dtc, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": f"same plan at SF{cpu_sf:g} ({n} scanned rows) on the oracle executor, {dtc:.1f} s"}
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=10.0)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cpu-sf", type=float, default=0.05)
+    ap.add_argument("--no-check", action="store_true")
+    a = ap.parse_args()
+    for r in measure(a.sf, a.reps, a.cpu_sf, check=not a.no_check):
+        print(json.dumps(r), flush=True)
