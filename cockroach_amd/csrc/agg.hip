@@ -2749,7 +2749,9 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
                       static_cast<size_t>(a->lds_seen) * (gmax + 1) + 15) & ~size_t(15);
   RadixSrc src;
   std::memset(&src, 0, sizeof(src));
-  src.key = key;
+  src.kp.n = 1;
+  src.kp.c[0] = key;
+  src.kp.range[0] = ~0ull;
   src.pay = vcol >= 0 ? static_cast<const uint8_t *>(cols[vcol].data) : nullptr;
   src.pay_width = vcol >= 0 ? 8 : 0;
   src.fast = vcol >= 0 ? 1 : 0;

@@ -302,4 +302,54 @@ __device__ __forceinline__ uint64_t pack_key(const DCol &c, int64_t i) {
   }
 }
 
+// ------------------------------------------------------------------ packed join keys
+// The packed / radix / exact-chained join tables compare ONE 64-bit word per row.  A single fixed-width key column is
+// its pack_key() value.  Several integer (or BOOL) key columns are range-compressed into one word: the build side's
+// [lo, hi] of every column is measured once, column c contributes (v - lo[c]) << shift[c], and the key is usable when
+// the columns' bit widths add up to <= 64 (TPC-H Q9: (l_partkey, l_suppkey) needs 21 + 17 bits at SF10).  A probe value
+// outside the build side's range cannot equal any build value: such a row has no key, exactly like a NULL.
+static constexpr int kMaxPackCols = 4;
+struct KeyPack {
+  int32_t n;
+  int32_t _pad;
+  DCol c[kMaxPackCols];
+  int64_t lo[kMaxPackCols];
+  uint64_t range[kMaxPackCols];  // hi - lo
+  uint32_t shift[kMaxPackCols];
+};
+__device__ __forceinline__ int64_t col_get_ival(const DCol &c, int64_t i) {
+  return c.type == CRGPU_BOOL ? static_cast<int64_t>(col_get_bool(c, i)) : col_get_int(c, i);
+}
+// false: the row has no key (a NULL key column, or a value outside the build side's range) and matches nothing
+__device__ __forceinline__ bool key_pack(const KeyPack &kp, int64_t i, uint64_t &k) {
+  if (kp.n == 1) {
+    if (col_is_null(kp.c[0], i)) return false;
+    k = pack_key(kp.c[0], i);
+    return true;
+  }
+  uint64_t v = 0;
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < kMaxPackCols; c++) {
+    if (c < kp.n) {
+      if (col_is_null(kp.c[c], i)) {
+        ok = false;
+      } else {
+        const uint64_t d = static_cast<uint64_t>(col_get_ival(kp.c[c], i)) - static_cast<uint64_t>(kp.lo[c]);  // wraps above range when v < lo
+        ok = ok && d <= kp.range[c];
+        v |= d << kp.shift[c];
+      }
+    }
+  }
+  k = v;
+  return ok;
+}
+// column c of a packed multi-column key (emitting a key column from the key word)
+__device__ __forceinline__ uint64_t key_unpack(const KeyPack &kp, int c, uint64_t k) {
+  if (kp.n == 1) return k;
+  const uint64_t r = kp.range[c];
+  const uint64_t mask = r == ~0ull ? ~0ull : ((2ull << (63 - __builtin_clzll(r | 1ull))) - 1ull);
+  return ((k >> kp.shift[c]) & mask) + static_cast<uint64_t>(kp.lo[c]);
+}
+
 }  // namespace crgpu

@@ -42,13 +42,13 @@ struct Special {  // the one build key whose packed value equals kEmptyKey
 };
 
 // ------------------------------------------------------------------ PACKED build
-__global__ __launch_bounds__(256) void packed_build_kernel(DCol key, int64_t n, Slot *__restrict__ slots,
+__global__ __launch_bounds__(256) void packed_build_kernel(KeyPack kp, int64_t n, Slot *__restrict__ slots,
                                                            uint64_t mask, const uint64_t *__restrict__ payload,
                                                            Special *__restrict__ special) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
-    if (col_is_null(key, row)) continue;  // NULL never matches (allowNullEquality=false, hashjoiner.go:264)
-    const uint64_t k = pack_key(key, row);
+    uint64_t k;
+    if (!key_pack(kp, row, k)) continue;  // NULL never matches (allowNullEquality=false, hashjoiner.go:264)
     const unsigned long long v = payload ? payload[row] : static_cast<unsigned long long>(row);
     if (k == kEmptyKey) {
       if (atomicCAS(&special->present, 0u, 1u) == 0u) special->val = v;
@@ -79,7 +79,7 @@ struct CopyCol {
   int32_t side;
 };
 struct ProbeArgs {
-  DCol key;
+  KeyPack kp;
   int64_t n;
   const Slot *slots;
   uint64_t mask;
@@ -135,9 +135,10 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
       found[j] = false;
       val[j] = 0;
       k[j] = kEmptyKey;
-      bool probe = inb[j] && !col_is_null(a.key, row);
+      uint64_t kk = kEmptyKey;
+      const bool probe = inb[j] && key_pack(a.kp, row, kk);
       if (probe) {
-        k[j] = pack_key(a.key, row);
+        k[j] = kk;
         if (k[j] == kEmptyKey) {
           found[j] = a.special->present != 0;
           val[j] = a.special->val;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void chain_narrow_kernel(const uint64_t *__res
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = static_cast<uint32_t>(in[i]);
 }
-__global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_t n, const uint32_t *__restrict__ hsave,
+__global__ __launch_bounds__(256) void chain_scatter_kernel(KeyPack kp, int64_t n, const uint32_t *__restrict__ hsave,
                                                             const uint32_t *__restrict__ start,
                                                             uint32_t *__restrict__ cnt, uint32_t *__restrict__ grp,
                                                             ulonglong2 *__restrict__ gkey) {
@@ -279,7 +280,11 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(KeyCols keys, int64_
     if (h == 0xFFFFFFFFu) continue;
     const uint32_t pos = start[h] + (atomicSub(&cnt[h], 1u) - 1u);  // cnt counts back down to zero
     grp[pos] = static_cast<uint32_t>(row);
-    if (gkey != nullptr) gkey[pos] = make_ulonglong2(static_cast<uint64_t>(col_get_int(keys.c[0], row)), static_cast<uint64_t>(row));
+    if (gkey != nullptr) {
+      uint64_t k = 0;
+      (void)key_pack(kp, row, k);  // rows without a key were left out by chain_hist_kernel (hsave = ~0)
+      gkey[pos] = make_ulonglong2(k, static_cast<uint64_t>(row));
+    }
   }
 }
 
@@ -327,7 +332,8 @@ struct ChainArgs {
   const uint32_t *start;  // [nb + 1] bucket boundaries in grp / gkey (row ids are 32-bit, so are these)
   const uint32_t *grp;    // build row ids, bucket by bucket
   const uint8_t *rep8;    // generic keys: offset in the bucket of each entry's representative (chain_mark_kernel), or nullptr
-  const ulonglong2 *gkey; // {key value, row id} in the same order (single integer key column), else nullptr
+  const ulonglong2 *gkey; // {packed key word, row id} in the same order (keys that pack into 64 bits, KeyPack), else nullptr
+  KeyPack kp;             // probe-side key word (when gkey is in use)
   uint32_t nb_mask;
   int32_t null_eq;
   uint8_t *matched;       // build-row matched flags (RIGHT/FULL OUTER, RIGHT SEMI/ANTI)
@@ -342,14 +348,15 @@ struct ChainArgs {
 // it, r)) ...`.
 struct ChainIter {
   uint32_t p, e;
-  int64_t k;
+  uint64_t k;
 };
 __device__ __forceinline__ ChainIter chain_begin(const ChainArgs &a, int64_t i) {
   const uint32_t h = hash_row32(a.probe, i, 1u) & a.nb_mask;
   ChainIter it;
   it.p = a.start[h];
   it.e = a.start[h + 1];
-  it.k = a.gkey != nullptr ? col_get_int(a.probe.c[0], i) : 0;
+  it.k = 0;
+  if (a.gkey != nullptr && !key_pack(a.kp, i, it.k)) it.e = it.p;  // outside the build side's key range: no match
   return it;
 }
 __device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainIter &it, int64_t &r) {
@@ -357,7 +364,7 @@ __device__ __forceinline__ bool chain_next(const ChainArgs &a, int64_t i, ChainI
     const uint32_t p = it.p++;
     if (a.gkey != nullptr) {
       const ulonglong2 kr = a.gkey[p];  // key and row id in one 16-byte load
-      if (static_cast<int64_t>(kr.x) != it.k) continue;
+      if (kr.x != it.k) continue;
       r = static_cast<int64_t>(kr.y);
       return true;
     }
@@ -431,7 +438,7 @@ __device__ __forceinline__ void chain_count_row(const ChainArgs &a, int64_t i, C
       for (int t = 0; t < kChainChunk; t++) e[t] = a.gkey[p + t < it.e ? p + t : it.e - 1];
 #pragma unroll
       for (int t = 0; t < kChainChunk; t++)
-        if (go && p + t < it.e && static_cast<int64_t>(e[t].x) == it.k) go = on_match(static_cast<int64_t>(e[t].y));
+        if (go && p + t < it.e && e[t].x == it.k) go = on_match(static_cast<int64_t>(e[t].y));
     }
   } else {
     bool go = true;
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
           for (int t = 0; t < kChainChunk; t++) e[t] = a.gkey[p + t < it.e ? p + t : it.e - 1];
 #pragma unroll
           for (int t = 0; t < kChainChunk; t++) {
-            if (written < cnt && p + t < it.e && static_cast<int64_t>(e[t].x) == it.k) {
+            if (written < cnt && p + t < it.e && e[t].x == it.k) {
               a.pair_p[o + written] = static_cast<int32_t>(i);
               a.pair_b[o + written] = static_cast<int32_t>(e[t].y);
               written++;
@@ -600,6 +607,44 @@ __global__ __launch_bounds__(256) void chain_fill_cached_kernel(ChainArgs a) {
       }
     }
     wave_lds_sync();  // the next round overwrites s_off / s_m
+  }
+}
+
+// Build-side [min, max] of every key column over the rows that have a key (no NULL key column): mm[2c] = min, mm[2c+1] = max.
+__global__ __launch_bounds__(256) void key_minmax_kernel(KeyPack kp, int64_t n, long long *__restrict__ mm) {
+  long long lo[kMaxPackCols], hi[kMaxPackCols];
+#pragma unroll
+  for (int c = 0; c < kMaxPackCols; c++) lo[c] = 0x7FFFFFFFFFFFFFFFll, hi[c] = static_cast<long long>(0x8000000000000000ull);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
+    bool null = false;
+#pragma unroll
+    for (int c = 0; c < kMaxPackCols; c++)
+      if (c < kp.n) null = null || col_is_null(kp.c[c], row);
+    if (null) continue;
+#pragma unroll
+    for (int c = 0; c < kMaxPackCols; c++) {
+      if (c < kp.n) {
+        const long long v = col_get_ival(kp.c[c], row);
+        lo[c] = v < lo[c] ? v : lo[c];
+        hi[c] = v > hi[c] ? v : hi[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxPackCols; c++) {
+    if (c < kp.n) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const long long l2 = __shfl_xor(lo[c], d, 64), h2 = __shfl_xor(hi[c], d, 64);
+        lo[c] = l2 < lo[c] ? l2 : lo[c];
+        hi[c] = h2 > hi[c] ? h2 : hi[c];
+      }
+      if (lane_id() == 0 && lo[c] <= hi[c]) {
+        atomicMin(&mm[2 * c], lo[c]);
+        atomicMax(&mm[2 * c + 1], hi[c]);
+      }
+    }
   }
 }
 
@@ -633,7 +678,11 @@ struct crgpu_join : crgpu::Handle {
   bool track_build_matches = false;
   bool null_eq = false;             // INTERSECT/EXCEPT ALL treat NULLs as equal (hashjoiner.go:264-268)
   std::vector<int> left_types, right_types, left_eq, right_eq;
-  bool packed = false;
+  bool packed = false;          // decided at build: the keys pack into one word and the first match decides the result
+  bool pack_candidate = false;  // the key columns could pack (fixed-width families; several columns: integers / BOOL only)
+  bool first_match = false, jt_packed_ok = false;
+  KeyPack kp;                   // build-side key word (columns + the measured ranges); probe sides reuse lo / range / shift
+  DevBuf minmax;
   // Output schema after the pushed-down projection: one entry per emitted column.
   struct OutSrc {
     bool is_left;
@@ -657,7 +706,7 @@ struct crgpu_join : crgpu::Handle {
   // chained table
   DevBuf first, next;          // chained table: per-bucket counters (zero again once built), per-row bucket numbers
   DevBuf cstart, grp, gkey, rep8;    // bucket boundaries, row ids and (single integer key) key values bucket by bucket
-  bool chain_exact = false;    // gkey is in use: equal gkey <=> equal key
+  bool chain_exact = false;    // gkey is in use: equal key word <=> equal key
   uint32_t nb = 0;
   // marks
   DevBuf matched, claimed;
@@ -748,11 +797,18 @@ extern "C" crgpu_status crgpu_dev_join_create(const crgpu_join_spec *spec, crgpu
   }
   // The packed table keeps one row per key: usable whenever the first match
   // decides the result (distinct build side, or pure existence tests).
-  bool first_match = rd || jt == CRGPU_LEFT_ANTI;
-  bool jt_ok = jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER ||
-               jt == CRGPU_LEFT_SEMI || jt == CRGPU_LEFT_ANTI;
-  int kt = j->right_types[j->right_eq[0]];
-  j->packed = spec->n_eq == 1 && first_match && jt_ok && kt != CRGPU_BYTES;
+  j->first_match = rd || jt == CRGPU_LEFT_ANTI;
+  j->jt_packed_ok = jt == CRGPU_INNER || jt == CRGPU_LEFT_OUTER || jt == CRGPU_RIGHT_OUTER || jt == CRGPU_FULL_OUTER ||
+                    jt == CRGPU_LEFT_SEMI || jt == CRGPU_LEFT_ANTI;
+  // One fixed-width key column always packs into a 64-bit word; several do when they are integers / BOOLs whose
+  // build-side ranges add up to <= 64 bits, which is only known at build time (KeyPack, device.h).
+  j->pack_candidate = spec->n_eq <= kMaxPackCols;
+  for (int i = 0; i < spec->n_eq; i++) {
+    const int lt = j->left_types[j->left_eq[i]], rt = j->right_types[j->right_eq[i]];
+    if (lt == CRGPU_BYTES || rt == CRGPU_BYTES) j->pack_candidate = false;
+    if (spec->n_eq > 1 && (lt == CRGPU_FLOAT64 || rt == CRGPU_FLOAT64)) j->pack_candidate = false;
+  }
+  j->packed = false;
   *out = j;
   return CRGPU_OK;
 }
@@ -786,15 +842,70 @@ static bool radix_eligible(const crgpu_join *j, int64_t n) {
   return n > 0 && n >= env_i64("CRGPU_RADIX_MIN_BUILD", int64_t(1) << 22);
 }
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-static RadixSrc radix_src(const DCol &key, const DCol *pay) {
+static RadixSrc radix_src(const KeyPack &kp, const DCol *pay) {
   RadixSrc s;
   std::memset(&s, 0, sizeof(s));
-  s.key = key;
+  s.kp = kp;
   s.pay = pay ? static_cast<const uint8_t *>(pay->data) : nullptr;
   s.pay_width = pay ? type_width(pay->type) : 0;
-  s.fast = key.type == CRGPU_INT64 && key.valid == nullptr && pay != nullptr && s.pay_width == 8 &&
+  const DCol &key = kp.c[0];
+  s.fast = kp.n == 1 && key.type == CRGPU_INT64 && key.valid == nullptr && pay != nullptr && s.pay_width == 8 &&
            aligned16(key.data) && aligned16(pay->data);
   return s;
+}
+
+// The build side's key word: one column packs as it is; several integer / BOOL columns are range-compressed, which
+// needs their [min, max] over the build rows (one reduction pass + a 64-byte read-back).  *ok = false: the ranges do
+// not fit 64 bits (or the key holds a BYTES / several FLOAT columns) and the join takes the chained table.
+static crgpu_status make_build_keypack(crgpu_join *j, int64_t n, bool *ok) {
+  *ok = false;
+  KeyPack &kp = j->kp;
+  std::memset(&kp, 0, sizeof(kp));
+  if (!j->pack_candidate) return CRGPU_OK;
+  kp.n = static_cast<int>(j->right_eq.size());
+  for (int c = 0; c < kp.n; c++) {
+    kp.c[c] = j->build_cols[j->right_eq[c]];
+    kp.range[c] = ~0ull;
+  }
+  if (kp.n == 1) {
+    *ok = true;
+    return CRGPU_OK;
+  }
+  long long mm[2 * kMaxPackCols];
+  for (int c = 0; c < kMaxPackCols; c++) mm[2 * c] = 0x7FFFFFFFFFFFFFFFll, mm[2 * c + 1] = static_cast<long long>(0x8000000000000000ull);
+  hipStream_t st = stream();
+  if (n > 0) {
+    CRGPU_TRY(j->minmax.ensure(sizeof(mm)));
+    CRGPU_HIP(hipMemcpyAsync(j->minmax.p, mm, sizeof(mm), hipMemcpyHostToDevice, st));
+    ProfScope prof("join_build");
+    hipLaunchKernelGGL(key_minmax_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, st, kp, n, j->minmax.as<long long>());
+    CRGPU_HIP(hipGetLastError());
+    CRGPU_HIP(hipMemcpyAsync(mm, j->minmax.p, sizeof(mm), hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+  }
+  uint32_t shift = 0;
+  for (int c = 0; c < kp.n; c++) {
+    long long lo = mm[2 * c], hi = mm[2 * c + 1];
+    if (lo > hi) lo = hi = 0;  // no build row has a key: nothing can match
+    const uint64_t range = static_cast<uint64_t>(hi) - static_cast<uint64_t>(lo);
+    uint32_t bits = 0;
+    while (bits < 64 && (range >> bits) != 0) bits++;
+    if (shift + bits > 64) return CRGPU_OK;  // does not fit: chained table
+    kp.lo[c] = lo;
+    kp.range[c] = range;
+    kp.shift[c] = shift;
+    shift += bits;
+  }
+  if (shift >= 64 && kp.n > 1) {
+    // a full 64-bit word could collide with the tables' EMPTY marker only through the side slot, which handles it
+  }
+  *ok = true;
+  return CRGPU_OK;
+}
+static KeyPack probe_keypack(const crgpu_join *j, const std::vector<DCol> &left) {
+  KeyPack kp = j->kp;
+  for (int c = 0; c < kp.n; c++) kp.c[c] = left[j->left_eq[c]];
+  return kp;
 }
 
 extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
@@ -829,6 +940,10 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
     CRGPU_HIP(hipMemsetAsync(j->claimed.p, 0, static_cast<size_t>(n > 0 ? n : 1) * 4, st));
   }
 
+  bool packable = false;
+  CRGPU_TRY(make_build_keypack(j, n, &packable));
+  j->packed = packable && j->first_match && j->jt_packed_ok;
+  j->chain_exact = false;
   if (j->packed) {
     const int kc = j->right_eq[0];
     j->cap = next_pow2(static_cast<uint64_t>(n) * 2 < 1024 ? 1024 : static_cast<uint64_t>(n) * 2);
@@ -836,13 +951,14 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
     // column, which then rides in the slot's val word (no row-id indirection at probe time).
     j->covering = false;
     j->cover_col = -1;
-    const bool key_castable = j->right_types[kc] != CRGPU_FLOAT64 && j->build_cols[kc].valid == nullptr;
+    // a build key column can be emitted from the probe row's key word when the key is that one non-float column
+    const bool key_castable = j->kp.n == 1 && j->right_types[kc] != CRGPU_FLOAT64 && j->build_cols[kc].valid == nullptr;
     if (!j->track_build_matches && j->out_src.size() <= static_cast<size_t>(kMaxFused)) {
       bool ok = true;
       int pc = -1;
       for (const auto &o : j->out_src) {
         if (o.is_left) continue;
-        if (o.src == kc) {
+        if (o.src == kc && key_castable) {
           ok = ok && key_castable;
         } else if (pc == -1 || pc == o.src) {
           pc = o.src;
@@ -858,8 +974,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
     }
     j->use_radix = false;
     if (radix_eligible(j, n)) {
-      RadixSrc src = radix_src(j->build_cols[kc],
-                               (j->covering && j->cover_col >= 0) ? &j->build_cols[j->cover_col] : nullptr);
+      RadixSrc src = radix_src(j->kp, (j->covering && j->cover_col >= 0) ? &j->build_cols[j->cover_col] : nullptr);
       bool ok = false;
       CRGPU_TRY(radix_build(j->radix, src, n, &ok));
       j->use_radix = ok;
@@ -875,7 +990,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
                                     ? static_cast<const uint64_t *>(j->build_cols[j->cover_col].data)
                                     : nullptr;
       ProfScope prof("join_build");
-      hipLaunchKernelGGL(packed_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, j->build_cols[kc], n,
+      hipLaunchKernelGGL(packed_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, j->kp, n,
                          j->slots.as<Slot>(), j->cap - 1, payload, j->special.as<Special>());
       CRGPU_HIP(hipGetLastError());
     }
@@ -891,11 +1006,9 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
       keys.n = static_cast<int>(j->right_eq.size());
       keys._pad = 0;
       for (int k = 0; k < keys.n; k++) keys.c[k] = j->build_cols[j->right_eq[k]];
-      // One integer key column: the bucket-ordered copy of the keys decides equality by itself.  Not with NULL = NULL
-      // semantics (set operations): a NULL row is in the table then, and its stored value is not its key.
-      const DCol &bk = keys.c[0];
-      const bool is_int = bk.type == CRGPU_INT16 || bk.type == CRGPU_INT32 || bk.type == CRGPU_INT64;
-      j->chain_exact = keys.n == 1 && is_int && !j->null_eq;
+      // Keys that pack into one word: the bucket-ordered copy of the key words decides equality by itself.  Not with
+      // NULL = NULL semantics (set operations): a NULL row is in the table then, and its stored word is not its key.
+      j->chain_exact = packable && !j->null_eq;
       CRGPU_TRY(j->cstart.ensure((static_cast<size_t>(nb) + 1) * 4));
       CRGPU_TRY(j->offsets.ensure((static_cast<size_t>(nb) + 1) * 8));  // scan output before narrowing; the probe reuses it
       CRGPU_TRY(j->grp.ensure(static_cast<size_t>(n) * 4));
@@ -909,7 +1022,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
       // half the footprint of the array every probe row reads at random
       hipLaunchKernelGGL(chain_narrow_kernel, dim3(grid_for(static_cast<int64_t>(nb) + 1, 256)), dim3(256), 0, st,
                          j->offsets.as<uint64_t>(), static_cast<int64_t>(nb) + 1, j->cstart.as<uint32_t>());
-      hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, keys, n,
+      hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, j->kp, n,
                          j->next.as<uint32_t>(), j->cstart.as<uint32_t>(), j->first.as<uint32_t>(),
                          j->grp.as<uint32_t>(), j->chain_exact ? j->gkey.as<ulonglong2>() : nullptr);
       CRGPU_HIP(hipGetLastError());
@@ -991,7 +1104,7 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
 
   ProbeArgs a;
   std::memset(&a, 0, sizeof(a));
-  a.key = left[j->left_eq[0]];
+  a.kp = probe_keypack(j, left);
   a.n = n;
   a.slots = j->slots.as<Slot>();
   a.mask = j->cap - 1;
@@ -1094,7 +1207,7 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
   const int64_t cap_rows = n > 0 ? n : 1;
   const int lkc = j->left_eq[0], rkc = j->right_eq[0];
   const DCol &lkey = left[lkc];
-  const bool key_castable = lkey.type != CRGPU_FLOAT64;
+  const bool key_castable = j->kp.n == 1 && lkey.type != CRGPU_FLOAT64;  // the probe key column can be emitted from the key word
 
   int pay_col = -1;
   bool need_pairs_p = false;
@@ -1106,7 +1219,7 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
     else pay_col = os.src;
   }
   if (need_pairs_p) pay_col = -1;
-  RadixSrc src = radix_src(lkey, pay_col >= 0 ? &left[pay_col] : nullptr);
+  RadixSrc src = radix_src(probe_keypack(j, left), pay_col >= 0 ? &left[pay_col] : nullptr);
 
   RadixEmit e;
   std::memset(&e, 0, sizeof(e));
@@ -1227,8 +1340,8 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
     a.gkey = nullptr;
     a.rep8 = j->chain_exact ? nullptr : j->rep8.as<uint8_t>();
     if (j->chain_exact) {
-      const int pt = a.probe.c[0].type;
-      if (pt == CRGPU_INT16 || pt == CRGPU_INT32 || pt == CRGPU_INT64) a.gkey = j->gkey.as<ulonglong2>();
+      a.gkey = j->gkey.as<ulonglong2>();
+      a.kp = probe_keypack(j, left);
     }
     a.nb_mask = j->nb - 1;
     a.null_eq = j->null_eq;

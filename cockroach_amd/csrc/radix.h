@@ -10,7 +10,7 @@
 // partition's tables (<= 3 MiB) stay in that XCD's L2.
 #pragma once
 
-#include "common.h"
+#include "device.h"
 
 namespace crgpu {
 
@@ -41,7 +41,7 @@ struct RadixEmit {
 
 // One side of the join as {packed key, 64-bit payload} rows.
 struct RadixSrc {
-  DCol key;
+  KeyPack kp;          // the key word of a row (device.h)
   const uint8_t *pay;  // payload column, or null => the payload is the row id
   int32_t pay_width;
   int32_t fast;  // int64 key without NULLs + 8-byte payload, both 16-byte aligned: vector loads

@@ -59,7 +59,7 @@ template <bool FAST>
 __device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64_t hi, uint64_t *k, uint64_t *v,
                                             bool *ok) {
   if (FAST && r0 + 1 < hi) {
-    const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(s.key.data)[r0 >> 1];
+    const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(s.kp.c[0].data)[r0 >> 1];
     const ulonglong2 b = reinterpret_cast<const ulonglong2 *>(s.pay)[r0 >> 1];
     k[0] = a.x, k[1] = a.y, v[0] = b.x, v[1] = b.y;
     ok[0] = ok[1] = true;
@@ -68,12 +68,9 @@ __device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64
 #pragma unroll
   for (int t = 0; t < 2; t++) {
     const int64_t r = r0 + t;
-    ok[t] = r < hi && !col_is_null(s.key, r);
     k[t] = 0, v[t] = 0;
-    if (ok[t]) {
-      k[t] = pack_key(s.key, r);
-      v[t] = s.pay ? rload(s.pay, r, s.pay_width) : static_cast<uint64_t>(r);
-    }
+    ok[t] = r < hi && key_pack(s.kp, r, k[t]);
+    if (ok[t]) v[t] = s.pay ? rload(s.pay, r, s.pay_width) : static_cast<uint64_t>(r);
   }
 }
 
@@ -89,14 +86,15 @@ __global__ __launch_bounds__(1024) void radix_hist_kernel(RadixSrc src, int64_t 
   if (hi > n) hi = n;
   for (int64_t r0 = lo + 2 * static_cast<int64_t>(threadIdx.x); r0 < hi; r0 += 2048) {
     if (FAST && r0 + 1 < hi) {
-      const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(src.key.data)[r0 >> 1];
+      const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(src.kp.c[0].data)[r0 >> 1];
       atomicAdd(&h[rpart(fmix64(a.x))], 1u);
       atomicAdd(&h[rpart(fmix64(a.y))], 1u);
     } else {
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const int64_t r = r0 + t;
-        if (r < hi && !col_is_null(src.key, r)) atomicAdd(&h[rpart(fmix64(pack_key(src.key, r)))], 1u);
+        uint64_t kk;
+        if (r < hi && key_pack(src.kp, r, kk)) atomicAdd(&h[rpart(fmix64(kk))], 1u);
       }
     }
   }
@@ -436,14 +434,13 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
           look[j] = true;
         }
       } else if (inb[j]) {
-        knull[j] = col_is_null(a.src.key, r);
+        knull[j] = !key_pack(a.src.kp, r, k[j]);  // NULL, or outside the build side's key range: matches nothing
         if (MODE == 2) {
-          inb[j] = knull[j];  // this pass only sees the NULL-key rows
+          inb[j] = knull[j];  // this pass only sees the rows without a key
         } else {
           look[j] = !knull[j];
-          if (knull[j]) inb[j] = false;  // NULL-key rows are emitted by the MODE 2 pass
+          if (knull[j]) inb[j] = false;  // rows without a key are emitted by the MODE 2 pass
         }
-        if (!knull[j]) k[j] = pack_key(a.src.key, r);
         pay[j] = a.src.pay ? rload(a.src.pay, r, a.src.pay_width) : static_cast<uint64_t>(r);
       }
     }
@@ -734,7 +731,9 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
     ProfScope prof("join_probe");
     CRGPU_TRY(launch_probe<1>(jt, a, static_cast<int>(tiles < cap ? tiles : cap)));
   }
-  if (keeps_unmatched && src.key.valid != nullptr) {  // NULL keys never match but LEFT OUTER / ANTI keep the row
+  bool keyless = src.kp.n > 1;  // a multi-column key: probe values may lie outside the build side's range
+  for (int c = 0; c < src.kp.n; c++) keyless = keyless || src.kp.c[c].valid != nullptr;
+  if (keeps_unmatched && keyless) {  // rows without a key (NULL / out of range) never match but LEFT OUTER / ANTI keep them
     int64_t tiles = (n + kTile - 1) / kTile;
     int64_t cap = static_cast<int64_t>(num_cus()) * 4;
     CRGPU_TRY(launch_probe<2>(jt, a, static_cast<int>(tiles < cap ? tiles : cap)));

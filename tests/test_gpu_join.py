@@ -245,3 +245,102 @@ def test_join_radix_large_checksums(radix_env):
     assert np.array_equal(w_out[order], pw[hit])
     assert np.array_equal(v_out[order], pk[hit] * 3 + 1)
     j.close()
+
+
+# ---------------------------------------------------------------------------
+# several integer key columns packed into one key word (KeyPack, csrc/device.h): packed table, radix table and the
+# exact chained table; the reference compares the columns one by one (hashtable_tmpl.go:96-223)
+# ---------------------------------------------------------------------------
+def _multi_col_tables(rng, nl, nr, shape, unique_right):
+    if shape == "two_i64":      # ranges of 13 + 9 bits, negative values, probe values outside the build range
+        a = rng.integers(-3000, 3000, nr, dtype=np.int64)
+        b = rng.integers(100, 400, nr, dtype=np.int64)
+        la = rng.integers(-4000, 4000, nl, dtype=np.int64)
+        lb = rng.integers(50, 450, nl, dtype=np.int64)
+        rkeys = [cd.Vec.from_numpy(cd.INT64, a, rng.random(nr) > 0.03), cd.Vec.from_numpy(cd.INT64, b)]
+        lkeys = [cd.Vec.from_numpy(cd.INT64, la, rng.random(nl) > 0.03), cd.Vec.from_numpy(cd.INT64, lb)]
+    elif shape == "mixed_widths_bool":  # INT16 x INT32 / INT64, plus a BOOL column (hash_utils.eg.go:363-366, :69-73)
+        a = rng.integers(-200, 200, nr).astype(np.int16)
+        b = rng.integers(0, 50, nr).astype(np.int32)
+        c = rng.integers(0, 2, nr).astype(np.uint8)
+        rkeys = [cd.Vec.from_numpy(cd.INT16, a), cd.Vec.from_numpy(cd.INT32, b, rng.random(nr) > 0.05), cd.Vec.from_numpy(cd.BOOL, c)]
+        lkeys = [cd.Vec.from_numpy(cd.INT64, rng.integers(-250, 250, nl, dtype=np.int64)),
+                 cd.Vec.from_numpy(cd.INT16, rng.integers(0, 60, nl).astype(np.int16)),
+                 cd.Vec.from_numpy(cd.BOOL, rng.integers(0, 2, nl).astype(np.uint8), rng.random(nl) > 0.05)]
+    elif shape == "too_wide":   # 2 x 40 bits do not fit one word: the generic chained table must take over
+        a = rng.integers(0, 300, nr, dtype=np.int64) << 32
+        b = rng.integers(0, 20, nr, dtype=np.int64) << 36
+        rkeys = [cd.Vec.from_numpy(cd.INT64, a), cd.Vec.from_numpy(cd.INT64, b)]
+        lkeys = [cd.Vec.from_numpy(cd.INT64, rng.integers(0, 320, nl, dtype=np.int64) << 32),
+                 cd.Vec.from_numpy(cd.INT64, rng.integers(0, 22, nl, dtype=np.int64) << 36)]
+    else:                       # "full_word": 32 + 32 bits use the whole key word, including the all-ones pattern of the EMPTY marker
+        a = np.concatenate([np.array([0xFFFFFFFF, 0, 0xFFFFFFFF], dtype=np.int64), rng.integers(0, 1 << 32, nr - 3, dtype=np.int64)])
+        b = np.concatenate([np.array([0xFFFFFFFF, 0xFFFFFFFF, 0], dtype=np.int64), rng.integers(0, 1 << 32, nr - 3, dtype=np.int64)])
+        rkeys = [cd.Vec.from_numpy(cd.INT64, a), cd.Vec.from_numpy(cd.INT64, b)]
+        pick = rng.integers(0, nr, nl)
+        la, lb = a[pick].copy(), b[pick].copy()
+        miss = rng.random(nl) < 0.3
+        la[miss] ^= 1
+        lkeys = [cd.Vec.from_numpy(cd.INT64, la), cd.Vec.from_numpy(cd.INT64, lb)]
+    if unique_right:  # keep the first row of every build key
+        rows = list(zip(*[k.to_values() for k in rkeys]))
+        seen, keep = set(), []
+        for i, r in enumerate(rows):
+            if r not in seen:
+                seen.add(r)
+                keep.append(i)
+        rkeys = [k.take(np.array(keep)) for k in rkeys]
+        nr = len(keep)
+    right = rkeys + [cd.Vec.from_numpy(cd.INT64, np.arange(nr, dtype=np.int64) * 7)]
+    left = lkeys + [cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(nl))]
+    return left, right, list(range(len(lkeys)))
+
+
+@pytest.mark.parametrize("jt", ALL_JOIN_TYPES)
+@pytest.mark.parametrize("shape", ["two_i64", "mixed_widths_bool", "too_wide", "full_word"])
+@pytest.mark.parametrize("unique_right", [False, True])
+def test_join_multi_col_int_keys_vs_oracle(oracle, jt, shape, unique_right):
+    rng = np.random.default_rng(hash((jt, shape, unique_right)) % 2**32)
+    left, right, eq = _multi_col_tables(rng, 30_000, 5_000, shape, unique_right)
+    if jt in ("INTERSECT_ALL", "EXCEPT_ALL"):
+        left, right = left[:len(eq)], right[:len(eq)]
+    want = H.vecs_to_tuples(oracle.hash_join(H.JOIN_TYPE[jt], left, right, eq, eq, unique_right))
+    got = G.gpu_join(jt, left, right, eq, eq, unique_right, probe_chunks=2)
+    H.assert_same_multiset(got, want, f"{jt} {shape} unique={unique_right}")
+
+
+@pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER", "LEFT_SEMI", "LEFT_ANTI"])
+@pytest.mark.parametrize("shape", ["two_i64", "mixed_widths_bool", "full_word"])
+def test_join_multi_col_int_keys_radix_vs_oracle(oracle, radix_env, jt, shape):
+    rng = np.random.default_rng(hash((jt, shape, "radix")) % 2**32)
+    left, right, eq = _multi_col_tables(rng, 50_000, 8_000, shape, True)
+    want = H.vecs_to_tuples(oracle.hash_join(H.JOIN_TYPE[jt], left, right, eq, eq, True))
+    got = G.gpu_join(jt, left, right, eq, eq, True, probe_chunks=2)
+    H.assert_same_multiset(got, want, f"{jt} {shape} {radix_env}")
+
+
+def test_join_two_col_keys_large_radix_checksums():
+    """Q9's shape: (l_partkey, l_suppkey) = (ps_partkey, ps_suppkey), a two-column key that is unique on the build side,
+    2^22 build x 2^24 probe rows through the radix path; verified row by row against numpy."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(9)
+    nb, npr = 1 << 22, 1 << 24
+    part = np.arange(nb, dtype=np.int64) // 4 + 1
+    supp = (part * 7 + np.arange(nb, dtype=np.int64) % 4 * 2501) % 10_000 + 1
+    cost = rng.integers(100, 100_000, nb).astype(np.float64) / 100.0
+    pick = rng.integers(0, nb, npr)
+    lp, ls = part[pick].copy(), supp[pick].copy()
+    miss = rng.random(npr) < 0.25
+    ls[miss] += 10_001  # outside the build side's range of the second column
+    lw = np.arange(npr, dtype=np.int64)
+    j = dev.Join(0, [cd.INT64] * 3, [cd.INT64, cd.INT64, cd.FLOAT64], [0, 1], [0, 1], True, out_cols=[2, 5])
+    j.build([dev.upload(cd.Vec.from_numpy(cd.INT64, part)), dev.upload(cd.Vec.from_numpy(cd.INT64, supp)),
+             dev.upload(cd.Vec.from_numpy(cd.FLOAT64, cost))], nb)
+    res = j.probe([dev.upload(cd.Vec.from_numpy(cd.INT64, lp)), dev.upload(cd.Vec.from_numpy(cd.INT64, ls)),
+                   dev.upload(cd.Vec.from_numpy(cd.INT64, lw))], npr)
+    assert res.n == int((~miss).sum())
+    w_out, c_out = (o.data for o in dev.result_to_vecs(res))
+    order = np.argsort(w_out, kind="stable")
+    assert np.array_equal(w_out[order], lw[~miss])
+    assert np.array_equal(c_out[order], cost[pick][~miss])
+    j.close()
