@@ -703,6 +703,7 @@ struct crgpu_join : crgpu::Handle {
   // radix-partitioned table (large unique-key build sides, radix.h)
   RadixTable radix;
   bool use_radix = false;
+  bool use_radix_dup = false;  // INNER / LEFT OUTER over a non-distinct build side: the grouped radix table (radix_build_dup)
   // chained table
   DevBuf first, next;          // chained table: per-bucket counters (zero again once built), per-row bucket numbers
   DevBuf cstart, grp, gkey, rep8;    // bucket boundaries, row ids and (single integer key) key values bucket by bucket
@@ -854,6 +855,33 @@ static RadixSrc radix_src(const KeyPack &kp, const DCol *pay) {
   return s;
 }
 
+// covering: every emitted build column is the int/bool key itself or ONE 8-byte non-null payload column, which then
+// rides in the table's value word (no row-id indirection at probe time).
+static void decide_covering(crgpu_join *j) {
+  const int kc = j->right_eq[0];
+  j->covering = false;
+  j->cover_col = -1;
+  // a build key column can be emitted from the probe row's key word when the key is that one non-float column
+  const bool key_castable = j->kp.n == 1 && j->right_types[kc] != CRGPU_FLOAT64 && j->build_cols[kc].valid == nullptr;
+  if (j->track_build_matches || j->out_src.size() > static_cast<size_t>(kMaxFused)) return;
+  bool ok = true;
+  int pc = -1;
+  for (const auto &o : j->out_src) {
+    if (o.is_left) continue;
+    if (o.src == kc && key_castable) continue;
+    if (pc == -1 || pc == o.src) {
+      pc = o.src;
+      ok = ok && type_width(j->right_types[pc]) == 8 && j->build_cols[pc].valid == nullptr;
+    } else {
+      ok = false;
+    }
+  }
+  if (ok) {
+    j->covering = true;
+    j->cover_col = pc;
+  }
+}
+
 // The build side's key word: one column packs as it is; several integer / BOOL columns are range-compressed, which
 // needs their [min, max] over the build rows (one reduction pass + a 64-byte read-back).  *ok = false: the ranges do
 // not fit 64 bits (or the key holds a BYTES / several FLOAT columns) and the join takes the chained table.
@@ -947,31 +975,7 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
   if (j->packed) {
     const int kc = j->right_eq[0];
     j->cap = next_pow2(static_cast<uint64_t>(n) * 2 < 1024 ? 1024 : static_cast<uint64_t>(n) * 2);
-    // covering: every emitted build column is the int/bool key itself or ONE 8-byte non-null payload
-    // column, which then rides in the slot's val word (no row-id indirection at probe time).
-    j->covering = false;
-    j->cover_col = -1;
-    // a build key column can be emitted from the probe row's key word when the key is that one non-float column
-    const bool key_castable = j->kp.n == 1 && j->right_types[kc] != CRGPU_FLOAT64 && j->build_cols[kc].valid == nullptr;
-    if (!j->track_build_matches && j->out_src.size() <= static_cast<size_t>(kMaxFused)) {
-      bool ok = true;
-      int pc = -1;
-      for (const auto &o : j->out_src) {
-        if (o.is_left) continue;
-        if (o.src == kc && key_castable) {
-          ok = ok && key_castable;
-        } else if (pc == -1 || pc == o.src) {
-          pc = o.src;
-          ok = ok && type_width(j->right_types[pc]) == 8 && j->build_cols[pc].valid == nullptr;
-        } else {
-          ok = false;
-        }
-      }
-      if (ok) {
-        j->covering = true;
-        j->cover_col = pc;
-      }
-    }
+    decide_covering(j);
     j->use_radix = false;
     if (radix_eligible(j, n)) {
       RadixSrc src = radix_src(j->kp, (j->covering && j->cover_col >= 0) ? &j->build_cols[j->cover_col] : nullptr);
@@ -994,7 +998,19 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
                          j->slots.as<Slot>(), j->cap - 1, payload, j->special.as<Special>());
       CRGPU_HIP(hipGetLastError());
     }
-  } else {
+  }
+  j->use_radix_dup = false;
+  if (!j->packed && packable && !j->null_eq && (j->join_type == CRGPU_INNER || j->join_type == CRGPU_LEFT_OUTER) &&
+      radix_eligible(j, n)) {
+    // duplicate build keys: group them per sub-partition of the radix table (falls back to the chained table when the
+    // keys are so skewed that a sub-partition overflows)
+    decide_covering(j);
+    RadixSrc src = radix_src(j->kp, (j->covering && j->cover_col >= 0) ? &j->build_cols[j->cover_col] : nullptr);
+    bool ok = false;
+    CRGPU_TRY(radix_build_dup(j->radix, src, n, &ok));
+    j->use_radix_dup = ok;
+  }
+  if (!j->packed && !j->use_radix_dup) {
     uint64_t nb = next_pow2(static_cast<uint64_t>(n) < 256 ? 256 : static_cast<uint64_t>(n));
     if (nb > 0x80000000ull) nb = 0x80000000ull;
     j->nb = static_cast<uint32_t>(nb);
@@ -1204,7 +1220,7 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
   const bool outer_nulls = left_or_full_outer(jt);
   const bool keeps_unmatched = jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_ANTI;
   hipStream_t st = stream();
-  const int64_t cap_rows = n > 0 ? n : 1;
+  int64_t cap_rows = n > 0 ? n : 1;
   const int lkc = j->left_eq[0], rkc = j->right_eq[0];
   const DCol &lkey = left[lkc];
   const bool key_castable = j->kp.n == 1 && lkey.type != CRGPU_FLOAT64;  // the probe key column can be emitted from the key word
@@ -1220,6 +1236,16 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
   }
   if (need_pairs_p) pay_col = -1;
   RadixSrc src = radix_src(probe_keypack(j, left), pay_col >= 0 ? &left[pay_col] : nullptr);
+  int64_t min_probe = j->n_build >> 3;
+  if (min_probe < (int64_t(1) << 20)) min_probe = int64_t(1) << 20;
+  const bool partitioned = n >= env_i64("CRGPU_RADIX_MIN_PROBE", min_probe);
+  if (j->use_radix_dup && n > 0) {  // duplicate build keys: the count pass sizes the outputs
+    uint64_t total = 0;
+    CRGPU_TRY(radix_probe_dup_count(j->radix, jt, src, n, partitioned, &total));
+    if (total > 0x7FFFFFF0ull)
+      return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_join_probe: more than 2^31 output rows for one probe chunk; probe in smaller chunks");
+    cap_rows = total > 0 ? static_cast<int64_t>(total) : 1;
+  }
 
   RadixEmit e;
   std::memset(&e, 0, sizeof(e));
@@ -1274,10 +1300,8 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
   }
   uint64_t nout = 0;
   if (n > 0) {
-    int64_t min_probe = j->n_build >> 3;
-    if (min_probe < (int64_t(1) << 20)) min_probe = int64_t(1) << 20;
-    const bool partitioned = n >= env_i64("CRGPU_RADIX_MIN_PROBE", min_probe);
-    CRGPU_TRY(radix_probe(j->radix, jt, src, n, e, partitioned));
+    if (j->use_radix_dup) CRGPU_TRY(radix_probe_dup_emit(j->radix, jt, src, n, e, partitioned));
+    else CRGPU_TRY(radix_probe(j->radix, jt, src, n, e, partitioned));
     CRGPU_HIP(hipMemcpyAsync(&nout, j->counter.p, 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
   }
@@ -1417,7 +1441,7 @@ extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *le
   join_setup_outputs(j);
   // Empty build side short-circuits (hashjoiner.go:300-306, join_type.go:79-88): the
   // kernels below already produce the right answer on an empty table, so no special case.
-  if (j->packed && j->use_radix) return probe_radix(j, left, n, res);
+  if ((j->packed && j->use_radix) || j->use_radix_dup) return probe_radix(j, left, n, res);
   if (j->packed) return probe_packed(j, left, n, res);
   return probe_chained(j, left, n, res);
 }

@@ -55,6 +55,9 @@ struct RadixSpecial {  // the one build key whose packed value equals kRadixEmpt
 
 struct RadixTable {
   bool ready = false;
+  bool dup = false;       // built by radix_build_dup: a slot's value is {first grouped row << 16 | rows of the key}
+  DevBuf pay_sorted;      // dup: the build payloads grouped by key, sub-partition by sub-partition
+  DevBuf vals, counters;  // dup probe: every probe row's slot value (count pass -> emit pass); {output rows, rows seen}
   int sub_bits = 0;
   int64_t n = 0;
   DevBuf rows_a, rows_b;  // level-1 output; level-2 output (kRadixSubCap rows reserved per sub-partition)
@@ -80,5 +83,17 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
 // (LEFT OUTER / LEFT ANTI).
 crgpu_status radix_probe(RadixTable &t, int join_type, const RadixSrc &src, int64_t n, const RadixEmit &emit,
                          bool partitioned);
+
+// Duplicate build keys (INNER / LEFT OUTER with a non-distinct build side): the same two partition levels, then per
+// sub-partition the rows are GROUPED by key in LDS; the table holds one slot per distinct key whose value is the
+// {first row, row count} of its group in pay_sorted.  *ok = false when a sub-partition overflows (heavily skewed keys):
+// the caller takes the chained table.
+crgpu_status radix_build_dup(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok);
+// Probe in two passes: count (looks every probe row up once, keeps its slot value, sums the output rows) ...
+crgpu_status radix_probe_dup_count(RadixTable &t, int join_type, const RadixSrc &src, int64_t n, bool partitioned,
+                                   uint64_t *out_rows);
+// ... then emit into outputs sized by the count (expands every probe row into its matches, tile by tile).
+crgpu_status radix_probe_dup_emit(RadixTable &t, int join_type, const RadixSrc &src, int64_t n, const RadixEmit &emit,
+                                  bool partitioned);
 
 }  // namespace crgpu

@@ -561,6 +561,330 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
   }
 }
 
+// ================================================================== duplicate build keys
+// One workgroup per sub-partition (<= kRadixSubCap rows).  The rows are grouped by key in LDS: a linear-probing table of
+// row ids (CAS; a row either becomes the head of a new group or joins the group whose head has its key) gives every row
+// its group and its rank inside it; an exclusive scan over the groups' counts gives every group its first position;
+// the payloads are written grouped to pay_sorted; the group HEADS (distinct keys, so no two equal keys ever race) are
+// inserted into the 3-way cuckoo table, whose image holds {key, (first grouped row << 16) | rows}.
+static constexpr int kGroupSlots = 4096;  // linear-probing group table (load <= 0.625)
+static constexpr size_t kGroupLds = static_cast<size_t>(kRadixSubCap) * 8 + kGroupSlots * 4 * 2 + kRadixSlots * 4 + kRadixSubCap * 2 * 2;
+__global__ __launch_bounds__(512) void radix_group_kernel(const ulonglong2 *__restrict__ rows,
+                                                          const uint32_t *__restrict__ sub_count,
+                                                          ulonglong2 *__restrict__ table,
+                                                          unsigned long long *__restrict__ pay_sorted,
+                                                          RadixSpecial *__restrict__ special, uint32_t *__restrict__ failed) {
+  constexpr int THREADS = 512;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  extern __shared__ __align__(16) unsigned char g_lds[];
+  unsigned long long *skey = reinterpret_cast<unsigned long long *>(g_lds);                       // [kRadixSubCap]
+  uint32_t *lp = reinterpret_cast<uint32_t *>(skey + kRadixSubCap);                                // [kGroupSlots] head row of the group
+  uint32_t *gcnt = lp + kGroupSlots;                                                                // [kGroupSlots] rows, then (start << 16 | rows)
+  uint32_t *tab = gcnt + kGroupSlots;                                                               // [kRadixSlots] cuckoo: head row ids
+  uint16_t *gof = reinterpret_cast<uint16_t *>(tab + kRadixSlots);                                  // [kRadixSubCap] group slot of the row
+  uint16_t *rnk = gof + kRadixSubCap;                                                               // [kRadixSubCap] rank inside the group
+  __shared__ uint32_t s_wsum[THREADS / 64];
+  const int q = blockIdx.x;
+  const int64_t base = static_cast<int64_t>(q) * kRadixSubCap;
+  uint32_t n = sub_count[q];
+  if (n > static_cast<uint32_t>(kRadixSubCap)) n = kRadixSubCap;  // overflow is reported by the split kernel
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) skey[i] = rows[base + i].x;
+  for (int i = threadIdx.x; i < kGroupSlots; i += THREADS) lp[i] = kNone, gcnt[i] = 0;
+  for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) tab[i] = kNone;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    const unsigned long long k = skey[i];
+    uint32_t s = static_cast<uint32_t>(fmix64(k) >> 20) & (kGroupSlots - 1);
+    while (true) {
+      const uint32_t old = atomicCAS(&lp[s], kNone, i);
+      if (old == kNone || skey[old] == k) break;
+      s = (s + 1) & (kGroupSlots - 1);
+    }
+    gof[i] = static_cast<uint16_t>(s);
+    rnk[i] = static_cast<uint16_t>(atomicAdd(&gcnt[s], 1u));
+  }
+  __syncthreads();
+  {  // exclusive scan of the 4096 group counts, 8 per thread, written back as (start << 16 | rows)
+    constexpr int PER = kGroupSlots / THREADS;
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      c[t] = gcnt[threadIdx.x * PER + t];
+      sum += c[t];
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane_id() == 63) s_wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t ex = incl - sum;
+    for (int w = 0; w < static_cast<int>(threadIdx.x >> 6); w++) ex += s_wsum[w];
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      gcnt[threadIdx.x * PER + t] = (ex << 16) | c[t];
+      ex += c[t];
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    const uint32_t g = gof[i];
+    pay_sorted[base + (gcnt[g] >> 16) + rnk[i]] = rows[base + i].y;
+    if (lp[g] != i) continue;  // only the head of a group goes into the table
+    const unsigned long long kh = skey[i];
+    if (kh == kRadixEmpty) {  // the one key equal to the empty marker lives beside the table
+      special->val = (static_cast<unsigned long long>(base + (gcnt[g] >> 16)) << 16) | (gcnt[g] & 0xFFFFu);
+      special->present = 1;
+      continue;
+    }
+    uint32_t cur = i, from = kNone, rnd = (i + 1u) * 2654435761u + static_cast<uint32_t>(q);
+    int iter = 0;
+    for (; iter < 4096; iter++) {
+      uint32_t s[3];
+      rslots(fmix64(skey[cur]), s);
+      bool placed = false;
+#pragma unroll
+      for (int c = 0; c < 3 && !placed; c++) placed = atomicCAS(&tab[s[c]], kNone, cur) == kNone;
+      if (placed) break;
+      rnd = rnd * 1664525u + 1013904223u;
+      uint32_t c = (rnd >> 16) % 3u;  // evict one of the three occupants (random walk)
+      if (s[c] == from) c = (c + 1u) % 3u;
+      const uint32_t old = atomicExch(&tab[s[c]], cur);
+      if (old == kNone) break;
+      from = s[c];
+      cur = old;
+    }
+    if (iter == 4096) atomicOr(failed, 2u);
+  }
+  __syncthreads();
+  ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
+  for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) {
+    const uint32_t id = tab[i];
+    if (id == kNone) {
+      dst[i] = make_ulonglong2(kRadixEmpty, 0);
+    } else {
+      const uint32_t g = gcnt[gof[id]];
+      dst[i] = make_ulonglong2(skey[id], (static_cast<unsigned long long>(base + (g >> 16)) << 16) | (g & 0xFFFFu));
+    }
+  }
+}
+
+struct RadixDupArgs {
+  const ulonglong2 *prow;  // partitioned probe rows (MODE 0)
+  const uint32_t *pstart;
+  const uint32_t *pcount;
+  RadixSrc src;  // probe columns (MODE 1)
+  int64_t n;
+  const ulonglong2 *table;
+  const RadixSpecial *special;
+  const unsigned long long *pay_sorted;
+  unsigned long long *vals;      // slot value of every probe row (0 = no match), indexed like prow (MODE 0) / the rows (MODE 1)
+  unsigned long long *counters;  // [0] output rows, [1] probe rows seen
+  uint32_t smask;
+  int32_t wg_per_part;
+  int32_t left_outer;
+  int32_t _pad;
+  RadixEmit emit;
+};
+
+// The tile loop bounds of a workgroup: MODE 0 partition-at-a-time with the XCD mapping of radix_probe_kernel, MODE 1 the
+// unpartitioned rows.
+template <int MODE, int kTile>
+__device__ __forceinline__ void dup_tiles(const RadixDupArgs &a, int64_t &lo, int64_t &hi, int64_t &step, uint32_t &part) {
+  part = 0;
+  if (MODE == 0) {
+    const uint32_t b = blockIdx.x, x = b & 7u, i = b >> 3;
+    part = (i / a.wg_per_part) * 8u + x;
+    const uint32_t slice = i % a.wg_per_part;
+    const int64_t pbeg = a.pstart[part];
+    lo = pbeg + static_cast<int64_t>(slice) * kTile;
+    hi = pbeg + a.pcount[part];
+    step = static_cast<int64_t>(a.wg_per_part) * kTile;
+  } else {
+    lo = static_cast<int64_t>(blockIdx.x) * kTile;
+    hi = a.n;
+    step = static_cast<int64_t>(gridDim.x) * kTile;
+  }
+}
+
+// pass 1: look every probe row up (as radix_probe_kernel does), keep its slot value, sum the output rows
+template <int MODE, int TB, int RPT>
+__global__ __launch_bounds__(TB) void radix_dup_count_kernel(RadixDupArgs a) {
+  constexpr int kTile = TB * RPT;
+  __shared__ unsigned long long s_sum[TB / 64], s_rows[TB / 64];
+  const int tid = threadIdx.x;
+  const uint32_t nsub = a.smask + 1;
+  int64_t lo, hi, step;
+  uint32_t part;
+  dup_tiles<MODE, kTile>(a, lo, hi, step, part);
+  unsigned long long out_rows = 0, seen = 0;
+  for (int64_t tbase = lo; tbase < hi; tbase += step) {
+    uint64_t k[RPT];
+    unsigned long long val[RPT];
+    bool look[RPT], inb[RPT];
+    const ulonglong2 *tb[RPT];
+    uint32_t s1[RPT], s2[RPT];
+    ulonglong2 rw[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int64_t r = tbase + static_cast<int64_t>(j) * TB + tid;
+      inb[j] = r < hi;
+      look[j] = false;
+      k[j] = 0, val[j] = 0;
+      if (inb[j]) {
+        if (MODE == 0) {
+          k[j] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(a.prow + r));
+          look[j] = true;
+        } else {
+          look[j] = key_pack(a.src.kp, r, k[j]);
+        }
+      }
+      if (look[j] && k[j] == kRadixEmpty) {
+        if (a.special->present != 0) val[j] = a.special->val;
+        look[j] = false;
+      }
+      tb[j] = a.table;
+      s1[j] = s2[j] = 0;
+      if (look[j]) {
+        const uint64_t h = fmix64(k[j]);
+        const uint32_t p = MODE == 0 ? part : rpart(h);
+        tb[j] = a.table + static_cast<int64_t>(p * nsub + rsub(h, a.smask)) * kRadixSlots;
+        uint32_t s[3];
+        rslots(h, s);
+        s1[j] = s[1], s2[j] = s[2];
+        rw[j] = tb[j][s[0]];
+      }
+    }
+#pragma unroll
+    for (int c = 1; c <= 3; c++) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (look[j]) {
+          if (rw[j].x == k[j]) {
+            val[j] = rw[j].y;
+            look[j] = false;
+          } else if (rw[j].x == kRadixEmpty || c == 3) {
+            look[j] = false;
+          } else {
+            rw[j] = tb[j][c == 1 ? s1[j] : s2[j]];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      if (!inb[j]) continue;
+      const int64_t r = tbase + static_cast<int64_t>(j) * TB + tid;
+      a.vals[r] = val[j];
+      const unsigned long long cnt = val[j] & 0xFFFFull;
+      out_rows += (a.left_outer && cnt == 0) ? 1ull : cnt;
+      seen++;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    out_rows += __shfl_xor(out_rows, d, 64);
+    seen += __shfl_xor(seen, d, 64);
+  }
+  if (lane_id() == 0) s_sum[tid >> 6] = out_rows, s_rows[tid >> 6] = seen;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long t0 = 0, t1 = 0;
+    for (int w = 0; w < TB / 64; w++) t0 += s_sum[w], t1 += s_rows[w];
+    if (t0) atomicAdd(&a.counters[0], t0);
+    if (t1) atomicAdd(&a.counters[1], t1);
+  }
+}
+
+// pass 2: every tile scans its rows' output counts, claims its output range with one atomicAdd and expands the rows
+// cooperatively -- output row o of the tile finds its probe row by binary search over the scanned counts in LDS, so the
+// output columns are written coalesced whatever the match counts are; build payloads come from the key's group in
+// pay_sorted (consecutive, and L2-resident under the partition-at-a-time mapping).
+template <int JT, int MODE, int TB, int RPT>
+__global__ __launch_bounds__(TB) void radix_dup_emit_kernel(RadixDupArgs a) {
+  constexpr int kTile = TB * RPT;
+  __shared__ uint32_t s_off[kTile + 1];
+  __shared__ unsigned long long s_key[kTile], s_pay[kTile], s_val[kTile];
+  __shared__ uint32_t s_wsum[TB / 64];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x;
+  int64_t lo, hi, step;
+  uint32_t part;
+  dup_tiles<MODE, kTile>(a, lo, hi, step, part);
+  for (int64_t tbase = lo; tbase < hi; tbase += step) {
+    uint32_t e[RPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {  // blocked: thread t owns rows t * RPT .. t * RPT + RPT - 1 of the tile
+      const int idx = tid * RPT + j;
+      const int64_t r = tbase + idx;
+      uint64_t k = 0, pay = 0;
+      unsigned long long v = 0;
+      e[j] = 0;
+      if (r < hi) {
+        bool keyed = true;
+        if (MODE == 0) {
+          const ull2 row = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(a.prow) + r);
+          k = row.x, pay = row.y;
+        } else {
+          keyed = key_pack(a.src.kp, r, k);
+          pay = a.src.pay ? rload(a.src.pay, r, a.src.pay_width) : static_cast<uint64_t>(r);
+        }
+        v = __builtin_nontemporal_load(a.vals + r);
+        const uint32_t cnt = static_cast<uint32_t>(v & 0xFFFFull);
+        e[j] = (JT == CRGPU_LEFT_OUTER && cnt == 0) ? 1u : cnt;
+        if (!keyed) v |= 1ull << 63;  // a row without a key (NULL / out of range): its key column is NULL in the output
+      }
+      s_key[idx] = k, s_pay[idx] = pay, s_val[idx] = v;
+      sum += e[j];
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t ex = incl - sum, total = 0;
+    for (int w = 0; w < TB / 64; w++) {
+      if (w < (tid >> 6)) ex += s_wsum[w];
+      total += s_wsum[w];
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      s_off[tid * RPT + j] = ex;
+      ex += e[j];
+    }
+    if (tid == 0) {
+      s_off[kTile] = total;
+      s_base = total ? atomicAdd(a.emit.out_count, static_cast<unsigned long long>(total)) : 0ull;
+    }
+    __syncthreads();
+    const unsigned long long obase = s_base;
+    for (uint32_t o = tid; o < total; o += TB) {
+      uint32_t idx = 0;
+#pragma unroll
+      for (uint32_t stp = kTile / 2; stp != 0; stp >>= 1)
+        if (s_off[idx + stp] <= o) idx += stp;  // the last row whose first output row is <= o owns o
+      const unsigned long long v = s_val[idx];
+      const bool found = (v & 0xFFFFull) != 0;
+      const unsigned long long bval = found ? a.pay_sorted[((v >> 16) & 0x7FFFFFFFFFFFull) + (o - s_off[idx])] : 0ull;
+      const int64_t pos = static_cast<int64_t>(obase + o);
+      for (int c = 0; c < a.emit.ncopy; c++) {
+        const RadixCopy cc = a.emit.copy[c];
+        uint64_t x;
+        uint32_t present = 1;
+        if (cc.side == R_KEY) {
+          x = s_key[idx];
+          present = (v >> 63) == 0;
+        } else if (cc.side == R_PROBE_PAY) {
+          x = s_pay[idx];
+        } else {  // build side: NULL when a LEFT OUTER row has no match (hashjoiner.go:671-682)
+          x = cc.side == R_BUILD_KEY ? s_key[idx] : bval;
+          present = found;
+        }
+        rstore(cc.dst, pos, cc.width, x);
+        if (cc.dst_valid) cc.dst_valid[pos] = static_cast<uint8_t>(present);
+      }
+      if (a.emit.pair_p != nullptr) a.emit.pair_p[pos] = static_cast<int32_t>(s_pay[idx]);
+      if (a.emit.pair_b != nullptr) a.emit.pair_b[pos] = found ? static_cast<int32_t>(bval) : -1;
+    }
+    __syncthreads();  // the LDS arrays are reused by the next tile
+  }
+}
+
 // ------------------------------------------------------------------ host side
 static void chunking(int64_t n, int *nchunks, int64_t *chunk_rows) {
   int64_t want = (n + 65535) / 65536;  // >= 64 rows per partition and chunk on average
@@ -737,6 +1061,135 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
     int64_t tiles = (n + kTile - 1) / kTile;
     int64_t cap = static_cast<int64_t>(num_cus()) * 4;
     CRGPU_TRY(launch_probe<2>(jt, a, static_cast<int>(tiles < cap ? tiles : cap)));
+  }
+  return CRGPU_OK;
+}
+
+crgpu_status radix_build_dup(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok) {
+  hipStream_t st = stream();
+  *ok = false;
+  t.dup = false;
+  bool split_ok = false;
+  CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap, 11, kRadixMaxSubBits));
+  if (!split_ok) return CRGPU_OK;  // heavily skewed keys: a sub-partition overflowed, the caller uses the chained table
+  const uint32_t nsub = 1u << t.sub_bits;
+  CRGPU_TRY(t.table.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSlots * 16));
+  CRGPU_TRY(t.pay_sorted.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSubCap * 8));
+  CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
+  CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
+  static bool attr_set = false;
+  if (!attr_set) {
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(kGroupLds)));
+    attr_set = true;
+  }
+  uint32_t overflow = 0;
+  {
+    ProfScope prof("radix_build_table");
+    hipLaunchKernelGGL(radix_group_kernel, dim3(kRadixP1 * nsub), dim3(512), kGroupLds, st, t.rows_b.as<ulonglong2>(),
+                       t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.pay_sorted.as<unsigned long long>(),
+                       t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (an unlucky hash): chained table
+  t.ready = true;
+  t.dup = true;
+  *ok = true;
+  return CRGPU_OK;
+}
+
+static constexpr int kDupTB = 512, kDupRPT = 4, kDupTile = kDupTB * kDupRPT;
+static void dup_args(RadixTable &t, const RadixSrc &src, int64_t n, int jt, bool partitioned, RadixDupArgs &a, int *grid) {
+  std::memset(&a, 0, sizeof(a));
+  a.src = src;
+  a.n = n;
+  a.table = t.table.as<ulonglong2>();
+  a.special = t.special.as<RadixSpecial>();
+  a.pay_sorted = t.pay_sorted.as<unsigned long long>();
+  a.vals = t.vals.as<unsigned long long>();
+  a.counters = t.counters.as<unsigned long long>();
+  a.smask = (1u << t.sub_bits) - 1;
+  a.left_outer = jt == CRGPU_LEFT_OUTER;
+  if (partitioned) {
+    a.prow = t.p_rows.as<ulonglong2>();
+    a.pstart = t.p_starts.as<uint32_t>();
+    a.pcount = t.p_totals.as<uint32_t>();
+    int64_t w = (n / kRadixP1 + kDupTile - 1) / kDupTile;
+    if (w < 1) w = 1;
+    if (w > kProbeWgPerPart) w = kProbeWgPerPart;
+    a.wg_per_part = static_cast<int32_t>(w);
+    *grid = kRadixP1 * static_cast<int>(w);
+  } else {
+    const int64_t tiles = (n + kDupTile - 1) / kDupTile;
+    const int64_t cap = static_cast<int64_t>(num_cus()) * 4;
+    *grid = static_cast<int>(tiles < cap ? tiles : cap);
+  }
+}
+
+crgpu_status radix_probe_dup_count(RadixTable &t, int jt, const RadixSrc &src, int64_t n, bool partitioned, uint64_t *out_rows) {
+  if (!t.ready || !t.dup) return fail(CRGPU_ERR_STATE, "radix probe: no duplicate-key table built");
+  *out_rows = 0;
+  if (n <= 0) return CRGPU_OK;
+  hipStream_t st = stream();
+  if (partitioned)
+    CRGPU_TRY(radix_partition(src, n, t.p_hist, t.p_totals, t.p_starts, t.p_rows, 0, "radix_probe_hist", "radix_probe_scatter"));
+  CRGPU_TRY(t.vals.ensure(static_cast<size_t>(n + 8 * kRadixP1) * 8));
+  CRGPU_TRY(t.counters.ensure(16));
+  CRGPU_HIP(hipMemsetAsync(t.counters.p, 0, 16, st));
+  RadixDupArgs a;
+  int grid;
+  dup_args(t, src, n, jt, partitioned, a, &grid);
+  {
+    ProfScope prof("join_probe");
+    if (partitioned) hipLaunchKernelGGL((radix_dup_count_kernel<0, kDupTB, kDupRPT>), dim3(grid), dim3(kDupTB), 0, st, a);
+    else hipLaunchKernelGGL((radix_dup_count_kernel<1, kDupTB, kDupRPT>), dim3(grid), dim3(kDupTB), 0, st, a);
+    CRGPU_HIP(hipGetLastError());
+  }
+  unsigned long long c[2] = {0, 0};
+  CRGPU_HIP(hipMemcpyAsync(c, t.counters.p, 16, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  *out_rows = c[0];
+  // the partition passes left the rows without a key (NULL / outside the build side's range) out: LEFT OUTER keeps them
+  if (partitioned && jt == CRGPU_LEFT_OUTER) *out_rows += static_cast<uint64_t>(n) - c[1];
+  return CRGPU_OK;
+}
+
+crgpu_status radix_probe_dup_emit(RadixTable &t, int jt, const RadixSrc &src, int64_t n, const RadixEmit &emit, bool partitioned) {
+  if (!t.ready || !t.dup) return fail(CRGPU_ERR_STATE, "radix probe: no duplicate-key table built");
+  if (n <= 0) return CRGPU_OK;
+  if (jt != CRGPU_INNER && jt != CRGPU_LEFT_OUTER) return fail(CRGPU_ERR_INVALID, "radix probe: the duplicate-key table serves INNER and LEFT OUTER joins");
+  hipStream_t st = stream();
+  RadixDupArgs a;
+  int grid;
+  dup_args(t, src, n, jt, partitioned, a, &grid);
+  a.emit = emit;
+  {
+    ProfScope prof("join_probe");
+    if (partitioned && jt == CRGPU_INNER) hipLaunchKernelGGL((radix_dup_emit_kernel<CRGPU_INNER, 0, kDupTB, kDupRPT>), dim3(grid), dim3(kDupTB), 0, st, a);
+    else if (partitioned) hipLaunchKernelGGL((radix_dup_emit_kernel<CRGPU_LEFT_OUTER, 0, kDupTB, kDupRPT>), dim3(grid), dim3(kDupTB), 0, st, a);
+    else if (jt == CRGPU_INNER) hipLaunchKernelGGL((radix_dup_emit_kernel<CRGPU_INNER, 1, kDupTB, kDupRPT>), dim3(grid), dim3(kDupTB), 0, st, a);
+    else hipLaunchKernelGGL((radix_dup_emit_kernel<CRGPU_LEFT_OUTER, 1, kDupTB, kDupRPT>), dim3(grid), dim3(kDupTB), 0, st, a);
+    CRGPU_HIP(hipGetLastError());
+  }
+  if (partitioned && jt == CRGPU_LEFT_OUTER) {  // the rows without a key, as unmatched (radix_probe_kernel's MODE 2 pass)
+    bool keyless = src.kp.n > 1;
+    for (int c = 0; c < src.kp.n; c++) keyless = keyless || src.kp.c[c].valid != nullptr;
+    if (keyless) {
+      RadixProbeArgs pa;
+      std::memset(&pa, 0, sizeof(pa));
+      pa.src = src;
+      pa.n = n;
+      pa.table = t.table.as<ulonglong2>();
+      pa.special = t.special.as<RadixSpecial>();
+      pa.smask = (1u << t.sub_bits) - 1;
+      pa.sub_bits = t.sub_bits;
+      pa.emit = emit;
+      const int64_t tiles = (n + kProbeTile - 1) / kProbeTile;
+      const int64_t cap = static_cast<int64_t>(num_cus()) * 4;
+      CRGPU_TRY(launch_probe<2>(jt, pa, static_cast<int>(tiles < cap ? tiles : cap)));
+    }
   }
   return CRGPU_OK;
 }

@@ -344,3 +344,98 @@ def test_join_two_col_keys_large_radix_checksums():
     assert np.array_equal(w_out[order], lw[~miss])
     assert np.array_equal(c_out[order], cost[pick][~miss])
     j.close()
+
+
+# ---------------------------------------------------------------------------
+# duplicate build keys on the radix path (radix_build_dup / radix_probe_dup_*, csrc/radix.hip): INNER and LEFT OUTER
+# over a non-distinct build side; the reference walks its Same chains (hashjoiner_tmpl.go:16-337)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER"])
+@pytest.mark.parametrize("shape", ["i64_cover", "nullable_rowid", "two_cols", "bytes_payload", "empty_marker_key", "f64_key"])
+def test_join_radix_duplicate_build_keys_vs_oracle(oracle, radix_env, jt, shape):
+    rng = np.random.default_rng(hash((jt, shape, "dup")) % 2**32)
+    nl, nr = 40_000, 12_000
+    leq = req = [0]
+    if shape == "i64_cover":
+        rk = rng.integers(0, 3000, nr, dtype=np.int64) - 500  # ~4 rows per key, some keys with many more below
+        rk[:300] = 77
+        right = [cd.Vec.from_numpy(cd.INT64, rk), cd.Vec.from_numpy(cd.INT64, np.arange(nr, dtype=np.int64) * 3 + 1)]
+        left = [cd.Vec.from_numpy(cd.INT64, rng.integers(-700, 3200, nl, dtype=np.int64)), cd.Vec.from_numpy(cd.INT64, np.arange(nl, dtype=np.int64))]
+    elif shape == "nullable_rowid":  # NULL keys on both sides, two build payload columns (row-id table + gathers)
+        right = [cd.Vec.from_numpy(cd.INT32, rng.integers(0, 2000, nr).astype(np.int32), rng.random(nr) > 0.05),
+                 cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(nr), rng.random(nr) > 0.1),
+                 cd.Vec.from_numpy(cd.INT16, rng.integers(-9, 9, nr).astype(np.int16))]
+        left = [cd.Vec.from_numpy(cd.INT16, rng.integers(0, 2500, nl).astype(np.int16), rng.random(nl) > 0.05),
+                cd.Vec.from_numpy(cd.BOOL, rng.integers(0, 2, nl).astype(np.uint8))]
+    elif shape == "two_cols":
+        leq = req = [0, 1]
+        right = [cd.Vec.from_numpy(cd.INT64, rng.integers(-40, 40, nr, dtype=np.int64)), cd.Vec.from_numpy(cd.INT32, rng.integers(0, 30, nr).astype(np.int32), rng.random(nr) > 0.02),
+                 cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(nr))]
+        left = [cd.Vec.from_numpy(cd.INT16, rng.integers(-50, 50, nl).astype(np.int16)), cd.Vec.from_numpy(cd.INT64, rng.integers(-5, 40, nl, dtype=np.int64), rng.random(nl) > 0.02),
+                cd.Vec.from_numpy(cd.INT64, np.arange(nl, dtype=np.int64))]
+    elif shape == "bytes_payload":
+        right = [cd.Vec.from_numpy(cd.INT64, rng.integers(0, 4000, nr, dtype=np.int64) * 977),
+                 cd.Vec.from_values(cd.BYTES, [None if i % 11 == 0 else b"r%d" % i * (1 + i % 4) for i in range(nr)])]
+        left = [cd.Vec.from_numpy(cd.INT64, rng.integers(0, 4400, nl, dtype=np.int64) * 977),
+                cd.Vec.from_values(cd.BYTES, [None if i % 13 == 0 else b"l%d" % i for i in range(nl)])]
+    elif shape == "empty_marker_key":  # -1 packs to the tables' EMPTY marker: it lives in the side slot, with its duplicates
+        rk = rng.integers(-3, 3, nr, dtype=np.int64)
+        right = [cd.Vec.from_numpy(cd.INT64, rk), cd.Vec.from_numpy(cd.INT64, np.arange(nr, dtype=np.int64))]
+        nl = 300
+        left = [cd.Vec.from_numpy(cd.INT64, rng.integers(-4, 4, nl, dtype=np.int64)), cd.Vec.from_numpy(cd.INT64, np.arange(nl, dtype=np.int64))]
+    else:
+        vals = np.array([0.0, np.nan, 1.5, -2.25, 1e300, 3.0, 4.0, 5.0])
+        right = [cd.Vec.from_numpy(cd.FLOAT64, rng.choice(vals, nr)), cd.Vec.from_numpy(cd.INT64, np.arange(nr, dtype=np.int64))]
+        nl = 200
+        left = [cd.Vec.from_numpy(cd.FLOAT64, rng.choice(np.concatenate([vals, np.array([-0.0, 7.0])]), nl)), cd.Vec.from_numpy(cd.INT64, np.arange(nl, dtype=np.int64))]
+    want = oracle.hash_join(H.JOIN_TYPE[jt], left, right, leq, req, False)
+    got_probe, got_right = G.gpu_join_vecs(jt, left, right, leq, req, False)
+    if any(v.type == cd.BYTES for v in want):
+        H.assert_same_multiset(H.vecs_to_tuples(got_probe), H.vecs_to_tuples(want), f"{jt} {shape} {radix_env}")
+    else:
+        assert np.array_equal(G.rows_as_sorted_array(got_probe), G.rows_as_sorted_array(want)), f"{jt} {shape} {radix_env}"
+    assert len(got_right[0]) == 0
+
+
+def test_join_radix_duplicates_skewed_key_falls_back(oracle, radix_env):
+    """One key with more rows than a sub-partition holds: the grouped table cannot be built, the chained table takes over."""
+    rng = np.random.default_rng(5)
+    rk = np.concatenate([np.full(6000, 7, dtype=np.int64), rng.integers(100, 400, 3000, dtype=np.int64)])
+    right = [cd.Vec.from_numpy(cd.INT64, rk), cd.Vec.from_numpy(cd.INT64, np.arange(len(rk), dtype=np.int64))]
+    left = [cd.Vec.from_numpy(cd.INT64, rng.integers(0, 420, 2000, dtype=np.int64)), cd.Vec.from_numpy(cd.INT64, np.arange(2000, dtype=np.int64))]
+    for jt in ("INNER", "LEFT_OUTER"):
+        want = oracle.hash_join(H.JOIN_TYPE[jt], left, right, [0], [0], False)
+        got_probe, _ = G.gpu_join_vecs(jt, left, right, [0], [0], False)
+        assert np.array_equal(G.rows_as_sorted_array(got_probe), G.rows_as_sorted_array(want)), jt
+
+
+def test_join_radix_duplicates_large_checksums():
+    """2^22 build rows (4 per key on average) x 2^23 probe rows through the grouped radix table at its real thresholds:
+    output row count and per-column checksums against numpy (sum over probe rows of the per-key aggregates)."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(21)
+    nb, npr, nkeys = 1 << 22, 1 << 23, 1 << 20
+    bk = rng.integers(0, nkeys, nb, dtype=np.int64) * 5 - 77
+    bv = np.arange(nb, dtype=np.int64)
+    pk = rng.integers(0, nkeys + nkeys // 4, npr, dtype=np.int64) * 5 - 77
+    pw = np.arange(npr, dtype=np.int64)
+    cnt = np.bincount((bk + 77) // 5, minlength=nkeys + nkeys // 4).astype(np.int64)
+    vsum = np.bincount((bk + 77) // 5, weights=bv.astype(np.float64), minlength=nkeys + nkeys // 4)
+    kidx = (pk + 77) // 5
+    for jt, name in ((0, "INNER"), (1, "LEFT_OUTER")):
+        j = dev.Join(jt, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], False, out_cols=[1, 3])
+        j.build([dev.upload(cd.Vec.from_numpy(cd.INT64, bk)), dev.upload(cd.Vec.from_numpy(cd.INT64, bv))], nb)
+        res = j.probe([dev.upload(cd.Vec.from_numpy(cd.INT64, pk)), dev.upload(cd.Vec.from_numpy(cd.INT64, pw))], npr)
+        want_rows = int(cnt[kidx].sum()) + (int((cnt[kidx] == 0).sum()) if jt == 1 else 0)
+        assert int(res.n) == want_rows, name
+        w_out, v_out = dev.result_to_vecs(res)
+        mult = np.maximum(cnt[kidx], 1) if jt == 1 else cnt[kidx]
+        assert int(w_out.data.sum()) == int((pw * mult).sum()), name
+        pres = v_out.present()
+        assert int(pres.sum()) == int(cnt[kidx].sum())
+        assert float(v_out.data[pres].astype(np.float64).sum()) == pytest.approx(float(vsum[kidx].sum()), rel=1e-12)
+        # every (w, v) pair is a real match: v's build key equals w's probe key
+        sample = rng.integers(0, int(res.n), 200_000)
+        sp = pres[sample]
+        assert np.array_equal(bk[v_out.data[sample][sp]], pk[w_out.data[sample][sp]])
+        j.close()
