@@ -98,7 +98,8 @@ def bench_build(lg, reps, dv, g):
 
 
 def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4, two_cols=False):
-    """The general (chained) join path: duplicate build keys, so the packed / radix tables do not apply.  INNER join,
+    """The general join path: duplicate build keys (radix_build_dup: rows grouped per sub-partition; the chained table only
+    takes over for heavily skewed keys and for the join types that track build matches).  INNER join,
     build keys drawn at random from nb/dup values (Poisson(dup) rows per key, `dup` on average); rows/s = (build + probe rows) / time for build + probe."""
     nb, npr = 1 << lg_b, 1 << lg_p
     bk = torch.randint(0, nb // dup, (nb,), generator=g, device=dv, dtype=torch.int64)
@@ -120,7 +121,8 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4, two_cols=False):
         j.build(build, nb)
         out_rows[0] = int(j.probe(probe, npr).n)
     dt = _timed(go, reps)
-    kern = _kernels(["join_build", "join_probe", "radix_build_hist", "radix_build_scatter", "radix_build_split", "radix_build_table"], reps)
+    kern = _kernels(["join_build", "join_probe", "radix_build_hist", "radix_build_scatter", "radix_build_split", "radix_build_table",
+                     "radix_probe_hist", "radix_probe_scatter"], reps)
     j.close()
     cpu = None
     if CPU_SAMPLE and not two_cols:
@@ -133,7 +135,7 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4, two_cols=False):
         cdt = time.perf_counter() - t0
         cpu = {"value": (sb + sp) / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
                "sample": f"{sb} build x {sp} probe rows of the same shape (keys folded to keep {dup} duplicates per key; oracle hashJoiner, 1 thread)"}
-    r = _line(f"general join (duplicate build keys, chained table{', two int64 key columns' if two_cols else ''}): 2^{lg_b} build (random keys, {dup} rows per key on average) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
+    r = _line(f"general join (duplicate build keys, grouped radix table{', two int64 key columns packed into one key word' if two_cols else ''}): 2^{lg_b} build (random keys, {dup} rows per key on average) x 2^{lg_p} probe, INNER, {out_rows[0]} output rows",
               nb + npr, dt, 16.0 * nb + 16.0 * npr + 16.0 * out_rows[0], kern, cpu)
     r["output_rows"] = out_rows[0]
     return r
