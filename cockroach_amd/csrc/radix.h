@@ -19,6 +19,7 @@ static constexpr int kRadixMaxSubBits = 6;   // level-2 sub-partitions per parti
 static constexpr int kRadixSlots = 3072;     // slots of one sub-partition's table (48 KiB, built in LDS)
 static constexpr int kRadixSubCap = 2560;    // rows one sub-partition may hold (load factor <= 0.83; ~0.67 typical)
 static constexpr unsigned long long kRadixEmpty = 0xFFFFFFFFFFFFFFFFull;
+static constexpr int kRadixBuckets = 1024;   // displacement buckets per sub-partition of a perfect-hash table (one byte each)
 static constexpr int kRadixMaxFused = 16;
 
 enum RadixSide : int32_t { R_KEY = 0, R_PROBE_PAY = 1, R_BUILD_VAL = 2, R_BUILD_KEY = 3 };
@@ -55,6 +56,8 @@ struct RadixSpecial {  // the one build key whose packed value equals kRadixEmpt
 
 struct RadixTable {
   bool ready = false;
+  bool chd = false;       // the tables are perfect-hash tables: disp holds one displacement byte per (sub-partition, bucket)
+  DevBuf disp;
   bool dup = false;       // built by radix_build_dup: a slot's value is {first grouped row << 16 | rows of the key}
   DevBuf pay_sorted;      // dup: the build payloads grouped by key, sub-partition by sub-partition
   DevBuf vals, counters;  // dup probe: every probe row's slot value (count pass -> emit pass); {output rows, rows seen}

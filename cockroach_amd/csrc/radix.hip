@@ -369,6 +369,244 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
   }
 }
 
+// ------------------------------------------------------------------ level 3, perfect-hash form
+// The probe kernel is bound by the number of divergent table reads it issues, and a cuckoo lookup costs
+// 1.5 of them on average.  A sub-partition's keys are known when its table is built, so the table can be a PERFECT
+// hash table (compress-hash-displace): the keys fall into kRadixBuckets buckets (~2 keys each); the buckets are
+// placed largest first, each one searching the displacement d in [0, 255] that sends all its keys to free slots,
+// slot = scale(a + d * b) with (a, b) two hash words of the key.  A lookup reads its bucket's displacement byte -- from
+// LDS in the partition-at-a-time probe, which stages its partition's displacement bytes (<= 64 KiB) once -- and then
+// exactly ONE table slot, hit or miss.  A bucket that finds no displacement raises `failed` and the build falls back
+// to the cuckoo kernel (needs a >= 256-try streak of collisions; not observed).
+__device__ __forceinline__ void chd_words(uint64_t h, uint32_t &bucket, uint32_t &a, uint32_t &b) {
+  const uint64_t g = fmix64(h + 0x9E3779B97F4A7C15ULL);
+  bucket = static_cast<uint32_t>(g) & (kRadixBuckets - 1);
+  a = static_cast<uint32_t>(h);
+  b = static_cast<uint32_t>(g >> 32) | 1u;
+}
+// The candidate slots of a key must look random in d: an arithmetic progression a + d * step (any step) visits only a
+// handful of slots for the few percent of steps close to a small fraction of 2^32, so the progression goes through a
+// multiply-xorshift mixer keyed by the key's second word.
+__device__ __forceinline__ uint32_t chd_slot(uint32_t a, uint32_t b, uint32_t d) {
+  uint32_t x = a + d * 0x9E3779B1u;
+  x ^= x >> 16;
+  x *= b;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return rscale(x);
+}
+
+// Displacement search of one bucket of S keys (S small and known at compile time: the keys' hash words stay in
+// registers and the S claims of a try are issued together, so a try costs one LDS round trip, not S dependent ones).
+template <int S>
+__device__ __forceinline__ uint32_t chd_place(uint32_t *tab, const unsigned long long *skey, const uint16_t *order, uint32_t st) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  constexpr int K = S == 1 ? 8 : (S == 2 ? 4 : 1);  // displacements looked at per LDS round trip before claiming one
+  uint32_t id[S], a[S], b[S];
+  unsigned long long key[S];
+  bool act[S];  // false: a duplicate of an earlier key of the bucket (first writer wins: it claims nothing)
+#pragma unroll
+  for (int t = 0; t < S; t++) {
+    id[t] = order[st + t];
+    key[t] = skey[id[t]];
+    uint32_t bb;
+    chd_words(fmix64(key[t]), bb, a[t], b[t]);
+    act[t] = true;
+#pragma unroll
+    for (int u = 0; u < t; u++) act[t] = act[t] && key[u] != key[t];
+  }
+#pragma nounroll
+  for (uint32_t d0 = 0; d0 < 256; d0 += K) {
+    uint32_t sl[K][S];
+    bool free_[K];
+#pragma unroll
+    for (int c = 0; c < K; c++)
+#pragma unroll
+      for (int t = 0; t < S; t++) sl[c][t] = chd_slot(a[t], b[t], d0 + c);
+    if (K > 1) {  // plain reads of all K x S candidate slots go out together; the claim below decides
+      uint32_t occ[K][S];
+#pragma unroll
+      for (int c = 0; c < K; c++)
+#pragma unroll
+        for (int t = 0; t < S; t++) occ[c][t] = tab[sl[c][t]];
+#pragma unroll
+      for (int c = 0; c < K; c++) {
+        free_[c] = true;
+#pragma unroll
+        for (int t = 0; t < S; t++) free_[c] = free_[c] && (!act[t] || occ[c][t] == kNone);
+      }
+    } else {
+      free_[0] = true;
+    }
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+      if (!free_[c]) continue;
+      uint32_t old[S];
+#pragma unroll
+      for (int t = 0; t < S; t++) old[t] = act[t] ? atomicCAS(&tab[sl[c][t]], kNone, id[t]) : kNone;
+      bool ok = true;
+#pragma unroll
+      for (int t = 0; t < S; t++) ok = ok && old[t] == kNone;
+      if (ok) return d0 + c;
+      if (S > 1) {
+#pragma unroll
+        for (int t = 0; t < S; t++)
+          if (act[t] && old[t] == kNone) atomicExch(&tab[sl[c][t]], kNone);  // release, try the next displacement
+      }
+    }
+  }
+  return 256;
+}
+
+static constexpr int kChdMaxBucket = 31;  // keys one bucket may hold (Poisson(2.5) over 2^26 buckets stays far below)
+__global__ __launch_bounds__(512) void radix_chd_table_kernel(const ulonglong2 *__restrict__ rows,
+                                                              const uint32_t *__restrict__ sub_count,
+                                                              ulonglong2 *__restrict__ table, uint8_t *__restrict__ disp,
+                                                              RadixSpecial *__restrict__ special, uint32_t *__restrict__ failed) {
+  constexpr int THREADS = 512;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  __shared__ unsigned long long skey[kRadixSubCap];  // 20 KiB
+  __shared__ uint32_t tab[kRadixSlots];              // 12 KiB: row id per slot
+  __shared__ uint32_t bcnt[kRadixBuckets];           // rows per bucket, then (start << 8 | rows)
+  __shared__ uint16_t order[kRadixSubCap];           // row ids bucket by bucket
+  __shared__ uint16_t rnk[kRadixSubCap];
+  __shared__ uint16_t bsorted[kRadixBuckets];        // bucket ids, largest bucket first
+  __shared__ uint8_t sdisp[kRadixBuckets];
+  __shared__ uint32_t s_wsum[THREADS / 64];
+  __shared__ uint32_t hsz[kChdMaxBucket + 2];        // buckets per size, then the fill cursor of a size in bsorted
+  __shared__ uint32_t hfirst[kChdMaxBucket + 2];     // first position of a size in bsorted; [kChdMaxBucket + 1] unused
+  const int q = blockIdx.x;
+  const int64_t base = static_cast<int64_t>(q) * kRadixSubCap;
+  uint32_t n = sub_count[q];
+  if (n > static_cast<uint32_t>(kRadixSubCap)) n = kRadixSubCap;  // overflow is reported by the split kernel
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) skey[i] = rows[base + i].x;
+  for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) tab[i] = kNone;
+  for (int i = threadIdx.x; i < kRadixBuckets; i += THREADS) bcnt[i] = 0, sdisp[i] = 0;
+  if (threadIdx.x < kChdMaxBucket + 2) hsz[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    const unsigned long long k = skey[i];
+    if (k == kRadixEmpty) {  // the one key equal to the empty marker lives beside the table
+      special->val = rows[base + i].y;
+      special->present = 1;
+      rnk[i] = 0xFFFF;
+      continue;
+    }
+    uint32_t bk, a, b;
+    chd_words(fmix64(k), bk, a, b);
+    rnk[i] = static_cast<uint16_t>(atomicAdd(&bcnt[bk], 1u));
+  }
+  __syncthreads();
+  {  // exclusive scan of the bucket sizes (2 per thread), kept as (start << 8 | size); histogram of the sizes
+    constexpr int PER = kRadixBuckets / THREADS;
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      c[t] = bcnt[threadIdx.x * PER + t];
+      sum += c[t];
+      atomicAdd(&hsz[c[t] > static_cast<uint32_t>(kChdMaxBucket) ? kChdMaxBucket + 1 : c[t]], 1u);
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum);
+    if (lane_id() == 63) s_wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t ex = incl - sum;
+    for (int w = 0; w < static_cast<int>(threadIdx.x >> 6); w++) ex += s_wsum[w];
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+      bcnt[threadIdx.x * PER + t] = (ex << 8) | (c[t] > 255u ? 255u : c[t]);
+      ex += c[t];
+    }
+  }
+  __syncthreads();
+  if (hsz[kChdMaxBucket + 1] != 0) {  // a bucket beyond what one thread places (uniform branch: LDS value after a barrier)
+    if (threadIdx.x == 0) atomicOr(failed, 4u);
+    return;
+  }
+  if (threadIdx.x == 0) {  // first position of every size in the largest-first order (32 values: serial is fine)
+    uint32_t pos = 0;
+    for (int sz = kChdMaxBucket; sz >= 0; sz--) {
+      const uint32_t c = hsz[sz];
+      hsz[sz] = pos;
+      hfirst[sz] = pos;
+      pos += c;
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    if (rnk[i] == 0xFFFF) continue;
+    uint32_t bk, a, b;
+    chd_words(fmix64(skey[i]), bk, a, b);
+    order[(bcnt[bk] >> 8) + rnk[i]] = static_cast<uint16_t>(i);
+  }
+  __syncthreads();
+  for (int bk = threadIdx.x; bk < kRadixBuckets; bk += THREADS) bsorted[atomicAdd(&hsz[bcnt[bk] & 255u], 1u)] = static_cast<uint16_t>(bk);
+  __syncthreads();
+  // Largest buckets first, one size class at a time (a large bucket needs a nearly empty table: the smaller ones must
+  // not get ahead of it); the buckets of one size search concurrently: claims are atomic and a failed attempt releases
+  // what it claimed, so a concurrent search only ever sees a slot as taken that may be free a moment later.
+  // A duplicate build key keeps its first claimant (first writer wins, as in the cuckoo table): equal keys share a
+  // bucket and every slot, so the later one finds its own key in the slot and lets it stand.
+  for (int size_i = kChdMaxBucket; size_i >= 1; size_i--) {
+    const uint32_t size = static_cast<uint32_t>(size_i);
+    const uint32_t first = hfirst[size], last = hfirst[size - 1];  // (uniform: written before the barriers above)
+    if (first == last) continue;
+    for (uint32_t pos = first + threadIdx.x; pos < last; pos += THREADS) {
+      const uint32_t bk = bsorted[pos];
+      const uint32_t st = bcnt[bk] >> 8;
+      {
+      uint32_t d = 0;
+      if (size == 1) d = chd_place<1>(tab, skey, order, st);
+      else if (size == 2) d = chd_place<2>(tab, skey, order, st);
+      else if (size == 3) d = chd_place<3>(tab, skey, order, st);
+      else if (size == 4) d = chd_place<4>(tab, skey, order, st);
+      else if (size == 5) d = chd_place<5>(tab, skey, order, st);
+      else if (size == 6) d = chd_place<6>(tab, skey, order, st);
+      else if (size == 7) d = chd_place<7>(tab, skey, order, st);
+      else if (size == 8) d = chd_place<8>(tab, skey, order, st);
+      else
+#pragma nounroll
+      for (; d < 256; d++) {
+        uint32_t claimed = 0;
+        bool okk = true;
+#pragma nounroll
+        for (uint32_t t = 0; t < size && okk; t++) {
+          const uint32_t id = order[st + t];
+          const unsigned long long k = skey[id];
+          uint32_t bb, a, b;
+          chd_words(fmix64(k), bb, a, b);
+          const uint32_t old = atomicCAS(&tab[chd_slot(a, b, d)], kNone, id);
+          if (old == kNone) claimed |= 1u << t;
+          else if (skey[old] != k) okk = false;
+        }
+        if (okk) break;
+#pragma nounroll
+        for (uint32_t t = 0; t < size; t++) {
+          if (!((claimed >> t) & 1u)) continue;
+          uint32_t bb, a, b;
+          chd_words(fmix64(skey[order[st + t]]), bb, a, b);
+          atomicExch(&tab[chd_slot(a, b, d)], kNone);  // release, try the next displacement
+        }
+      }
+      if (d == 256) {
+        if (atomicOr(failed, 2u) == 0u) {
+          uint32_t occ = 0;
+          for (int i = 0; i < kRadixSlots; i++) occ += tab[i] != kNone;
+          printf("[chd] q=%d bk=%u size=%u st=%u n=%u occupied=%u class=[%u,%u) keys %llx %llx\n", q, bk, size, st, n, occ, first, last,
+                 skey[order[st]], skey[order[st + size - 1]]);
+        }
+      } else sdisp[bk] = static_cast<uint8_t>(d);
+      }
+    }
+    __syncthreads();
+  }
+  ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
+  for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) {
+    const uint32_t id = tab[i];
+    dst[i] = id == kNone ? make_ulonglong2(kRadixEmpty, 0) : rows[base + id];
+  }
+  for (int i = threadIdx.x; i < kRadixBuckets; i += THREADS) disp[static_cast<int64_t>(q) * kRadixBuckets + i] = sdisp[i];
+}
+
 // ------------------------------------------------------------------ probe
 struct RadixProbeArgs {
   const ulonglong2 *prow;  // partitioned probe rows (MODE 0)
@@ -378,6 +616,7 @@ struct RadixProbeArgs {
   int64_t n;
   const ulonglong2 *table;
   const RadixSpecial *special;
+  const uint8_t *disp;  // perfect-hash tables: one displacement byte per (sub-partition, bucket)
   uint32_t smask;
   int32_t sub_bits;
   int32_t wg_per_part;
@@ -390,13 +629,14 @@ struct RadixProbeArgs {
 //         read from HBM once and then served by that XCD's L2);
 // MODE 1: direct lookups of unpartitioned probe rows (small probes);
 // MODE 2: only the rows whose key is NULL, as unmatched (LEFT OUTER / LEFT ANTI).
-template <int JT, int MODE, int TB, int RPT>
+template <int JT, int MODE, int TB, int RPT, bool CHD>
 __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
   constexpr int kWaves = TB / 64;
   constexpr int kTile = TB * RPT;
   __shared__ uint32_t s_cnt[RPT * kWaves];
   __shared__ uint32_t s_pre[RPT * kWaves];
   __shared__ unsigned long long s_base;
+  extern __shared__ __align__(16) uint8_t s_disp[];  // CHD, MODE 0: the partition's displacement bytes [nsub][kRadixBuckets]
   const int tid = threadIdx.x, wave = tid >> 6;
   const uint32_t nsub = a.smask + 1;
 
@@ -411,6 +651,12 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
     lo = pbeg + static_cast<int64_t>(slice) * kTile;
     hi = pbeg + a.pcount[part];
     step = static_cast<int64_t>(a.wg_per_part) * kTile;
+    if (CHD && lo < hi) {  // stage the partition's displacement bytes: every lookup below then costs ONE table read
+      const uint4 *src = reinterpret_cast<const uint4 *>(a.disp + static_cast<int64_t>(part) * nsub * kRadixBuckets);
+      uint4 *dst = reinterpret_cast<uint4 *>(s_disp);
+      for (uint32_t i = tid; i < nsub * (kRadixBuckets / 16); i += TB) dst[i] = src[i];
+      __syncthreads();
+    }
   } else {
     lo = static_cast<int64_t>(blockIdx.x) * kTile;
     hi = a.n;
@@ -444,7 +690,42 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
         pay[j] = a.src.pay ? rload(a.src.pay, r, a.src.pay_width) : static_cast<uint64_t>(r);
       }
     }
-    if (MODE != 2) {
+    if (MODE != 2 && CHD) {
+      // perfect-hash tables: the bucket's displacement byte (LDS in MODE 0), then exactly one slot read per row
+      ulonglong2 rw[RPT];
+      uint32_t db[RPT], sa[RPT], sb[RPT];
+      const ulonglong2 *tb[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (look[j] && k[j] == kRadixEmpty) {
+          found[j] = a.special->present != 0;
+          val[j] = a.special->val;
+          look[j] = false;
+        }
+        db[j] = 0, sa[j] = 0, sb[j] = 1;
+        tb[j] = a.table;
+        if (look[j]) {
+          const uint64_t h = fmix64(k[j]);
+          const uint32_t p = MODE == 0 ? part : rpart(h);
+          const uint32_t sub = rsub(h, a.smask);
+          uint32_t bk;
+          chd_words(h, bk, sa[j], sb[j]);
+          tb[j] = a.table + static_cast<int64_t>(p * nsub + sub) * kRadixSlots;
+          db[j] = MODE == 0 ? s_disp[sub * kRadixBuckets + bk]
+                            : a.disp[static_cast<int64_t>(p * nsub + sub) * kRadixBuckets + bk];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RPT; j++)
+        if (look[j]) rw[j] = tb[j][chd_slot(sa[j], sb[j], db[j])];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (look[j] && rw[j].x == k[j]) {
+          found[j] = true;
+          val[j] = rw[j].y;
+        }
+      }
+    } else if (MODE != 2) {
       // At most three dependent slot reads per row (3-way cuckoo).  Each stage is issued for all
       // rows of the lane before the next one resolves; only lanes that still need a slot take
       // part in a load (the cost of a divergent load is ~2 cycles per ACTIVE lane).  Everything
@@ -988,6 +1269,34 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
   CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
   uint32_t overflow = 0;
+  t.chd = false;
+  t.dup = false;
+  // The perfect-hash form takes 1.06 ms off the probe of config J (6.78 -> 5.72 ms: one slot read per row instead of 1.5)
+  // but its build costs 3.8 ms against the cuckoo kernel's 1.7 (size-ordered displacement searches are latency chains
+  // of LDS atomics), so it only pays when the probe side is >~ 14 x the build side: opt-in, CRGPU_RADIX_TABLE=chd.
+  const char *kind = std::getenv("CRGPU_RADIX_TABLE");
+  if (kind != nullptr && kind[0] == 'c' && kind[1] == 'h') {
+    CRGPU_TRY(t.disp.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixBuckets));
+    {
+      ProfScope prof("radix_build_table");
+      hipLaunchKernelGGL(radix_chd_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                         t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.disp.as<uint8_t>(),
+                         t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (!overflow) {
+      t.chd = true;
+      t.ready = true;
+      *ok = true;
+      return CRGPU_OK;
+    }
+    // a bucket found no displacement (or held too many keys): the cuckoo form below takes over
+    CRGPU_HIP(hipMemsetAsync(t.flag.p, 0, 4, st));
+    CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
+    overflow = 0;
+  }
   {
     ProfScope prof("radix_build_table");
     hipLaunchKernelGGL(radix_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
@@ -997,24 +1306,41 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   }
   CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
-  if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (>= 4 equal keys, or an unlucky hash): classic table
+  if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (an unlucky hash): classic table
   t.ready = true;
   *ok = true;
   return CRGPU_OK;
 }
 
-template <int MODE, int TB, int RPT>
-static crgpu_status launch_probe_cfg(int jt, const RadixProbeArgs &a, int grid) {
+template <int JT, int MODE, int TB, int RPT>
+static crgpu_status launch_probe_jt(const RadixProbeArgs &a, int grid) {
   hipStream_t st = stream();
-  switch (jt) {
-    case CRGPU_INNER: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_INNER, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
-    case CRGPU_LEFT_OUTER: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_LEFT_OUTER, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
-    case CRGPU_LEFT_SEMI: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_LEFT_SEMI, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
-    case CRGPU_LEFT_ANTI: hipLaunchKernelGGL((radix_probe_kernel<CRGPU_LEFT_ANTI, MODE, TB, RPT>), dim3(grid), dim3(TB), 0, st, a); break;
-    default: return fail(CRGPU_ERR_INVALID, "radix probe: join type not handled");
+  if (a.disp != nullptr) {  // perfect-hash tables; MODE 0 stages the partition's displacement bytes in dynamic LDS
+    const size_t lds = MODE == 0 ? static_cast<size_t>(a.smask + 1) * kRadixBuckets : 0;
+    if (lds > 48 * 1024) {
+      static bool attr_set = false;  // per instantiation
+      if (!attr_set) {
+        CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_probe_kernel<JT, MODE, TB, RPT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kRadixBuckets));
+        attr_set = true;
+      }
+    }
+    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, true>), dim3(grid), dim3(TB), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, false>), dim3(grid), dim3(TB), 0, st, a);
   }
   CRGPU_HIP(hipGetLastError());
   return CRGPU_OK;
+}
+template <int MODE, int TB, int RPT>
+static crgpu_status launch_probe_cfg(int jt, const RadixProbeArgs &a, int grid) {
+  switch (jt) {
+    case CRGPU_INNER: return launch_probe_jt<CRGPU_INNER, MODE, TB, RPT>(a, grid);
+    case CRGPU_LEFT_OUTER: return launch_probe_jt<CRGPU_LEFT_OUTER, MODE, TB, RPT>(a, grid);
+    case CRGPU_LEFT_SEMI: return launch_probe_jt<CRGPU_LEFT_SEMI, MODE, TB, RPT>(a, grid);
+    case CRGPU_LEFT_ANTI: return launch_probe_jt<CRGPU_LEFT_ANTI, MODE, TB, RPT>(a, grid);
+    default: return fail(CRGPU_ERR_INVALID, "radix probe: join type not handled");
+  }
 }
 // 512 threads x 4 rows per tile, 64 workgroups per partition: the best of the shapes measured
 // ((256,4) 7.5 ms, (1024,2) 7.3, (512,2) 6.9, (256,8) 8.3, (512,8) 8.6 against 6.6 on config J).
@@ -1034,6 +1360,7 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
   a.n = n;
   a.table = t.table.as<ulonglong2>();
   a.special = t.special.as<RadixSpecial>();
+  a.disp = t.chd ? t.disp.as<uint8_t>() : nullptr;
   a.smask = (1u << t.sub_bits) - 1;
   a.sub_bits = t.sub_bits;
   a.emit = emit;
@@ -1096,6 +1423,7 @@ crgpu_status radix_build_dup(RadixTable &t, const RadixSrc &src, int64_t n, bool
   if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (an unlucky hash): chained table
   t.ready = true;
   t.dup = true;
+  t.chd = false;
   *ok = true;
   return CRGPU_OK;
 }

@@ -166,10 +166,14 @@ def test_join_packed_covering_large():
 # radix-partitioned path (csrc/radix.hip): forced on for small inputs through the
 # CRGPU_RADIX_MIN_BUILD / CRGPU_RADIX_MIN_PROBE environment overrides
 # ---------------------------------------------------------------------------
-@pytest.fixture(params=["partitioned", "direct"])
+@pytest.fixture(params=["partitioned", "direct", "partitioned-chd", "direct-chd"])
 def radix_env(request, monkeypatch):
+    """partitioned / direct: the probe side is radix-partitioned first / looked up row by row; -chd: the sub-partition
+    tables are perfect-hash tables (CRGPU_RADIX_TABLE=chd, one slot read per lookup) instead of 3-way cuckoo tables."""
     monkeypatch.setenv("CRGPU_RADIX_MIN_BUILD", "1")
-    monkeypatch.setenv("CRGPU_RADIX_MIN_PROBE", "1" if request.param == "partitioned" else str(1 << 40))
+    monkeypatch.setenv("CRGPU_RADIX_MIN_PROBE", "1" if request.param.startswith("partitioned") else str(1 << 40))
+    if request.param.endswith("-chd"):
+        monkeypatch.setenv("CRGPU_RADIX_TABLE", "chd")
     return request.param
 
 
