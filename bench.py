@@ -36,7 +36,7 @@ def np_log(x):
     return math.log(x)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -47,10 +47,14 @@ def parse():
     ap.add_argument("--cpu-log2-build", type=int, default=25)
     ap.add_argument("--cpu-log2-probe", type=int, default=27)
     ap.add_argument("--no-other-paths", action="store_true", help="skip the aggregation / decode side measurements")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the N > 1 code path (hash repartition -> crgpu_exchange over RCCL -> local join, then the "
+                         "two-stage GROUP BY) even with one rank: a self-exchange through RCCL")
+    ap.add_argument("--log2-groupby", type=int, default=26, help="rows per GPU of the distributed GROUP BY leg (N > 1)")
     ap.add_argument("--variant", default="hit100", choices=["hit100", "hit50", "zipf", "null1"],
                     help="probe-key variants of config J (SURVEY.md 8(d)): 100%% hit (the headline), 50%% hit, "
                          "Zipf-like skew (theta=1), 1%% NULL probe keys")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(lb, lp):
@@ -109,14 +113,13 @@ def pmc_traffic(prof_name, streamed_read_bytes):
     return fetch * 1024.0 + streamed_read_bytes / 2.0 + write * 1024.0
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    args = parse(argv)
     import torch
     import torch.distributed as dist
     from cockroach_amd import coldata as cd
     from cockroach_amd import device as dev
     from cockroach_amd import _lib
-    from cockroach_amd.exchange import all_to_all_regions
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,6 +131,17 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     _lib.check(_lib.load().crgpu_init(local_rank))
+    distributed = world > 1 or args.force_distributed
+    xch = None
+    if distributed:
+        # the exchange lives behind the C-ABI (crgpu_exchange_*: RCCL directly); torch.distributed only carries the
+        # bootstrap id, the barriers and the timing reductions of this harness
+        uid = torch.zeros(dev.Exchange.ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid = torch.tensor(list(dev.Exchange.unique_id()), dtype=torch.uint8, device=device)
+        if world > 1:
+            dist.broadcast(uid, 0)
+        xch = dev.Exchange(bytes(uid.cpu().tolist()), world, rank)
 
     nb, npr = 1 << args.log2_build, 1 << args.log2_probe
     g = torch.Generator(device=device)
@@ -159,32 +173,31 @@ def main():
 
     I64 = cd.INT64
     join = dev.Join(0, [I64, I64], [I64, I64], [0], [0], True, out_cols=[1, 3])  # INNER, output (w, v)
-    part_b = part_p = None
-    if world > 1:
+    part_b = part_p = xch_b = xch_p = None
+    if distributed:
         part_b = dev.Partitioner([I64, I64], [0], world)
         part_p = dev.Partitioner([I64, I64], [0], world)
+        # one exchange handle per join input: a result is owned by its handle until that handle's next call
+        xch_b, xch_p = xch, dev.Exchange(_second_id(torch, dist, dev, world, rank, device), world, rank)
 
-    def exchange(part, cols_t, n):
-        """hash-repartition + all-to-all; returns received torch tensors (k, x)."""
+    def exchange(part, x, cols_t, n):
+        """hash-repartition (crgpu_dev_partition) + RCCL all-to-all (crgpu_exchange_all_to_all); device columns."""
         res, counts = part.partition([dev.from_torch(I64, t) for t in cols_t], n)
-        torch.cuda.synchronize()  # the regions were written on the library stream
-        srcs = [_wrap(torch, res.cols[c].data, n, device) for c in range(res.ncols)]
-        outs, rc = all_to_all_regions(srcs, counts.tolist())
-        return outs, int(sum(rc))
+        got, rc = x.all_to_all(dev.result_columns(res), counts)
+        return dev.result_columns(got), int(rc.sum())
 
     def step():
-        if world == 1:
-            b_cols, nbl = [bk, bv], nb
-            p_cols, npl = [pk, pw], npr
+        if not distributed:
+            b_cols = [dev.from_torch(I64, t) for t in (bk, bv)]
+            p_cols = [dev.from_torch(I64, t) for t in (pk, pw)]
+            nbl, npl = nb, npr
+            if pk_valid is not None:
+                p_cols[0] = dev.from_torch(I64, pk, valid=pk_valid)
         else:
-            b_cols, nbl = exchange(part_b, [bk, bv], nb)
-            p_cols, npl = exchange(part_p, [pk, pw], npr)
-            torch.cuda.synchronize()
-        join.build([dev.from_torch(I64, t) for t in b_cols], nbl)
-        pcols = [dev.from_torch(I64, t) for t in p_cols]
-        if pk_valid is not None and world == 1:
-            pcols[0] = dev.from_torch(I64, p_cols[0], valid=pk_valid)
-        res = join.probe(pcols, npl)
+            b_cols, nbl = exchange(part_b, xch_b, [bk, bv], nb)
+            p_cols, npl = exchange(part_p, xch_p, [pk, pw], npr)
+        join.build(b_cols, nbl)
+        res = join.probe(p_cols, npl)
         return res, b_cols, p_cols
 
     def barrier():
@@ -212,7 +225,7 @@ def main():
     v_out = _wrap(torch, res.cols[1].data, out_rows, device)
     ok = True
     if world == 1:
-        hit = pk < nb  # build keys are a permutation of [0, nb)
+        hit = pk < nb  # build keys are a permutation of [0, nb) (a self-exchange only reorders the rows)
         if args.variant == "null1":
             hit = hit & ~isnull
         ok = out_rows == int(hit.sum().item()) and int(v_out.sum().item()) == int(((pk * 3 + 1) * hit).sum().item()) \
@@ -231,7 +244,7 @@ def main():
     kern_rows = {"join_build": (nb, 16.0), "join_probe": (npr, 32.0),
                  "radix_build_hist": (nb, 8.0), "radix_build_scatter": (nb, 32.0), "radix_build_split": (nb, 32.0),
                  "radix_build_table": (nb, 40.0), "radix_probe_hist": (npr, 8.0), "radix_probe_scatter": (npr, 32.0),
-                 "partition": (nb + npr, 32.0)}
+                 "partition": (nb + npr, 32.0), "exchange": (nb + npr, 32.0)}
     kern = {}
     for name in kern_rows:
         ms, cnt = dev.prof_get(name)
@@ -273,16 +286,96 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2_build, args.cpu_log2_probe)
     join.close()
+    if distributed:
+        gb = distributed_group_by(args, torch, dist, dev, cd, _lib, xch_b, world, rank, device)
+        if rank == 0:
+            line["group_by"] = gb
     if rank == 0:
-        if world == 1 and not args.no_other_paths:
+        if world == 1 and not args.no_other_paths and not args.force_distributed:
             # the other rows of the hot path, measured in the same run (not part of `value`): DESIGN.md 4.3 / 4.4
             line["other_paths"] = other_paths(local_rank)
         print(json.dumps(line), flush=True)
+    for h in (part_b, part_p, xch_b, xch_p):
+        if h is not None:
+            h.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         sys.exit(3)
+    return line if rank == 0 else None
+
+
+def _second_id(torch, dist, dev, world, rank, device):
+    uid = torch.zeros(dev.Exchange.ID_BYTES, dtype=torch.uint8, device=device)
+    if rank == 0:
+        uid = torch.tensor(list(dev.Exchange.unique_id()), dtype=torch.uint8, device=device)
+    if world > 1:
+        dist.broadcast(uid, 0)
+    return bytes(uid.cpu().tolist())
+
+
+def distributed_group_by(args, torch, dist, dev, cd, _lib, xch, world, rank, device):
+    """BASELINE.json configs[4] shape on N GPUs: high-cardinality GROUP BY as the reference distributes it
+    (distsql_physical_planner.go:2790-2844, physicalplan/aggregator_funcs.go:83-306): local hash aggregation ->
+    BY_HASH repartition of the PARTIAL rows on the group key -> all-to-all -> final aggregation (COUNT_ROWS becomes a
+    final SUM_INT of the local counts).  Rows (k int64, x int64): every key appears 4 times, twice on this rank and
+    twice on the next one, so both stages have work.  Everything stays in HBM and goes through the C-ABI."""
+    import time
+    n = 1 << args.log2_groupby
+    g = torch.Generator(device=device)
+    g.manual_seed(77 + rank)
+    base = torch.arange(n // 4, device=device, dtype=torch.int64)
+    mult = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64: an odd multiplier, a bijection on the wrapped 64-bit ring
+    mine = (base * world + rank) * mult
+    nxt = (base * world + (rank + 1) % world) * mult
+    k = torch.cat([mine, mine, nxt, nxt])[torch.randperm(n, generator=g, device=device)]
+    x = torch.ones(n, device=device, dtype=torch.int64)
+    torch.cuda.synchronize()
+    I64 = cd.INT64
+    ANY, SUM_INT, COUNT_ROWS = 0, 11, 14
+    part = dev.Partitioner([I64, I64, I64], [0], world)
+
+    def once():
+        local = dev.Agg([I64, I64], [0], [(ANY, 0, -1), (SUM_INT, 1, -1), (COUNT_ROWS, -1, -1)])
+        local.consume([dev.from_torch(I64, k), dev.from_torch(I64, x)], n)
+        partial = dev.result_columns(local.finish())
+        regions, counts = part.partition(partial, partial[0].n)
+        got, rc = xch.all_to_all(dev.result_columns(regions), counts)
+        final = dev.Agg([I64, I64, I64], [0], [(ANY, 0, -1), (SUM_INT, 1, -1), (SUM_INT, 2, -1)])
+        rcols = dev.result_columns(got)
+        final.consume(rcols, int(rc.sum()))
+        out = dev.result_columns(final.finish())
+        groups = out[0].n
+        s = int(_wrap(torch, out[1].data_ptr, groups, device).sum().item()) if groups else 0
+        c = int(_wrap(torch, out[2].data_ptr, groups, device).sum().item()) if groups else 0
+        local.close()
+        final.close()
+        return groups, s, c
+
+    once()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        groups, s, c = once()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    tot = torch.tensor([float(groups), float(s), float(c), dt], device=device, dtype=torch.float64)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[3].item())
+    # every key occurs 4 times in the union of the ranks' inputs: n * world / 4 groups, sum(x) = count = n * world
+    ok = int(tot[0].item()) == n * world // 4 and int(tot[1].item()) == n * world and int(tot[2].item()) == n * world
+    part.close()
+    return {"case": f"two-stage GROUP BY: 2^{args.log2_groupby} rows (k int64, x int64) per GPU, each key 4x, SUM_INT + COUNT_ROWS",
+            "rows_per_s": n * world / dt, "ms": dt * 1e3, "groups": int(tot[0].item()), "result_check": "ok" if ok else "MISMATCH"}
 
 
 def other_paths(device_index):

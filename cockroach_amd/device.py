@@ -239,6 +239,43 @@ class Partitioner:
             pass
 
 
+class Exchange:
+    """crgpu_exchange handle: RCCL all-to-all of partitioned regions between the GPUs of a node."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * Exchange.ID_BYTES)()
+        _lib.check(_lib.load().crgpu_exchange_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, world: int, rank: int):
+        self.world, self.rank = world, rank
+        self._uid = (C.c_uint8 * Exchange.ID_BYTES)(*uid)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_exchange_create(self._uid, world, rank, C.byref(self.h)))
+
+    def all_to_all(self, cols, send_counts):
+        """cols: partitioned DeviceColumns; returns (DevResult of the received rows, recv_counts)."""
+        sc = (C.c_int64 * self.world)(*[int(v) for v in send_counts])
+        rc = (C.c_int64 * self.world)()
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_exchange_all_to_all(self.h, dcol_array(cols), len(cols), sc, C.byref(res), rc))
+        return res, np.array(list(rc), dtype=np.int64)
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_exchange_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 CMP = {"EQ": 0, "NE": 1, "LT": 2, "LE": 3, "GT": 4, "GE": 5}
 BIN = {"+": 0, "-": 1, "*": 2, "*(1-)": 3, "*(1+)": 4}
 

@@ -289,3 +289,42 @@ def distributed_agg(ex, types, group_cols, aggs, cols: List[TCol], group=None) -
     regions, counts = local_stage(ex, plan, types, group_cols, cols, world)
     received, _ = exchange_tcols(regions, counts, group)
     return final_stage(ex, plan, received)
+
+
+# ------------------------------------------------------------------------------------------------ device-resident form
+def distributed_agg_device(xch, types, group_cols, aggs, dcols, n) -> List[cd.Vec]:
+    """The same two-stage plan with every step behind the C-ABI and every intermediate in HBM: crgpu_dev_agg_* (local) ->
+    crgpu_dev_partition of the partial rows -> crgpu_exchange_all_to_all (RCCL) -> crgpu_dev_agg_* (final); only the
+    final groups of this rank come back to the host, where AVG is rendered.  `xch`: a device.Exchange; `dcols`: this
+    rank's input as device columns.  This is the form bench.py --gpus N and a Go host run; the TCol form above exists
+    for the gloo tests."""
+    from . import device as dev
+    plan = plan_stages(types, group_cols, aggs)
+    local = dev.Agg(types, group_cols, plan.local_aggs)
+    part = dev.Partitioner(plan.inter_types, plan.final_group_cols, xch.world)
+    final = dev.Agg(plan.inter_types, plan.final_group_cols, plan.final_aggs)
+    try:
+        if n:
+            local.consume(dcols, n)
+        partial = dev.result_columns(local.finish())
+        regions, counts = part.partition(partial, partial[0].n if partial else 0)
+        got, rc = xch.all_to_all(dev.result_columns(regions), counts)
+        m = int(rc.sum())
+        if m:
+            final.consume(dev.result_columns(got), m)
+        vecs = dev.result_to_vecs(final.finish())
+    finally:
+        local.close()
+        part.close()
+        final.close()
+    out = []
+    for r in plan.render:
+        if r[0] == "col":
+            out.append(vecs[r[1]])
+            continue
+        s, c = vecs[r[1]], vecs[r[2]]
+        cnt = c.data.astype(np.float64)
+        pres = s.present() & c.present() & (cnt != 0)
+        q = np.divide(s.data, cnt, out=np.zeros(len(s), dtype=np.float64), where=pres)
+        out.append(cd.Vec.from_numpy(cd.FLOAT64, q, pres))
+    return out

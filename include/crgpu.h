@@ -226,6 +226,27 @@ crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, i
                                  int64_t *counts_host);
 void crgpu_dev_partitioner_destroy(crgpu_partitioner *p);
 
+/* ---- exchange: the one collective on the data path.  Replaces the movement of routed batches between nodes --
+ * HashRouter.Run -> routerOutputOp -> colrpc.Outbox.Run (Arrow serialisation, gRPC FlowStream) -> colrpc.Inbox
+ * (sql/colflow/routers.go:592-715, sql/colflow/colrpc/outbox.go:153) -- between the GPUs of one node: after
+ * crgpu_dev_partition every rank holds one contiguous region per destination, and crgpu_exchange_all_to_all swaps
+ * the regions with RCCL over xGMI (an all-gather of the counts, then one grouped ncclSend/ncclRecv set per column).
+ * Bootstrap as RCCL does it: rank 0 calls crgpu_exchange_unique_id, the host ships the 128 bytes to the other ranks
+ * (the Go side already ships a FlowSpec to every node: sql/colflow/vectorized_flow.go:1137), every rank calls
+ * crgpu_exchange_create (collective).  The communicator lives on the device of the calling thread's library
+ * context (crgpu_init): one process per GPU, or one thread per GPU.
+ * all_to_all: `cols` are this rank's partitioned columns (rows grouped by destination in rank order, send_counts[p]
+ * rows for rank p -- exactly crgpu_dev_partition's result and counts); `out` = the rows received, grouped by source
+ * rank, recv_counts[p] from rank p (host arrays of `world` entries).  All families incl. BYTES and validity bitmaps;
+ * a column must carry a bitmap on every rank or on none.  Collective: every rank calls it with the same schema. */
+#define CRGPU_EXCHANGE_ID_BYTES 128
+typedef struct crgpu_exchange crgpu_exchange;
+crgpu_status crgpu_exchange_unique_id(uint8_t *id_out /* CRGPU_EXCHANGE_ID_BYTES */);
+crgpu_status crgpu_exchange_create(const uint8_t *id, int32_t world, int32_t rank, crgpu_exchange **out);
+crgpu_status crgpu_exchange_all_to_all(crgpu_exchange *x, const crgpu_dcol *cols, int32_t n_cols, const int64_t *send_counts,
+                                       crgpu_dev_result *out, int64_t *recv_counts);
+void crgpu_exchange_destroy(crgpu_exchange *x);
+
 /* ---- the one entry point that allocates nothing.  It has NO counterpart in the reference: it exists for callers
  * that cannot call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid allocation.
  * Same repartition as crgpu_dev_partition (same kernels, same destinations), without a handle: the spec travels in
