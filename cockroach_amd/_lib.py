@@ -145,6 +145,10 @@ SYMBOLS = [
     ("crgpu_agg_next_output", _I32, [_VP, C.POINTER(OutBatch)]),
     ("crgpu_agg_reset", _I32, [_VP]),
     ("crgpu_agg_free", None, [_VP]),
+    ("crgpu_agg_track_input", _I32, [_VP, _I32]),
+    ("crgpu_agg_export_buffered", _I32, [_VP, C.POINTER(OutBatch)]),
+    ("crgpu_agg_release_before_export", _I32, [_VP]),
+    ("crgpu_agg_release_after_export", _I32, [_VP]),
     ("crgpu_route_new", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _I32, C.POINTER(_VP)]),
     ("crgpu_route_partition", _I32, [_VP, C.POINTER(Batch)]),
     ("crgpu_route_finish", _I32, [_VP]),
@@ -156,6 +160,7 @@ SYMBOLS = [
     ("crgpu_distinct_next_output", _I32, [_VP, C.POINTER(OutBatch)]),
     ("crgpu_distinct_reset", _I32, [_VP]),
     ("crgpu_distinct_free", None, [_VP]),
+    ("crgpu_distinct_export_buffered", _I32, [_VP, C.POINTER(OutBatch)]),
 ]
 
 _lib = None

@@ -271,6 +271,22 @@ static crgpu_status emit_from_queue(std::deque<std::unique_ptr<HostResult>> &q, 
   return emit_rows(*q.front(), out, &emitted);
 }
 
+// dst ++= src (row-wise append of staged columns)
+static void append_cols(std::vector<HostCol> &dst, const std::vector<HostCol> &src) {
+  for (size_t c = 0; c < src.size(); c++) {
+    HostCol &d = dst[c];
+    const HostCol &s = src[c];
+    if (s.type == CRGPU_BYTES) {
+      const uint32_t base = static_cast<uint32_t>(d.data.size());
+      for (int64_t i = 1; i <= s.n; i++) d.offsets.push_back(base + s.offsets[i]);
+    }
+    d.data.insert(d.data.end(), s.data.begin(), s.data.end());
+    d.present.insert(d.present.end(), s.present.begin(), s.present.end());
+    d.any_null = d.any_null || s.any_null;
+    d.n += s.n;
+  }
+}
+
 static void init_cols(std::vector<HostCol> &cols, const std::vector<int> &types) {
   cols.resize(types.size());
   for (size_t i = 0; i < types.size(); i++) cols[i].init(types[i]);
@@ -463,6 +479,12 @@ struct crgpu_ha : crgpu::Shell {
   DevTable staged_dev;
   bool finished = false;
   std::deque<std::unique_ptr<HostResult>> outq;
+  // hashAggregator.inputTrackingState (hash_aggregator.go:138-153): when the planner wraps the aggregator in a disk
+  // spiller, every input tuple is kept so that ExportBuffered can replay the whole input to the disk-backed fallback
+  bool track = false;
+  std::vector<HostCol> tracked;
+  std::unique_ptr<HostResult> export_copy;
+  bool released = false;
 };
 
 extern "C" crgpu_status crgpu_agg_new(const crgpu_agg_spec *spec, crgpu_ha **out) {
@@ -489,6 +511,9 @@ extern "C" crgpu_status crgpu_agg_reset(crgpu_ha *h) {
   CRGPU_ENTER(h->inner);
   CRGPU_TRY(crgpu_dev_agg_reset(h->dev));
   clear_cols(h->stage);
+  clear_cols(h->tracked);
+  h->export_copy.reset();
+  h->released = false;
   h->outq.clear();
   h->finished = false;
   return CRGPU_OK;
@@ -497,9 +522,64 @@ extern "C" crgpu_status crgpu_agg_reset(crgpu_ha *h) {
 static crgpu_status ha_flush(crgpu_ha *h) {
   const int64_t n = h->stage.empty() ? 0 : h->stage[0].n;
   if (n == 0) return CRGPU_OK;
+  if (h->track) append_cols(h->tracked, h->stage);  // before the device call: a failing call (OOM) must not lose them
+  if (h->released) {
+    clear_cols(h->stage);
+    return fail(CRGPU_ERR_STATE, "crgpu_agg: the device state was released for export");
+  }
   CRGPU_TRY(upload_table(h->stage, h->staged_dev));
-  CRGPU_TRY(crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n));
-  clear_cols(h->stage);
+  const crgpu_status st = crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n);
+  clear_cols(h->stage);  // (tracked rows keep the batch when tracking is on)
+  return st;
+}
+
+// colexecop.BufferingInMemoryOperator for the aggregator (hash_aggregator.go:455-500)
+extern "C" crgpu_status crgpu_agg_track_input(crgpu_ha *h, int32_t on) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_track_input: null handle");
+  if (!h->stage.empty() && (h->stage[0].n > 0 || (!h->tracked.empty() && h->tracked[0].n > 0)))
+    return fail(CRGPU_ERR_STATE, "crgpu_agg_track_input: call before the first append");
+  h->track = on != 0;
+  if (h->track) init_cols(h->tracked, h->types);
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_agg_export_buffered(crgpu_ha *h, crgpu_out_batch *out) {
+  if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_export_buffered: null argument");
+  out->length = 0;
+  if (!h->track) return fail(CRGPU_ERR_STATE, "crgpu_agg_export_buffered: input tracking was not enabled (crgpu_agg_track_input)");
+  if (!h->export_copy) {
+    // everything consumed so far plus what is still staged: the whole input, in arrival order
+    if (!h->stage.empty() && h->stage[0].n > 0) {
+      append_cols(h->tracked, h->stage);
+      clear_cols(h->stage);
+    }
+    h->export_copy.reset(new HostResult());
+    h->export_copy->cols = std::move(h->tracked);
+    h->export_copy->n = h->export_copy->cols.empty() ? 0 : h->export_copy->cols[0].n;
+    h->export_copy->cursor = 0;
+    init_cols(h->tracked, h->types);
+  }
+  if (h->export_copy->cursor >= h->export_copy->n) return CRGPU_OK;  // zero-length batch: all tuples have been exported
+  bool emitted;
+  return emit_rows(*h->export_copy, out, &emitted);
+}
+
+extern "C" crgpu_status crgpu_agg_release_before_export(crgpu_ha *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_release_before_export: null handle");
+  CRGPU_ENTER(h->inner);
+  // the hash table and the accumulators go back to the pool; only the tracked input is kept (hash_aggregator.go:475-492)
+  CRGPU_TRY(crgpu_dev_agg_reset(h->dev));
+  h->staged_dev = DevTable();
+  h->outq.clear();
+  h->released = true;
+  return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_agg_release_after_export(crgpu_ha *h) {
+  if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_agg_release_after_export: null handle");
+  h->export_copy.reset();
+  clear_cols(h->tracked);
+  for (auto &c : h->tracked) { c.data.shrink_to_fit(); c.present.shrink_to_fit(); c.offsets.shrink_to_fit(); }
   return CRGPU_OK;
 }
 
@@ -627,6 +707,23 @@ extern "C" crgpu_status crgpu_distinct_next_output(crgpu_ud *h, crgpu_out_batch 
   while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
   // the operator streams (unordered_distinct.go:113-119): nothing queued => push what is staged through the device
   if (h->outq.empty()) CRGPU_TRY(ud_flush(h));
+  return emit_from_queue(h->outq, out);
+}
+
+// colexecop.BufferingInMemoryOperator for unordered DISTINCT (unordered_distinct.go:123-150): only the tuples of the last
+// input that are new and not yet emitted are "buffered" -- the hash table itself stays, because the external distinct
+// keeps filtering against it (unorderedDistinctFilterer) -- so ReleaseBeforeExport / ReleaseAfterExport are no-ops there
+// and have no entry point here.  What is staged is first pushed through the device, then the unemitted new tuples are
+// handed out in input order.
+extern "C" crgpu_status crgpu_distinct_export_buffered(crgpu_ud *h, crgpu_out_batch *out) {
+  if (h == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_distinct_export_buffered: null argument");
+  CRGPU_ENTER(h->inner);
+  out->length = 0;
+  while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
+  if (h->outq.empty()) {
+    const crgpu_status st = ud_flush(h);
+    if (st != CRGPU_OK && st != CRGPU_ERR_DUPLICATE) return st;
+  }
   return emit_from_queue(h->outq, out);
 }
 

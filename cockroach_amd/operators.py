@@ -259,9 +259,11 @@ AGG_OUTPUT_TYPE = {  # colexecagg.ProcessAggregations output types for the suppo
 class HashAggregator(Operator):
     """colexec.NewHashAggregator(args): aggs = [(func, col, filter_col)]."""
 
-    def __init__(self, types, group_cols, aggs, input: Operator, capacity=cd.BATCH_SIZE):
+    def __init__(self, types, group_cols, aggs, input: Operator, capacity=cd.BATCH_SIZE, track_input=False):
         self.lib = _lib.load()
         self.input = input
+        self.types = list(types)
+        self.capacity = capacity
         descs = (_lib.AggDesc * max(len(aggs), 1))()
         self.out_types = []
         for i, (f, c, fc) in enumerate(aggs):
@@ -271,7 +273,10 @@ class HashAggregator(Operator):
         spec = _lib.AggSpec(len(types), len(group_cols), self._keep[0], self._keep[1], len(aggs), 0, descs)
         self.h = C.c_void_p()
         _lib.check(self.lib.crgpu_agg_new(C.byref(spec), C.byref(self.h)))
+        if track_input:  # planned under a disk spiller: hashAggregator.inputTrackingState (hash_aggregator.go:138-153)
+            _lib.check(self.lib.crgpu_agg_track_input(self.h, 1))
         self.out = _OutBatch(self.out_types, capacity)
+        self._export = None
         self.state = "aggregating"
 
     def init(self):
@@ -288,6 +293,18 @@ class HashAggregator(Operator):
             _lib.check(self.lib.crgpu_agg_finish(self.h))
             self.state = "outputting"
         return self.out.call(self.lib.crgpu_agg_next_output, self.h)
+
+    def export_buffered(self):
+        """hashAggregator.ExportBuffered (hash_aggregator.go:455-471): the tracked input, one batch per call."""
+        if self._export is None:
+            self._export = _OutBatch(self.types, self.capacity)
+        return self._export.call(self.lib.crgpu_agg_export_buffered, self.h)
+
+    def release_before_export(self):
+        _lib.check(self.lib.crgpu_agg_release_before_export(self.h))
+
+    def release_after_export(self):
+        _lib.check(self.lib.crgpu_agg_release_after_export(self.h))
 
     def reset(self):
         _lib.check(self.lib.crgpu_agg_reset(self.h))
@@ -316,6 +333,7 @@ class UnorderedDistinct(Operator):
         _lib.check(self.lib.crgpu_distinct_new(self._keep[0], len(types), self._keep[1], len(distinct_cols),
                                                int(bool(nulls_are_distinct)), int(bool(error_on_dup)), C.byref(self.h)))
         self.out = _OutBatch(list(types), capacity)
+        self._export = _OutBatch(list(types), capacity)
         self.lookahead = max(1, lookahead)
         self.state = "reading"
 
@@ -341,6 +359,10 @@ class UnorderedDistinct(Operator):
             out = self.out.call(self._next_output, self.h)
             if out.length > 0 or self.state == "draining":
                 return out
+
+    def export_buffered(self):
+        """UnorderedDistinct.ExportBuffered (unordered_distinct.go:123-134): new tuples not emitted yet."""
+        return self._export.call(self.lib.crgpu_distinct_export_buffered, self.h)
 
     def _next_output(self, h, out):
         st = self.lib.crgpu_distinct_next_output(h, out)

@@ -431,6 +431,17 @@ crgpu_status crgpu_agg_finish(crgpu_ha *h); /* input exhausted */
 crgpu_status crgpu_agg_next_output(crgpu_ha *h, crgpu_out_batch *out);
 crgpu_status crgpu_agg_reset(crgpu_ha *h);
 void crgpu_agg_free(crgpu_ha *h);
+/* colexecop.BufferingInMemoryOperator for the aggregator (colexecop/operator.go:167-196; hashAggregator.ExportBuffered /
+ * ReleaseBeforeExport / ReleaseAfterExport, sql/colexec/hash_aggregator.go:455-500; asserted by the disk spiller at
+ * colbuilder/execplan.go:1135).  The reference keeps every input tuple in inputTrackingState when it is planned under a
+ * disk spiller (hash_aggregator.go:138-153, 221-231): crgpu_agg_track_input(h, 1), called before the first append,
+ * makes the shell keep the staged input on the host.  On CRGPU_ERR_OOM the Go shell calls release_before_export (device
+ * state back to the pool), then export_buffered until length == 0 (the whole input so far, in arrival order, including
+ * rows not yet pushed to the device), then release_after_export. */
+crgpu_status crgpu_agg_track_input(crgpu_ha *h, int32_t on);
+crgpu_status crgpu_agg_export_buffered(crgpu_ha *h, crgpu_out_batch *out);
+crgpu_status crgpu_agg_release_before_export(crgpu_ha *h);
+crgpu_status crgpu_agg_release_after_export(crgpu_ha *h);
 
 /* colflow.NewHashRouter + processNextBatch + routerOutputOp.Next
  * (sql/colflow/routers.go:490,683,238). */
@@ -454,6 +465,11 @@ crgpu_status crgpu_distinct_finish(crgpu_ud *h); /* input exhausted */
 crgpu_status crgpu_distinct_next_output(crgpu_ud *h, crgpu_out_batch *out);
 crgpu_status crgpu_distinct_reset(crgpu_ud *h);
 void crgpu_distinct_free(crgpu_ud *h);
+/* UnorderedDistinct.ExportBuffered (sql/colexec/unordered_distinct.go:123-134; asserted at colbuilder/execplan.go:1216):
+ * the new tuples of the input seen so far that were not emitted yet, in input order; length 0 when there are none.  The
+ * table of seen tuples stays (the external distinct filters against it), so ReleaseBeforeExport / ReleaseAfterExport
+ * are no-ops in the reference (:136-150) and the Go shell implements them empty. */
+crgpu_status crgpu_distinct_export_buffered(crgpu_ud *h, crgpu_out_batch *out);
 
 #ifdef __cplusplus
 }

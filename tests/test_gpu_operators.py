@@ -279,3 +279,90 @@ def test_unordered_distinct_random_vs_oracle(oracle):
     ud.init()
     ordered_equal(drain(ud), H.vecs_to_tuples(want), "random")
     ud.close()
+
+
+# ---------------------------------------------------------------- BufferingInMemoryOperator on the aggregator / DISTINCT
+def _export_all(op):
+    rows = []
+    for _ in range(100000):
+        b = op.export_buffered()
+        if b.length == 0:
+            return rows
+        rows += H.vecs_to_tuples(b.cols, b.length)
+    raise AssertionError("ExportBuffered did not terminate")
+
+
+def test_hash_aggregator_export_buffered(oracle):
+    """hash_aggregator.go:455-505 as the disk spiller drives it (disk_spiller.go:81-200): after some input the spiller
+    calls ReleaseBeforeExport, drains ExportBuffered into the disk-backed operator, then ReleaseAfterExport.  The
+    exported tuples are the whole input so far, in arrival order (selection vectors applied)."""
+    import ctypes as C
+    from cockroach_amd import _lib
+    rng = np.random.default_rng(21)
+    n = 9_000
+    g = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 50, n, dtype=np.int64), rng.random(n) > 0.05)
+    s = cd.Vec.from_values(cd.BYTES, [None if i % 13 == 0 else b"s%d" % i * (1 + i % 11) for i in range(n)])
+    x = cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(n))
+    cols, types = [g, s, x], [cd.INT64, cd.BYTES, cd.FLOAT64]
+    aggs = [(0, 0, -1), (10, 2, -1), (14, -1, -1)]
+    batches = make_batches(cols, 700, True, rng)
+    ha = ops.HashAggregator(types, [0], aggs, ops.BatchSource(batches, types), capacity=512, track_input=True)
+    ha.init()
+    fed = 0
+    for b in batches[:9]:  # part of the input: some of it already on the device, some still staged on the host
+        mb, _keep = ops._marshal_batch(b)
+        _lib.check(ha.lib.crgpu_agg_append(ha.h, C.byref(mb)))
+        fed += b.length
+    ha.release_before_export()
+    got = _export_all(ha)
+    assert got == H.vecs_to_tuples(cols)[:fed]
+    assert ha.export_buffered().length == 0  # "all tuples have been exported"
+    with pytest.raises(_lib.CrgpuError) as e:  # the device state is gone: only Reset brings the operator back
+        mb, _keep = ops._marshal_batch(batches[9])
+        _lib.check(ha.lib.crgpu_agg_append(ha.h, C.byref(mb)))
+        _lib.check(ha.lib.crgpu_agg_finish(ha.h))
+    assert e.value.code == _lib.ERR_STATE
+    ha.release_after_export()
+    ha.reset()
+    want = H.vecs_to_tuples(oracle.hash_agg(cols, [0], aggs))
+    H.assert_same_multiset(drain(ha), want, "after export + Reset")
+    # the whole input is still tracked after a complete run
+    assert _export_all(ha) == H.vecs_to_tuples(cols)
+    ha.close()
+    # without tracking the operator says so instead of handing out nothing
+    ha = ops.HashAggregator(types, [0], aggs, ops.BatchSource(batches, types))
+    with pytest.raises(_lib.CrgpuError) as e:
+        ha.export_buffered()
+    assert e.value.code == _lib.ERR_STATE
+    ha.close()
+
+
+def test_unordered_distinct_export_buffered(oracle):
+    """unordered_distinct.go:123-134: ExportBuffered hands out the new tuples of the input read so far that Next has
+    not returned yet; the table of seen tuples stays, so a later batch is still filtered against them."""
+    import ctypes as C
+    from cockroach_amd import _lib
+    rng = np.random.default_rng(22)
+    n = 6_000
+    k = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 900, n, dtype=np.int64), rng.random(n) > 0.05)
+    p = cd.Vec.from_values(cd.BYTES, [b"p%d" % i for i in range(n)])
+    cols, types = [k, p], [cd.INT64, cd.BYTES]
+    want, _ = oracle.unordered_distinct(cols, [0])
+    want = H.vecs_to_tuples(want)
+    batches = make_batches(cols, 500, True, rng)
+    ud = ops.UnorderedDistinct(types, [0], ops.BatchSource(batches, types), capacity=100)
+    ud.init()
+    for b in batches[:6]:
+        mb, _keep = ops._marshal_batch(b)
+        _lib.check(ud.lib.crgpu_distinct_append(ud.h, C.byref(mb)))
+    first = ud.out.call(ud._next_output, ud.h)  # one output batch through Next ...
+    got = H.vecs_to_tuples(first.cols, first.length) + _export_all(ud)  # ... the rest through ExportBuffered
+    want6, _ = oracle.unordered_distinct([v.slice(0, 3000) for v in cols], [0])
+    ordered_equal(got, H.vecs_to_tuples(want6), "first six batches")
+    for b in batches[6:]:
+        mb, _keep = ops._marshal_batch(b)
+        _lib.check(ud.lib.crgpu_distinct_append(ud.h, C.byref(mb)))
+    _lib.check(ud.lib.crgpu_distinct_finish(ud.h))
+    ud.state = "draining"
+    ordered_equal(got + drain(ud), want, "whole input")
+    ud.close()
