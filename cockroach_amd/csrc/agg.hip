@@ -66,8 +66,10 @@ static constexpr int kAccRows = CRGPU_ACC_ROWS;                     // rows per 
 
 enum AccKind : int32_t {
   ACC_COUNT_ROWS = 0, ACC_COUNT, ACC_SUM_F64, ACC_AVG_F64, ACC_SUM_I128, ACC_MIN_I64, ACC_MAX_I64, ACC_MIN_F64,
-  ACC_MAX_F64, ACC_BOOL_AND, ACC_BOOL_OR, ACC_ANY_KEY, ACC_ANY_ROW
+  ACC_MAX_F64, ACC_BOOL_AND, ACC_BOOL_OR, ACC_ANY_KEY, ACC_ANY_ROW,
+  ACC_MIN_BYTES, ACC_MAX_BYTES  // w0: best row of the current pass (~0: none), w1: 8-byte prefix of the best value, value in the any store
 };
+__host__ __device__ __forceinline__ bool is_minmax_bytes(int kind) { return kind == ACC_MIN_BYTES || kind == ACC_MAX_BYTES; }
 
 struct AggOpDev {
   int32_t kind;
@@ -596,7 +598,9 @@ __device__ __forceinline__ unsigned long long acc_init_w0(int kind) {
     case ACC_MAX_I64: return 0x8000000000000000ull;
     case ACC_MIN_F64: return ~0ull;
     case ACC_BOOL_AND: return 1ull;
-    case ACC_ANY_ROW: return ~0ull;
+    case ACC_ANY_ROW:
+    case ACC_MIN_BYTES:
+    case ACC_MAX_BYTES: return ~0ull;
     default: return 0ull;
   }
 }
@@ -1452,6 +1456,27 @@ __global__ __launch_bounds__(256) void agg_resolve_kernel(ResolveArgs a) {
   }
 }
 
+// MIN/MAX over BYTES (hash_min_max_agg.eg.go:247-356: bytes.Compare decides): the first 8 bytes of a value, big-endian and
+// zero-padded, order values the way bytes.Compare does whenever they differ (a strictly larger prefix means a strictly
+// larger value; equal prefixes decide nothing), so one 64-bit atomic min/max per row leaves only the rows that share the
+// best prefix for the full comparison.
+__device__ __forceinline__ unsigned long long bytes_prefix(const uint8_t *p, uint32_t len) {
+  unsigned long long v = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < 8; t++) v = (v << 8) | (t < len ? p[t] : 0u);
+  return v;
+}
+__device__ __forceinline__ unsigned long long bytes_prefix_of(const DCol &c, int64_t row) {
+  const uint32_t a0 = c.offsets[row];
+  return bytes_prefix(reinterpret_cast<const uint8_t *>(c.data) + a0, c.offsets[row + 1] - a0);
+}
+__device__ inline int bytes_compare(const uint8_t *x, uint32_t lx, const uint8_t *y, uint32_t ly) {
+  const uint32_t m = lx < ly ? lx : ly;
+  for (uint32_t t = 0; t < m; t++)
+    if (x[t] != y[t]) return x[t] < y[t] ? -1 : 1;
+  return lx < ly ? -1 : (lx > ly ? 1 : 0);
+}
+
 // ANY_NOT_NULL over a non-group column: store the value of `row` as group gid's value
 // (fixed-width: w1 word; BYTES: per-op append buffer)
 __device__ inline void any_store_value(const AggOpDev &op, int f, int64_t row, uint32_t gid, uint64_t *const *any_off,
@@ -1505,13 +1530,16 @@ __device__ inline void first_row_store(const AggOpDev &op, int f, int64_t row, u
       case ACC_BOOL_AND:
       case ACC_BOOL_OR: w0 = col_get_bool(op.col, row) ? 1ull : 0ull; seen = 1; break;
       case ACC_ANY_ROW: w0 = seq; break;
+      case ACC_MIN_BYTES:
+      case ACC_MAX_BYTES: seen = 1; break;  // the claimant's value becomes the stored one below; w0 stays "no candidate"
       default: break;
     }
   }
+  if (is_minmax_bytes(op.kind)) w1 = take ? bytes_prefix_of(op.col, row) : (op.kind == ACC_MIN_BYTES ? ~0ull : 0ull);
   op.w0[gid] = w0;
   if (op.w1 != nullptr) op.w1[gid] = w1;
   if (op.seen != nullptr) op.seen[gid] = seen;
-  if (op.kind == ACC_ANY_ROW) {
+  if (op.kind == ACC_ANY_ROW || is_minmax_bytes(op.kind)) {
     if (any_off[f] != nullptr) {
       any_off[f][gid] = 0;
       any_len[f][gid] = 0;
@@ -1700,6 +1728,67 @@ __global__ __launch_bounds__(256) void agg_any_fixup_kernel(AnyFixArgs a) {
   }
 }
 
+// MIN/MAX over BYTES, three passes over the rows of a round (the grid-wide order between them is the kernel boundary):
+//   phase 0: w1[gid] = min/max of the rows' 8-byte prefixes (it persists across chunks: it also is the stored value's);
+//   phase 1: the rows whose prefix equals w1[gid] elect the best row of this round with a CAS loop on w0[gid], comparing
+//            the full values of the contender and the holder (both rows of the current chunk, immutable);
+//   phase 2: the elected row compares itself with the group's stored value, replaces it when it is better (appending to
+//            the op's value buffer: a group appends at most once per round, a claimant once per group, so the bytes of
+//            the chunk bound what a chunk can append) and clears w0[gid] for the next round.
+__global__ __launch_bounds__(256) void agg_minmax_bytes_kernel(AnyFixArgs a, int phase) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.m; i += stride) {
+    uint32_t gid = a.out_gid[i];
+    if (gid == kGidDefer) continue;
+    if (gid & kGidSlotRef) gid = static_cast<uint32_t>(a.meta[gid & ~kGidSlotRef]);
+    const int64_t row = a.list != nullptr ? static_cast<int64_t>(a.list[i]) : i;
+    for (int f = 0; f < a.naggs; f++) {
+      const AggOpDev &op = a.ops[f];
+      if (!is_minmax_bytes(op.kind)) continue;
+      if (op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row))) continue;
+      if (col_is_null(op.col, row)) continue;
+      const bool is_min = op.kind == ACC_MIN_BYTES;
+      const uint8_t *base = reinterpret_cast<const uint8_t *>(op.col.data);
+      const uint32_t a0 = op.col.offsets[row], len = op.col.offsets[row + 1] - a0;
+      const unsigned long long pre = bytes_prefix(base + a0, len);
+      if (phase == 0) {
+        const unsigned long long cur = __hip_atomic_load(&op.w1[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (is_min ? pre < cur : pre > cur) {
+          if (is_min) atomicMin(&op.w1[gid], pre);
+          else atomicMax(&op.w1[gid], pre);
+        }
+        continue;
+      }
+      if (pre != op.w1[gid]) continue;  // (final since phase 0 ended)
+      if (phase == 1) {
+        unsigned long long cur = __hip_atomic_load(&op.w0[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (true) {
+          if (cur != ~0ull) {
+            const uint32_t b0 = op.col.offsets[cur], blen = op.col.offsets[cur + 1] - b0;
+            const int c = bytes_compare(base + a0, len, base + b0, blen);
+            if (!(is_min ? c < 0 : c > 0)) break;  // the holder is at least as good
+          }
+          const unsigned long long old = atomicCAS(&op.w0[gid], cur, static_cast<unsigned long long>(row));
+          if (old == cur) break;
+          cur = old;
+        }
+        continue;
+      }
+      if (op.w0[gid] != static_cast<unsigned long long>(row)) continue;
+      bool better = op.seen[gid] == 0;
+      if (!better) {
+        const int c = bytes_compare(base + a0, len, a.any_buf[f] + a.any_off[f][gid], a.any_len[f][gid]);
+        better = is_min ? c < 0 : c > 0;
+      }
+      if (better) {
+        any_store_value(op, f, row, gid, a.any_off, a.any_len, a.any_buf, a.any_tails);
+        op.seen[gid] = 1;
+      }
+      op.w0[gid] = ~0ull;
+    }
+  }
+}
+
 // finalisation: one output value per group (Flush, e.g. hash_sum_agg.eg.go:562-572); group g is row g
 struct FinalArgs {
   AggOpDev op;
@@ -1832,15 +1921,17 @@ struct AggOpHost {
   int lw0 = -1, lw1 = -1, lseen = -1;
   bool has_w0 = false, has_w1 = false, has_seen = false;
   DevBuf w0, w1, seen;
-  // BYTES value store for ACC_ANY_ROW
+  // BYTES value store for ACC_ANY_ROW and ACC_MIN_BYTES / ACC_MAX_BYTES
   DevBuf any_off, any_len, any_buf;
   uint64_t any_tail = 0;
+  bool uses_any_store() const { return (kind == ACC_ANY_ROW && in_type == CRGPU_BYTES) || is_minmax_bytes(kind); }
 };
 
 struct crgpu_agg : crgpu::Handle {
   std::vector<int> types, group_cols;
   std::vector<AggOpHost> ops;
   bool need_any_fix = false;
+  bool need_minmax_bytes = false;
   bool bytes_keys = false;
   int lds_words = 0, lds_seen = 0;  // planes of the LDS partial table
   int acc_words = 0;                // HBM atomics per row on the fallback path (cost model)
@@ -1937,7 +2028,7 @@ static crgpu_status ensure_groups(crgpu_agg *a, size_t need) {
     if (op.has_w0) CRGPU_TRY(op.w0.ensure(ncap * 8, true));
     if (op.has_w1) CRGPU_TRY(op.w1.ensure(ncap * 8, true));
     if (op.has_seen) CRGPU_TRY(op.seen.ensure(ncap, true));
-    if (op.kind == ACC_ANY_ROW && op.in_type == CRGPU_BYTES) {
+    if (op.uses_any_store()) {
       CRGPU_TRY(op.any_off.ensure(ncap * 8, true));
       CRGPU_TRY(op.any_len.ensure(ncap * 4, true));
     }
@@ -2074,8 +2165,11 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
         op.kind = ACC_SUM_I128; op.out_type = CRGPU_INT64; break;
       case CRGPU_MIN:
       case CRGPU_MAX:
-        if (t == CRGPU_BYTES) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: MIN/MAX over BYTES is planned on the CPU operator");
-        if (t == CRGPU_FLOAT64) op.kind = d.func == CRGPU_MIN ? ACC_MIN_F64 : ACC_MAX_F64;
+        if (t == CRGPU_BYTES) {
+          op.kind = d.func == CRGPU_MIN ? ACC_MIN_BYTES : ACC_MAX_BYTES;
+          a->need_any_fix = true;
+          a->need_minmax_bytes = true;
+        } else if (t == CRGPU_FLOAT64) op.kind = d.func == CRGPU_MIN ? ACC_MIN_F64 : ACC_MAX_F64;
         else op.kind = d.func == CRGPU_MIN ? ACC_MIN_I64 : ACC_MAX_I64;
         op.out_type = t; break;
       case CRGPU_BOOL_AND:
@@ -2095,8 +2189,8 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
     }
     // accumulator words: HBM arrays and planes of the LDS partial table
     op.has_w0 = op.kind != ACC_ANY_KEY;
-    op.has_w1 = op.kind == ACC_AVG_F64 || op.kind == ACC_SUM_I128 || op.kind == ACC_ANY_ROW;
-    op.has_seen = op.kind == ACC_SUM_F64 || op.kind == ACC_SUM_I128 || (op.kind >= ACC_MIN_I64 && op.kind <= ACC_BOOL_OR);
+    op.has_w1 = op.kind == ACC_AVG_F64 || op.kind == ACC_SUM_I128 || op.kind == ACC_ANY_ROW || is_minmax_bytes(op.kind);
+    op.has_seen = op.kind == ACC_SUM_F64 || op.kind == ACC_SUM_I128 || (op.kind >= ACC_MIN_I64 && op.kind <= ACC_BOOL_OR) || is_minmax_bytes(op.kind);
     if (op.has_w0) {
       op.lw0 = a->lds_words++;
       a->acc_words++;
@@ -2489,7 +2583,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
   }
   for (size_t f = 0; f < a->ops.size(); f++) {
     AggOpHost &op = a->ops[f];
-    if (op.kind != ACC_ANY_ROW || op.in_type != CRGPU_BYTES) continue;
+    if (!op.uses_any_store()) continue;
     const DCol &c = cols[op.col];
     uint32_t ends[1] = {0}, begins[1] = {0};
     CRGPU_HIP(hipMemcpyAsync(begins, c.offsets, 4, hipMemcpyDeviceToHost, st));
@@ -2627,6 +2721,10 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
         ProfScope prof("agg_any_fixup");
         hipLaunchKernelGGL(agg_any_fixup_kernel, dim3(grid_for(in.m, 256)), dim3(256), 0, st, fa);
         CRGPU_HIP(hipGetLastError());
+        if (a->need_minmax_bytes) {
+          for (int phase = 0; phase < 3; phase++) hipLaunchKernelGGL(agg_minmax_bytes_kernel, dim3(grid_for(in.m, 256)), dim3(256), 0, st, fa, phase);
+          CRGPU_HIP(hipGetLastError());
+        }
       }
     }
     CRGPU_HIP(hipStreamSynchronize(st));
@@ -2646,7 +2744,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     CRGPU_HIP(hipMemcpyAsync(any_tails.data(), a->any_tails_dev.p, any_tails.size() * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     for (size_t f = 0; f < a->ops.size(); f++)
-      if (a->ops[f].kind == ACC_ANY_ROW && a->ops[f].in_type == CRGPU_BYTES) a->ops[f].any_tail = any_tails[f];
+      if (a->ops[f].uses_any_store()) a->ops[f].any_tail = any_tails[f];
   }
   CRGPU_HIP(hipStreamSynchronize(st));  // `cols` descriptors and host temporaries are done
   a->new_ratio = static_cast<double>(a->ngroups - groups_before) / static_cast<double>(n);
@@ -2908,11 +3006,12 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
     CRGPU_TRY(o.valid.ensure(static_cast<size_t>((ng + 7) / 8 + 1)));
     if (op.out_type == CRGPU_BYTES) {
       // ANY_NOT_NULL over a BYTES group key or BYTES column
-      const bool any_row = op.kind == ACC_ANY_ROW;
-      const uint64_t *off = any_row ? op.any_off.as<uint64_t>() : a->ks[op.key_idx].b_off.as<uint64_t>();
-      const uint32_t *len = any_row ? op.any_len.as<uint32_t>() : a->ks[op.key_idx].b_len.as<uint32_t>();
-      const uint8_t *buf = any_row ? op.any_buf.as<uint8_t>() : a->ks[op.key_idx].b_buf.as<uint8_t>();
-      const uint8_t *pres = any_row ? nullptr : a->ks[op.key_idx].present.as<uint8_t>();
+      // ... or MIN / MAX over a BYTES column (present = a value was stored)
+      const bool any_row = op.kind == ACC_ANY_ROW, stored = any_row || is_minmax_bytes(op.kind);
+      const uint64_t *off = stored ? op.any_off.as<uint64_t>() : a->ks[op.key_idx].b_off.as<uint64_t>();
+      const uint32_t *len = stored ? op.any_len.as<uint32_t>() : a->ks[op.key_idx].b_len.as<uint32_t>();
+      const uint8_t *buf = stored ? op.any_buf.as<uint8_t>() : a->ks[op.key_idx].b_buf.as<uint8_t>();
+      const uint8_t *pres = any_row ? nullptr : (stored ? op.seen.as<uint8_t>() : a->ks[op.key_idx].present.as<uint8_t>());
       CRGPU_TRY(a->lens_tmp.ensure(static_cast<size_t>(ng > 0 ? ng : 1) * 4));
       CRGPU_TRY(a->offs64_tmp.ensure(static_cast<size_t>(ng + 1) * 8));
       CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(ng + 1) * 4));

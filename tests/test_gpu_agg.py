@@ -353,3 +353,48 @@ def test_agg_bulk_path_float_values_and_fallback(oracle):
     assert dev.prof_get("radix_build_split")[1] == 1 and dev.prof_get("agg_bulk")[1] == 0, "expected an abandoned bulk attempt"
     dev.prof_enable(False)
     assert np.array_equal(_canon(got2), _canon(oracle.hash_agg(cols2, [0], aggs)))
+
+
+@pytest.mark.parametrize("ngroups", [1, 7, 5000, 120_000])
+def test_agg_min_max_bytes_vs_oracle(oracle, ngroups):
+    """MIN / MAX over a BYTES column (hash_min_max_agg.eg.go:247-356: bytes.Compare; NULL inputs skipped, a group with no
+    non-NULL input yields NULL), with FILTER, beside other aggregates, over several chunks so that a later chunk has to
+    beat (or lose against) the stored value.  The values share long prefixes, differ only in length, contain 0x00 and
+    0xff bytes and the empty string: the 8-byte prefix test alone decides none of those.  The reference's case tables
+    hold no MIN/MAX over bytes (parity unpinned by literal vectors): the oracle restates bytes.Compare."""
+    rng = np.random.default_rng(1000 + ngroups)
+    n = 200_000
+    stems = [b"", b"\x00", b"\x00\x00", b"a", b"ab", b"abcdefgh", b"abcdefgh\x00", b"abcdefghi", b"abcdefgh\xff", b"\xff" * 9,
+             b"\xff" * 8, b"customer#00000", b"zz"]
+    pick = rng.integers(0, len(stems), size=n)
+    tail = rng.integers(0, 50, size=n)
+    vals = [None if rng.random() < 0.1 else stems[pick[i]] + (b"%d" % tail[i] if tail[i] % 3 else b"") for i in range(n)]
+    k = rng.integers(0, ngroups, size=n, dtype=np.int64)
+    if ngroups > 1:  # some groups see NULLs only
+        for i in np.nonzero(k == 1)[0]:
+            vals[i] = None
+    flt = rng.integers(0, 2, size=n).astype(np.uint8)
+    cols = [cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_values(cd.BYTES, vals),
+            cd.Vec.from_numpy(cd.BOOL, flt, rng.random(n) > 0.05), cd.Vec.from_numpy(cd.INT64, rng.integers(-9, 9, size=n, dtype=np.int64))]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1), (F["MIN"], 1, 2), (F["MAX"], 1, 2),
+            (F["SUM_INT"], 3, -1), (F["COUNT"], 1, -1)]
+    want = H.vecs_to_tuples(oracle.hash_agg(cols, [0], aggs))
+    for chunks in (1, 4):
+        got = H.vecs_to_tuples(G.gpu_agg(cols, [0], aggs, chunks=chunks))
+        H.assert_same_multiset(got, want, f"chunks={chunks}")
+
+
+def test_agg_min_max_bytes_group_key_and_empty(oracle):
+    """BYTES group key + MIN/MAX over another BYTES column; an empty input; all-NULL input."""
+    rng = np.random.default_rng(8)
+    n = 30_000
+    keys = [b"", b"k", b"key-%d"]
+    k = cd.Vec.from_values(cd.BYTES, [None if i % 97 == 0 else (keys[i % 3] % (i % 211) if i % 3 == 2 else keys[i % 3]) for i in range(n)])
+    v = cd.Vec.from_values(cd.BYTES, [bytes(rng.integers(0, 256, size=rng.integers(0, 20)).astype(np.uint8)) for _ in range(n)])
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    want = H.vecs_to_tuples(oracle.hash_agg([k, v], [0], aggs))
+    H.assert_same_multiset(H.vecs_to_tuples(G.gpu_agg([k, v], [0], aggs, chunks=3)), want)
+    empty = [cd.Vec.from_values(cd.BYTES, []), cd.Vec.from_values(cd.BYTES, [])]
+    assert len(G.gpu_agg(empty, [0], aggs)[0]) == 0
+    nulls = [cd.Vec.from_values(cd.BYTES, [b"g"] * 5), cd.Vec.from_values(cd.BYTES, [None] * 5)]
+    assert H.vecs_to_tuples(G.gpu_agg(nulls, [0], aggs)) == [(b"g", None, None, 5)]

@@ -195,7 +195,8 @@ def test_hash_aggregator_random_vs_oracle(oracle):
     x = cd.Vec.from_numpy(cd.INT64, rng.integers(-10**6, 10**6, n, dtype=np.int64), rng.random(n) > 0.1)
     f = cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(n), rng.random(n) > 0.1)
     cols = [g1, g2, x, f]
-    aggs = [(0, 0, -1), (0, 1, -1), (11, 2, -1), (10, 3, -1), (1, 3, -1), (7, 2, -1), (8, 3, -1), (5, 3, -1), (14, -1, -1)]
+    aggs = [(0, 0, -1), (0, 1, -1), (11, 2, -1), (10, 3, -1), (1, 3, -1), (7, 2, -1), (8, 3, -1), (5, 3, -1), (14, -1, -1),
+            (7, 1, -1), (8, 1, -1)]  # ... and MIN / MAX over the BYTES column
     want = H.vecs_to_tuples(oracle.hash_agg(cols, [0, 1], aggs))
     types = [v.type for v in cols]
     src = ops.BatchSource(make_batches(cols, 1024, True, rng), types)
