@@ -396,7 +396,7 @@ def other_paths(device_index):
         agg = load("bench_agg")
         out["hash_aggregation"] = [
             {k: r[k] for k in ("case", "rows", "groups", "ms", "rows_per_s", "frac_of_8TBps", "cpu_baseline")}
-            for r in agg.measure(27, ["q1", "q1full", "1024", str(1 << 20), str(1 << 27)], reps=3, cpu_sample=1 << 21, device_index=device_index)]
+            for r in agg.measure(27, ["q1", "q1full", "q1fused", "1024", str(1 << 20), str(1 << 27)], reps=3, cpu_sample=1 << 21, device_index=device_index)]
         dec = load("bench_decode").measure(1 << 21, 4, 10 << 20, device_index)
         out["kv_fetch_decode"] = {k: dec[k] for k in ("rows", "input_bytes", "wall_ms", "kv_walk_ms", "kv_decode_ms", "rows_per_s",
                                                       "input_GBps_wall", "q1_pipeline_decode_plus_agg_ms", "q1_pipeline_rows_per_s",

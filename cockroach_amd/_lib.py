@@ -48,6 +48,10 @@ class AggSpec(C.Structure):  # crgpu_agg_spec
                 ("aggs", C.POINTER(AggDesc))]
 
 
+class AggVcol(C.Structure):  # crgpu_agg_vcol
+    _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("cst", C.c_int64)]
+
+
 class FetchSpec(C.Structure):  # crgpu_fetch_spec
     _fields_ = [("key_prefix_len", C.c_int32), ("n_key_cols", C.c_int32), ("key_types", C.POINTER(C.c_int32)),
                 ("key_dirs", C.POINTER(C.c_int32)), ("key_out", C.POINTER(C.c_int32)), ("n_val_cols", C.c_int32),
@@ -102,6 +106,7 @@ SYMBOLS = [
     ("crgpu_dev_join_reset", _I32, [_VP]),
     ("crgpu_dev_join_destroy", None, [_VP]),
     ("crgpu_dev_agg_create", _I32, [C.POINTER(AggSpec), C.POINTER(_VP)]),
+    ("crgpu_dev_agg_create_fused", _I32, [C.POINTER(AggSpec), _I32, C.POINTER(AggVcol), C.POINTER(_VP)]),
     ("crgpu_dev_agg_consume", _I32, [_VP, C.POINTER(DCol), _I64]),
     ("crgpu_dev_agg_finish", _I32, [_VP, C.POINTER(DevResult)]),
     ("crgpu_dev_agg_reset", _I32, [_VP]),

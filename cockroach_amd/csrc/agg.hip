@@ -73,11 +73,16 @@ __host__ __device__ __forceinline__ bool is_minmax_bytes(int kind) { return kind
 
 struct AggOpDev {
   int32_t kind;
-  int32_t has_filter;
+  int32_t has_filter;        // 0 none, 1 `filter` is a BOOL column, 2 `filter` is an INT64 column compared with f_cst (f_cmp)
   int32_t key_idx;           // ACC_ANY_KEY: which group column
   int32_t lw0, lw1, lseen;   // LDS partial table: word / seen-byte plane numbers (-1: none)
   DCol col;
   DCol filter;
+  // computed input (crgpu_dev_agg_create_fused): value = e_op2(e_op1(col, col2), col3); e_op1 < 0: the plain column
+  int32_t e_op1, e_op2;
+  int32_t f_cmp, _pad;
+  long long f_cst;
+  DCol col2, col3;
   unsigned long long *w0;    // [gid]
   unsigned long long *w1;    // [gid] (AVG count, SUM_INT high word, ANY_NOT_NULL value)
   uint8_t *seen;             // [gid] a non-NULL input was accumulated
@@ -102,8 +107,8 @@ struct KeyStore {
 // per-op fields are scalar loads that no store or atomic of the kernel can invalidate.  (As loads from
 // a device array they were re-fetched per lane after every atomic: 68 vector loads per row.)
 struct OpK {
-  int8_t kind, in_type, has_filter, _p0;
-  int8_t lw0, lw1, lseen, _p1;  // LDS partial table: word / seen-byte plane numbers (-1: none)
+  int8_t kind, in_type, has_filter, vex;  // has_filter: 0 none, 1 BOOL column, 2 selection fsel - 1; vex: computed input vex - 1 (0: plain column)
+  int8_t lw0, lw1, lseen, fsel;  // LDS partial table: word / seen-byte plane numbers (-1: none)
   const void *data;             // input column
   const uint8_t *valid;
   const uint8_t *fdata;         // FILTER column (BOOL)
@@ -113,6 +118,46 @@ struct OpK {
   uint8_t *seen;
 };
 static constexpr int kMaxOpsPerLaunch = 32;  // 2 KiB of the 4 KiB kernel-argument budget
+
+// Computed inputs of the fused scan -> selection -> projection -> aggregation form (crgpu_dev_agg_create_fused; the
+// reference plans colexecsel / colexecproj operators in front of the aggregator, tpch_vec:20537-20546): evaluated in
+// the accumulate kernels' row loop, so neither the selection's BOOL column nor the projected FLOAT64 columns ever exist
+// in HBM.  value = op2(op1(x, y), z) with the roundings of two (three) separate projection operators; a NULL operand
+// makes the value NULL (proj_non_const_ops.eg.go:12253).  The tables travel in the kernel arguments like the ops.
+enum { EX_PLUS = 0, EX_MINUS, EX_MULT, EX_MULT_ONE_MINUS, EX_MULT_ONE_PLUS };  // = crgpu_dev_project_f64's op codes
+enum { SEL_EQ = 0, SEL_NE, SEL_LT, SEL_LE, SEL_GT, SEL_GE };                      // = crgpu_dev_select_i64_const's
+struct VExpr {
+  const double *x, *y, *z;
+  const uint8_t *vx, *vy, *vz;
+  int8_t op1, op2;  // op2 < 0: one operator only
+  int8_t _pad[6];
+};
+struct VSel {
+  const long long *data;
+  const uint8_t *valid;
+  long long cst;
+  int32_t cmp, _pad;
+};
+static constexpr int kMaxVex = 8, kMaxVsel = 4;
+__device__ __forceinline__ double ex_apply(int op, double a, double b) {
+  switch (op) {
+    case EX_PLUS: return __dadd_rn(a, b);
+    case EX_MINUS: return __dsub_rn(a, b);
+    case EX_MULT: return __dmul_rn(a, b);
+    case EX_MULT_ONE_MINUS: return __dmul_rn(a, __dsub_rn(1.0, b));
+    default: return __dmul_rn(a, __dadd_rn(1.0, b));
+  }
+}
+__device__ __forceinline__ bool sel_apply(int cmp, long long v, long long c) {
+  switch (cmp) {
+    case SEL_EQ: return v == c;
+    case SEL_NE: return v != c;
+    case SEL_LT: return v < c;
+    case SEL_LE: return v <= c;
+    case SEL_GT: return v > c;
+    default: return v >= c;
+  }
+}
 
 // total-order map for float MIN/MAX: NaN is the smallest value
 // (hash_min_max_agg.eg.go:966-981) -> 0; everything else order-preserving and > 0.
@@ -544,10 +589,38 @@ __device__ __forceinline__ void apply_rows_lds(const OpK &op, const unsigned lon
 // The same test-and-load for the kAccRows rows of a thread, written column-wise: every branch is on a
 // per-op (wave-uniform) property and every loop body is a plain load, so the compiler issues the loads of
 // all rows back to back and waits once (row-wise code waited after every single load).
+// FILTER given as a selection on an INT64 column: `col cmp constant`, a NULL never passes (selection_ops.eg.go:34971)
 template <int K>
+__device__ __forceinline__ void apply_vsel(const VSel &s, const int64_t (&row)[K], bool (&take)[K]) {
+  long long x[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) x[k] = s.data[row[k]];
+  if (s.valid != nullptr) {
+    uint8_t vb[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) vb[k] = s.valid[row[k] >> 3];
+#pragma unroll
+    for (int k = 0; k < K; k++) take[k] = take[k] && ((vb[k] >> (row[k] & 7)) & 1);
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) take[k] = take[k] && sel_apply(s.cmp, x[k], s.cst);
+}
+template <int K>
+__device__ __forceinline__ void and_valid(const uint8_t *valid, const int64_t (&row)[K], bool (&take)[K]) {
+  if (valid == nullptr) return;
+  uint8_t vb[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) vb[k] = valid[row[k] >> 3];
+#pragma unroll
+  for (int k = 0; k < K; k++) take[k] = take[k] && ((vb[k] >> (row[k] & 7)) & 1);
+}
+
+template <int K, bool VC = false>
 __device__ __forceinline__ void load_inputs(const OpK &op, const int64_t (&row)[K], bool (&take)[K],
-                                            unsigned long long (&v)[K]) {
-  if (op.has_filter) {  // aggregators_util.go:216-234
+                                            unsigned long long (&v)[K], const VExpr *vex = nullptr, const VSel *vsel = nullptr) {
+  if (VC && op.has_filter == 2) {
+    apply_vsel<K>(vsel[op.fsel - 1], row, take);
+  } else if (op.has_filter) {  // aggregators_util.go:216-234
     uint8_t fb[K];
 #pragma unroll
     for (int k = 0; k < K; k++) fb[k] = op.fdata[row[k]];
@@ -564,6 +637,28 @@ __device__ __forceinline__ void load_inputs(const OpK &op, const int64_t (&row)[
 #pragma unroll
   for (int k = 0; k < K; k++) v[k] = 0;
   if (op.kind == ACC_COUNT_ROWS) return;
+  if (VC && op.vex) {  // computed FLOAT64 input
+    const VExpr &e = vex[op.vex - 1];
+    double x[K], y[K], z[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) x[k] = e.x[row[k]];
+#pragma unroll
+    for (int k = 0; k < K; k++) y[k] = e.y[row[k]];
+    if (e.op2 >= 0) {
+#pragma unroll
+      for (int k = 0; k < K; k++) z[k] = e.z[row[k]];
+    }
+    and_valid<K>(e.vx, row, take);
+    and_valid<K>(e.vy, row, take);
+    if (e.op2 >= 0) and_valid<K>(e.vz, row, take);
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      double r = ex_apply(e.op1, x[k], y[k]);
+      if (e.op2 >= 0) r = ex_apply(e.op2, r, z[k]);
+      v[k] = static_cast<unsigned long long>(__double_as_longlong(r));
+    }
+    return;
+  }
   if (op.valid != nullptr) {  // aggregates skip NULL inputs
     uint8_t vb[K];
 #pragma unroll
@@ -773,14 +868,20 @@ struct AccArgs {
   // PK: LDS key table over the packed keys of all groups
   PackSpec pack;
   uint32_t C;                             // key table entries (power of two, >= 2 G)
-  uint32_t _pad2;
+  int32_t cf_kind;                        // a FILTER shared by every op of the launch, tested once per row: 0 none, 1 BOOL column, 2 vsel[0]
+  const uint8_t *cf_data, *cf_valid;
+  VExpr vex[kMaxVex];
+  VSel vsel[kMaxVsel];
 };
+static_assert(sizeof(AccArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
 // FUSED: hash -> index lookup -> accumulate (misses are listed);  !FUSED: the group comes from out_gid.
 // LDS: accumulate into the workgroup's partial table and merge it at the end;  !LDS: HBM atomics.
 // PK (with FUSED and LDS): the lookup runs against an LDS table of the groups' packed keys; the HBM index
 // only serves unpackable rows and rows whose group does not exist yet.
-template <bool FUSED, bool LDS, bool PK>
+// VC: computed inputs / selections / a common FILTER are in play (the plain form keeps them out of its instruction stream:
+// the pass is instruction-issue bound, and the extra uniform tests cost the Q1 shape 2.22 -> 2.60 ms).
+template <bool FUSED, bool LDS, bool PK, bool VC = false>
 __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
   extern __shared__ unsigned long long lds_words[];
   const uint32_t plane = (a.G + 1) * a.R;  // one plane per accumulator word: G groups + the trash group, R replicas each
@@ -914,6 +1015,19 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
     uint32_t gr[kAccRows];  // LDS: position of the row's group inside a plane
 #pragma unroll
     for (int k = 0; k < kAccRows; k++) gr[k] = LDS && gid[k] != kGidDefer ? gid[k] * a.R + rep : 0;
+    bool pass[kAccRows];
+#pragma unroll
+    for (int k = 0; k < kAccRows; k++) pass[k] = gid[k] != kGidDefer;
+    if (VC && a.cf_kind == 2) {
+      apply_vsel<kAccRows>(a.vsel[0], row, pass);
+    } else if (VC && a.cf_kind == 1) {
+      uint8_t fb[kAccRows];
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) fb[k] = a.cf_data[row[k]];
+      and_valid<kAccRows>(a.cf_valid, row, pass);
+#pragma unroll
+      for (int k = 0; k < kAccRows; k++) pass[k] = pass[k] && fb[k] != 0;
+    }
     // kOpGroup aggregations at a time: all their input loads are issued before the first atomic
     for (int f0 = 0; f0 < a.naggs; f0 += kOpGroup) {
       unsigned long long v[kOpGroup][kAccRows];
@@ -924,8 +1038,8 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
         if (f0 + u < a.naggs) {
           bool take[kAccRows];
 #pragma unroll
-          for (int k = 0; k < kAccRows; k++) take[k] = gid[k] != kGidDefer;
-          load_inputs<kAccRows>(a.ops[f0 + u], row, take, v[u]);
+          for (int k = 0; k < kAccRows; k++) take[k] = pass[k];
+          load_inputs<kAccRows, VC>(a.ops[f0 + u], row, take, v[u], a.vex, a.vsel);
 #pragma unroll
           for (int k = 0; k < kAccRows; k++) takem[u] |= (take[k] ? 1u : 0u) << k;
         }
@@ -1497,6 +1611,26 @@ __device__ inline void any_store_value(const AggOpDev &op, int f, int64_t row, u
   }
 }
 
+// FILTER / input of an aggregation in its device-array form (fixup kernels), computed inputs included
+__device__ inline bool op_filter_pass(const AggOpDev &op, int64_t row) {
+  if (op.has_filter == 0) return true;
+  if (col_is_null(op.filter, row)) return false;
+  if (op.has_filter == 2) return sel_apply(op.f_cmp, col_get_int(op.filter, row), op.f_cst);
+  return col_get_bool(op.filter, row);
+}
+__device__ inline bool op_input_null(const AggOpDev &op, int64_t row) {
+  if (col_is_null(op.col, row)) return true;
+  if (op.e_op1 < 0) return false;
+  return col_is_null(op.col2, row) || (op.e_op2 >= 0 && col_is_null(op.col3, row));
+}
+__device__ inline double op_input_f64(const AggOpDev &op, int64_t row) {
+  double r = col_get_f64(op.col, row);
+  if (op.e_op1 < 0) return r;
+  r = ex_apply(op.e_op1, r, col_get_f64(op.col2, row));
+  if (op.e_op2 >= 0) r = ex_apply(op.e_op2, r, col_get_f64(op.col3, row));
+  return r;
+}
+
 // A new group's accumulators after its first row (the claimant), written with plain stores:
 // nobody else touches the group before the fixup kernel has finished.
 __device__ inline void first_row_store(const AggOpDev &op, int f, int64_t row, unsigned long long seq, uint32_t gid,
@@ -1505,14 +1639,14 @@ __device__ inline void first_row_store(const AggOpDev &op, int f, int64_t row, u
   if (op.kind == ACC_ANY_KEY) return;
   unsigned long long w0 = acc_init_w0(op.kind), w1 = 0;
   uint8_t seen = 0;
-  bool take = !(op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row)));
-  if (take && op.kind != ACC_COUNT_ROWS && col_is_null(op.col, row)) take = false;
+  bool take = op_filter_pass(op, row);
+  if (take && op.kind != ACC_COUNT_ROWS && op_input_null(op, row)) take = false;
   if (take) {
     switch (op.kind) {
       case ACC_COUNT_ROWS:
       case ACC_COUNT: w0 = 1; break;
-      case ACC_SUM_F64: w0 = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); seen = 1; break;
-      case ACC_AVG_F64: w0 = static_cast<unsigned long long>(__double_as_longlong(col_get_f64(op.col, row))); w1 = 1; break;
+      case ACC_SUM_F64: w0 = static_cast<unsigned long long>(__double_as_longlong(op_input_f64(op, row))); seen = 1; break;
+      case ACC_AVG_F64: w0 = static_cast<unsigned long long>(__double_as_longlong(op_input_f64(op, row))); w1 = 1; break;
       case ACC_SUM_I128: {
         const long long v = col_get_int(op.col, row);
         w0 = static_cast<unsigned long long>(v);
@@ -1526,7 +1660,7 @@ __device__ inline void first_row_store(const AggOpDev &op, int f, int64_t row, u
         seen = 1;
         break;
       case ACC_MIN_F64:
-      case ACC_MAX_F64: w0 = f64_to_ordered(col_get_f64(op.col, row)); seen = 1; break;
+      case ACC_MAX_F64: w0 = f64_to_ordered(op_input_f64(op, row)); seen = 1; break;
       case ACC_BOOL_AND:
       case ACC_BOOL_OR: w0 = col_get_bool(op.col, row) ? 1ull : 0ull; seen = 1; break;
       case ACC_ANY_ROW: w0 = seq; break;
@@ -1745,7 +1879,7 @@ __global__ __launch_bounds__(256) void agg_minmax_bytes_kernel(AnyFixArgs a, int
     for (int f = 0; f < a.naggs; f++) {
       const AggOpDev &op = a.ops[f];
       if (!is_minmax_bytes(op.kind)) continue;
-      if (op.has_filter && (col_is_null(op.filter, row) || !col_get_bool(op.filter, row))) continue;
+      if (!op_filter_pass(op, row)) continue;
       if (col_is_null(op.col, row)) continue;
       const bool is_min = op.kind == ACC_MIN_BYTES;
       const uint8_t *base = reinterpret_cast<const uint8_t *>(op.col.data);
@@ -1918,6 +2052,11 @@ using namespace crgpu;
 // ====================================================================== handle
 struct AggOpHost {
   int func = 0, col = -1, filter_col = -1, kind = 0, key_idx = -1, in_type = 0, out_type = 0;
+  // computed input (crgpu_dev_agg_create_fused): value = op2(op1(col, col2), col3), physical ordinals; e_op1 < 0: plain column
+  int e_op1 = -1, e_op2 = -1, col2 = -1, col3 = -1;
+  // FILTER as a selection: filter_col is then an INT64 column compared with f_cst
+  int f_cmp = -1;
+  long long f_cst = 0;
   int lw0 = -1, lw1 = -1, lseen = -1;
   bool has_w0 = false, has_w1 = false, has_seen = false;
   DevBuf w0, w1, seen;
@@ -1932,6 +2071,8 @@ struct crgpu_agg : crgpu::Handle {
   std::vector<AggOpHost> ops;
   bool need_any_fix = false;
   bool need_minmax_bytes = false;
+  int n_phys = 0;            // columns consume() receives; the spec's further ordinals are computed columns
+  bool has_computed = false;
   bool bytes_keys = false;
   int lds_words = 0, lds_seen = 0;  // planes of the LDS partial table
   int acc_words = 0;                // HBM atomics per row on the fallback path (cost model)
@@ -1974,13 +2115,19 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
     AggOpDev &d = ops[f];
     std::memset(&d, 0, sizeof(d));
     d.kind = h.kind;
-    d.has_filter = h.filter_col >= 0;
+    d.has_filter = h.filter_col < 0 ? 0 : (h.f_cmp >= 0 ? 2 : 1);
+    d.f_cmp = h.f_cmp;
+    d.f_cst = h.f_cst;
+    d.e_op1 = h.e_op1;
+    d.e_op2 = h.e_op2;
     d.key_idx = h.key_idx;
     d.lw0 = h.lw0;
     d.lw1 = h.lw1;
     d.lseen = h.lseen;
     if (chunk != nullptr) {
       if (h.col >= 0) d.col = (*chunk)[h.col];
+      if (h.col2 >= 0) d.col2 = (*chunk)[h.col2];
+      if (h.col3 >= 0) d.col3 = (*chunk)[h.col3];
       if (h.filter_col >= 0) d.filter = (*chunk)[h.filter_col];
     } else if (h.col >= 0) {
       d.col.type = h.in_type;
@@ -2114,9 +2261,44 @@ static PackSpec plan_pack(const std::vector<int> &types, const std::vector<int> 
   return best;
 }
 
+static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtual, const crgpu_agg_vcol *vcols, crgpu_agg **out);
 extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_agg **out) {
+  return agg_create_impl(spec, 0, nullptr, out);
+}
+extern "C" crgpu_status crgpu_dev_agg_create_fused(const crgpu_agg_spec *spec, int32_t n_virtual, const crgpu_agg_vcol *vcols,
+                                                   crgpu_agg **out) {
+  if (n_virtual < 0 || (n_virtual > 0 && vcols == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: null computed columns");
+  return agg_create_impl(spec, n_virtual, vcols, out);
+}
+
+// A computed FLOAT64 column resolved to physical operands: value = op2(op1(x, y), z).
+struct ResolvedExpr {
+  int op1 = -1, op2 = -1, x = -1, y = -1, z = -1;
+};
+static crgpu_status resolve_vcol(const crgpu_agg_spec *spec, int n_phys, const crgpu_agg_vcol *vcols, int ord, ResolvedExpr *r) {
+  const crgpu_agg_vcol &v = vcols[ord - n_phys];
+  if (v.kind != CRGPU_VCOL_PROJECT_F64) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: aggregation input must be a projection");
+  if (v.op < EX_PLUS || v.op > EX_MULT_ONE_PLUS) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: unknown projection operator");
+  if (v.b < 0 || v.b >= n_phys || spec->types[v.b] != CRGPU_FLOAT64)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: the right operand of a projection must be a FLOAT64 input column");
+  if (v.a < 0 || v.a >= ord) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: operand ordinal out of range (a computed column may use earlier ones)");
+  if (v.a < n_phys) {
+    if (spec->types[v.a] != CRGPU_FLOAT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: FLOAT64 operands only");
+    r->op1 = v.op, r->x = v.a, r->y = v.b;
+    return CRGPU_OK;
+  }
+  ResolvedExpr inner;
+  CRGPU_TRY(resolve_vcol(spec, n_phys, vcols, v.a, &inner));
+  if (inner.op2 >= 0) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: at most two chained projections per aggregation input");
+  r->op1 = inner.op1, r->x = inner.x, r->y = inner.y, r->op2 = v.op, r->z = v.b;
+  return CRGPU_OK;
+}
+
+static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtual, const crgpu_agg_vcol *vcols, crgpu_agg **out) {
   CRGPU_TRY(ensure_init());
   if (spec == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: null argument");
+  if (n_virtual > spec->n_cols) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: more computed columns than columns");
+  const int n_phys = spec->n_cols - n_virtual;
   if (spec->n_cols < 0 || spec->n_cols > kMaxCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: column count out of range");
   if (spec->n_group < 0 || spec->n_group > kMaxKeyCols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: at most 8 grouping columns");
   if (spec->n_aggs < 1 || spec->n_aggs > kMaxAggs) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: between 1 and 64 aggregations");
@@ -2130,7 +2312,16 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
     if (!valid_type(spec->types[i])) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: unsupported column type");
     a->types.push_back(spec->types[i]);
   }
+  a->n_phys = n_phys;
+  a->has_computed = n_virtual > 0;
+  for (int i = 0; i < n_virtual; i++) {
+    const int want = vcols[i].kind == CRGPU_VCOL_SELECT_I64_CONST ? CRGPU_BOOL : CRGPU_FLOAT64;
+    if (vcols[i].kind != CRGPU_VCOL_SELECT_I64_CONST && vcols[i].kind != CRGPU_VCOL_PROJECT_F64)
+      return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: unknown computed column kind");
+    if (a->types[n_phys + i] != want) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: a selection is a BOOL column, a projection a FLOAT64 column");
+  }
   for (int i = 0; i < spec->n_group; i++) {
+    if (spec->group_cols[i] >= n_phys && spec->group_cols[i] < spec->n_cols) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: grouping by a computed column");
     if (spec->group_cols[i] < 0 || spec->group_cols[i] >= spec->n_cols) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: grouping column ordinal out of range");
     a->group_cols.push_back(spec->group_cols[i]);
     if (a->types[spec->group_cols[i]] == CRGPU_BYTES) a->bytes_keys = true;
@@ -2151,6 +2342,22 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
       return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: aggregation column ordinal out of range");
     const int t = d.func == CRGPU_COUNT_ROWS ? -1 : a->types[d.col];
     op.in_type = t;
+    if (d.filter_col >= n_phys) {  // FILTER = a computed selection: test the INT64 column itself
+      const crgpu_agg_vcol &v = vcols[d.filter_col - n_phys];
+      if (v.kind != CRGPU_VCOL_SELECT_I64_CONST) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: FILTER must be a selection");
+      if (v.op < SEL_EQ || v.op > SEL_GE) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: unknown comparison");
+      if (v.a < 0 || v.a >= n_phys || a->types[v.a] != CRGPU_INT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: selections compare an INT64 input column with a constant");
+      op.filter_col = v.a;
+      op.f_cmp = v.op;
+      op.f_cst = v.cst;
+    }
+    if (d.func != CRGPU_COUNT_ROWS && d.col >= n_phys) {  // computed input
+      if (d.func != CRGPU_SUM && d.func != CRGPU_AVG && d.func != CRGPU_MIN && d.func != CRGPU_MAX && d.func != CRGPU_COUNT)
+        return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: SUM / AVG / MIN / MAX / COUNT over computed columns");
+      ResolvedExpr r;
+      CRGPU_TRY(resolve_vcol(spec, n_phys, vcols, d.col, &r));
+      op.col = r.x, op.col2 = r.y, op.col3 = r.z, op.e_op1 = r.op1, op.e_op2 = r.op2;
+    }
     switch (d.func) {
       case CRGPU_COUNT_ROWS: op.kind = ACC_COUNT_ROWS; op.out_type = CRGPU_INT64; op.col = -1; break;
       case CRGPU_COUNT: op.kind = ACC_COUNT; op.out_type = CRGPU_INT64; break;
@@ -2218,6 +2425,12 @@ extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_a
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
@@ -2311,7 +2524,7 @@ static AccPlan plan_accumulate(const crgpu_agg *a, int64_t ngroups, int64_t m, b
     // moving a row costs ~(8 + 8 per value column) bytes written and read again; an HBM atomic costs 1/24 ns
     const double move_cost = (16.0 + 16.0 * static_cast<double>(cols.size())) / 3e12;
     const double atomic_cost = static_cast<double>(a->acc_words > 0 ? a->acc_words : 1) / 24e9;
-    if (!fused_only_lds && !a->need_any_fix && m >= (int64_t(1) << 18) && P <= kMaxParts && nops <= kMaxOpsPerLaunch &&
+    if (!fused_only_lds && !a->need_any_fix && !a->has_computed && m >= (int64_t(1) << 18) && P <= kMaxParts && nops <= kMaxOpsPerLaunch &&
         static_cast<int>(cols.size()) <= kMaxPartCols && move_cost < atomic_cost) {
       p.part = true;
       p.shift = shift;
@@ -2368,13 +2581,38 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
   }
   // the op descriptors travel in the kernel arguments, kMaxOpsPerLaunch at a time (one launch in practice)
   std::vector<OpK> ops;
+  // a FILTER that every aggregation of the pass shares is tested once per row, not once per aggregation
+  bool common_filter = true;
+  int cf_col = -2, cf_cmp = -2;
+  long long cf_cst = 0;
+  for (const AggOpHost &h : a->ops) {
+    if (h.kind == ACC_ANY_KEY) continue;
+    if (cf_col == -2) cf_col = h.filter_col, cf_cmp = h.f_cmp, cf_cst = h.f_cst;
+    common_filter = common_filter && h.filter_col == cf_col && h.f_cmp == cf_cmp && h.f_cst == cf_cst;
+  }
+  common_filter = common_filter && cf_col >= 0;
+  int nvex = 0, nvsel = 0;
+  if (common_filter) {
+    const DCol &fc = (*in.cols)[cf_col];
+    if (cf_cmp >= 0) {
+      args.cf_kind = 2;
+      args.vsel[0].data = static_cast<const long long *>(fc.data);
+      args.vsel[0].valid = fc.valid;
+      args.vsel[0].cst = cf_cst;
+      args.vsel[0].cmp = cf_cmp;
+      nvsel = 1;
+    } else {
+      args.cf_kind = 1;
+      args.cf_data = static_cast<const uint8_t *>(fc.data);
+      args.cf_valid = fc.valid;
+    }
+  }
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
     OpK k;
     std::memset(&k, 0, sizeof(k));
     k.kind = static_cast<int8_t>(h.kind);
     k.in_type = static_cast<int8_t>(h.in_type);
-    k.has_filter = h.filter_col >= 0;
     k.lw0 = static_cast<int8_t>(h.lw0);
     k.lw1 = static_cast<int8_t>(h.lw1);
     k.lseen = static_cast<int8_t>(h.lseen);
@@ -2382,9 +2620,53 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
       k.data = (*in.cols)[h.col].data;
       k.valid = (*in.cols)[h.col].valid;
     }
-    if (h.filter_col >= 0) {
-      k.fdata = static_cast<const uint8_t *>((*in.cols)[h.filter_col].data);
-      k.fvalid = (*in.cols)[h.filter_col].valid;
+    if (h.e_op1 >= 0) {  // computed input: one table entry per distinct expression
+      VExpr e;
+      std::memset(&e, 0, sizeof(e));
+      e.x = static_cast<const double *>((*in.cols)[h.col].data);
+      e.vx = (*in.cols)[h.col].valid;
+      e.y = static_cast<const double *>((*in.cols)[h.col2].data);
+      e.vy = (*in.cols)[h.col2].valid;
+      e.op1 = static_cast<int8_t>(h.e_op1);
+      e.op2 = static_cast<int8_t>(h.e_op2);
+      if (h.e_op2 >= 0) {
+        e.z = static_cast<const double *>((*in.cols)[h.col3].data);
+        e.vz = (*in.cols)[h.col3].valid;
+      }
+      int at = -1;
+      for (int i = 0; i < nvex && at < 0; i++)
+        if (std::memcmp(&args.vex[i], &e, sizeof(e)) == 0) at = i;
+      if (at < 0) {
+        if (nvex == kMaxVex) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg: more than 8 distinct computed inputs");
+        at = nvex;
+        args.vex[nvex++] = e;
+      }
+      k.vex = static_cast<int8_t>(at + 1);
+    }
+    if (h.filter_col >= 0 && !common_filter) {
+      const DCol &fc = (*in.cols)[h.filter_col];
+      if (h.f_cmp >= 0) {
+        VSel sl;
+        std::memset(&sl, 0, sizeof(sl));
+        sl.data = static_cast<const long long *>(fc.data);
+        sl.valid = fc.valid;
+        sl.cst = h.f_cst;
+        sl.cmp = h.f_cmp;
+        int at = -1;
+        for (int i = 0; i < nvsel && at < 0; i++)
+          if (std::memcmp(&args.vsel[i], &sl, sizeof(sl)) == 0) at = i;
+        if (at < 0) {
+          if (nvsel == kMaxVsel) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg: more than 4 distinct selections as FILTER");
+          at = nvsel;
+          args.vsel[nvsel++] = sl;
+        }
+        k.has_filter = 2;
+        k.fsel = static_cast<int8_t>(at + 1);
+      } else {
+        k.has_filter = 1;
+        k.fdata = static_cast<const uint8_t *>(fc.data);
+        k.fvalid = fc.valid;
+      }
     }
     k.w0 = h.w0.as<unsigned long long>();
     k.w1 = h.w1.as<unsigned long long>();
@@ -2404,12 +2686,18 @@ static crgpu_status launch_accumulate(crgpu_agg *a, const PassInput &in, bool fu
         args.G = plan.sweeps == 1 ? plan.G : static_cast<uint32_t>(left < static_cast<int64_t>(plan.G) ? left : plan.G);
       }
       ProfScope prof(plan.lds ? (fused ? "agg_fused_lds" : "agg_accum_lds") : (fused ? "agg_fused_hbm" : "agg_accum_hbm"));
+      const bool vc = args.cf_kind != 0 || nvex > 0 || nvsel > 0;
       if (plan.lds) {
-        if (fused && plan.pk) hipLaunchKernelGGL((agg_accum_kernel<true, true, true>), grid, block, lds, st, args);
+        if (fused && plan.pk && vc) hipLaunchKernelGGL((agg_accum_kernel<true, true, true, true>), grid, block, lds, st, args);
+        else if (fused && plan.pk) hipLaunchKernelGGL((agg_accum_kernel<true, true, true>), grid, block, lds, st, args);
+        else if (fused && vc) hipLaunchKernelGGL((agg_accum_kernel<true, true, false, true>), grid, block, lds, st, args);
         else if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, true, false>), grid, block, lds, st, args);
+        else if (vc) hipLaunchKernelGGL((agg_accum_kernel<false, true, false, true>), grid, block, lds, st, args);
         else hipLaunchKernelGGL((agg_accum_kernel<false, true, false>), grid, block, lds, st, args);
       } else {
-        if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false, false>), grid, block, 0, st, args);
+        if (fused && vc) hipLaunchKernelGGL((agg_accum_kernel<true, false, false, true>), grid, block, 0, st, args);
+        else if (fused) hipLaunchKernelGGL((agg_accum_kernel<true, false, false>), grid, block, 0, st, args);
+        else if (vc) hipLaunchKernelGGL((agg_accum_kernel<false, false, false, true>), grid, block, 0, st, args);
         else hipLaunchKernelGGL((agg_accum_kernel<false, false, false>), grid, block, 0, st, args);
       }
       CRGPU_HIP(hipGetLastError());
@@ -2763,7 +3051,7 @@ __global__ void agg_sample_keys_kernel(const long long *__restrict__ keys, int64
 // and the caller continues with the incremental path.
 static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
   *done = false;
-  if (a->ngroups != 0 || a->seq != 0 || n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix) return CRGPU_OK;
+  if (a->ngroups != 0 || a->seq != 0 || n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
   if (a->group_cols.size() != 1 || a->types[a->group_cols[0]] != CRGPU_INT64) return CRGPU_OK;
   const DCol &key = cols[a->group_cols[0]];
   if (key.valid != nullptr || (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0) return CRGPU_OK;
@@ -2920,7 +3208,7 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
   if (n < 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: negative row count");
   if (n == 0) return CRGPU_OK;
   if (cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null columns");
-  const int nc = static_cast<int>(a->types.size());
+  const int nc = a->n_phys;  // computed columns (crgpu_dev_agg_create_fused) are not passed in
   std::vector<DCol> in;
   for (int c = 0; c < nc; c++) {
     if (cols[c].type != a->types[c]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: column type differs from the spec");

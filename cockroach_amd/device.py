@@ -383,6 +383,51 @@ class FilteredAgg:
         self.agg.close()
 
 
+PROJ_OP = {"+": 0, "-": 1, "*": 2, "*(1-)": 3, "*(1+)": 4}
+CMP_OP = {"EQ": 0, "NE": 1, "LT": 2, "LE": 3, "GT": 4, "GE": 5}
+
+
+class FusedAgg(Agg):
+    """crgpu_dev_agg_create_fused: scan -> selection -> projections -> hash aggregation in one pass.  `types` are the
+    physical input columns; `vcols` define computed columns at the ordinals len(types), len(types) + 1, ...:
+    ("project", op, a, b) -- FLOAT64, op in PROJ_OP -- or ("select", cmp, a, constant) -- BOOL, cmp in CMP_OP.
+    aggs may name them as col / filter_col.  With `where` (the ordinal of a selection) the selection becomes the FILTER
+    of every aggregate (ANY_NOT_NULL of a group column excepted) plus a hidden COUNT_ROWS, and finish_vecs() drops the
+    groups no passing row reached: the result of `sel -> projections -> hashAggregator` in the reference's plan."""
+
+    def __init__(self, types, group_cols, aggs, vcols, where=None):
+        self.naggs = len(aggs)
+        self.where = where
+        aggs = [(a[0], a[1], a[2] if len(a) > 2 else -1) for a in aggs]
+        if where is not None:
+            if any(a[2] >= 0 for a in aggs):
+                raise _lib.CrgpuError(_lib.ERR_UNSUPPORTED, "FusedAgg: an aggregate with its own FILTER under a WHERE")
+            aggs = [(f, c, -1) if (f == 0 and c in group_cols) else (f, c, where) for f, c, _ in aggs] + [(14, -1, where)]
+        all_types = list(types)
+        self._vc = (_lib.AggVcol * max(len(vcols), 1))()
+        for i, v in enumerate(vcols):
+            if v[0] == "project":
+                self._vc[i] = _lib.AggVcol(0, PROJ_OP[v[1]], v[2], v[3], 0)
+                all_types.append(cd.FLOAT64)
+            else:
+                self._vc[i] = _lib.AggVcol(1, CMP_OP[v[1]], v[2], -1, int(v[3]))
+                all_types.append(cd.BOOL)
+        self._types, self._groups = _i32arr(all_types), _i32arr(group_cols)
+        self._aggs = (_lib.AggDesc * max(len(aggs), 1))()
+        for i, a in enumerate(aggs):
+            self._aggs[i] = _lib.AggDesc(a[0], a[1], a[2], 0)
+        spec = _lib.AggSpec(len(all_types), len(group_cols), self._types, self._groups, len(aggs), 0, self._aggs)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_agg_create_fused(C.byref(spec), len(vcols), self._vc, C.byref(self.h)))
+
+    def finish_vecs(self):
+        vecs = result_to_vecs(self.finish())
+        if self.where is None:
+            return vecs
+        keep = np.flatnonzero(vecs[-1].data > 0)
+        return [v.take(keep) for v in vecs[:self.naggs]]
+
+
 class Distinct:
     """crgpu_distinct handle (unordered DISTINCT): consume() returns the first occurrences of new tuples, in input order."""
 

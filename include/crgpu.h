@@ -211,6 +211,30 @@ crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *out);
 crgpu_status crgpu_dev_agg_reset(crgpu_agg *a);
 void crgpu_dev_agg_destroy(crgpu_agg *a);
 
+/* ---- scan -> selection -> projections -> aggregation in ONE pass.  The reference plans
+ * colexecsel.sel*Int64Int64ConstOp and colexecproj / colexecprojconst float projections in front of the hash aggregator
+ * (Q1: tpch_vec:20537-20546; colexecsel/selection_ops.eg.go:34952, colexecproj/proj_non_const_ops.eg.go:4922,8126,12196,
+ * colexecprojconst/proj_const_left_ops.eg.go:4515,7503,11295) and materialises every intermediate vector.  Here the
+ * last n_virtual ordinals of spec->types are COMPUTED columns, evaluated inside the aggregation kernels' row loop with
+ * the roundings of the separate operators; crgpu_dev_agg_consume then receives only the first n_cols - n_virtual
+ * (physical) columns.  A computed column is either
+ *   CRGPU_VCOL_PROJECT_F64 (type FLOAT64):  a op b, op as in crgpu_dev_project_f64 (0 +, 1 -, 2 *, 3 a*(1-b), 4 a*(1+b));
+ *     b is a physical FLOAT64 column, a a physical FLOAT64 column or an earlier computed projection (two chained
+ *     projections at most); NULL if an operand is NULL.  Usable as the input of SUM / AVG / MIN / MAX / COUNT.
+ *   CRGPU_VCOL_SELECT_I64_CONST (type BOOL):  a cmp cst, cmp as in crgpu_dev_select_i64_const, a a physical INT64
+ *     column; false for a NULL.  Usable as an aggregation's filter_col (a WHERE in front of the aggregator is the
+ *     FILTER of every aggregate plus a filtered COUNT_ROWS whose zero groups the caller drops).
+ * Grouping columns must be physical.  Everything else behaves as crgpu_dev_agg_create. */
+enum { CRGPU_VCOL_PROJECT_F64 = 0, CRGPU_VCOL_SELECT_I64_CONST = 1 };
+typedef struct crgpu_agg_vcol {
+  int32_t kind; /* CRGPU_VCOL_* */
+  int32_t op;   /* projection operator / comparison */
+  int32_t a, b; /* operand ordinals (b unused by a selection) */
+  int64_t cst;  /* selection constant */
+} crgpu_agg_vcol;
+crgpu_status crgpu_dev_agg_create_fused(const crgpu_agg_spec *spec, int32_t n_virtual, const crgpu_agg_vcol *vcols,
+                                        crgpu_agg **out);
+
 /* ---- hash repartition: replaces colexechash.TupleHashDistributor.Distribute
  * (hash_utils.go:163) + the per-output row copies of HashRouter
  * (sql/colflow/routers.go:683-715).  Rows of `cols` are regrouped by

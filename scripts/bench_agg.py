@@ -128,6 +128,47 @@ def run_q1_full(n, dv, g, rf, ls, offs, f, reps):
             "kernels": kern, "cpu_baseline": cpu}
 
 
+def run_q1_fused(n, dv, g, rf, ls, offs, f, reps):
+    """Config Q1 with the selection and the projections evaluated INSIDE the aggregation kernels
+    (crgpu_dev_agg_create_fused): the same plan and result as run_q1_full, no intermediate column exists in HBM."""
+    ship = torch.randint(8036, 10562, (n,), generator=g, device=dv, dtype=torch.int64)
+    cutoff = 10562 - 36
+    qty, price, disc, tax = f
+    base = [dev.from_torch(cd.INT64, ship), dev.from_torch(cd.BYTES, rf, offsets=offs), dev.from_torch(cd.BYTES, ls, offsets=offs)] + \
+           [dev.from_torch(cd.FLOAT64, x) for x in (qty, price, disc, tax)]
+    types = [cd.INT64, cd.BYTES, cd.BYTES] + [cd.FLOAT64] * 4
+    # computed: 7 disc_price = price * (1 - disc), 8 charge = disc_price * (1 + tax), 9 WHERE ship <= cutoff
+    vcols = [("project", "*(1-)", 4, 5), ("project", "*(1+)", 7, 6), ("select", "LE", 0, cutoff)]
+    aggs = [(0, 1, -1), (0, 2, -1), (10, 3, -1), (10, 4, -1), (10, 7, -1), (10, 8, -1), (1, 3, -1), (1, 4, -1), (1, 5, -1), (14, -1, -1)]
+    torch.cuda.synchronize()
+    a = dev.FusedAgg(types, [1, 2], aggs, vcols, where=9)
+
+    def once():
+        a.consume(base, n)
+        res = a.finish()
+        ng = int(res.n)
+        a.reset()
+        return ng
+
+    ngroups = once()
+    _lib.load().crgpu_dev_synchronize()
+    dev.prof_enable(True); dev.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    _lib.load().crgpu_dev_synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kern = {}
+    for k in ("agg_fused_lds", "agg_resolve", "agg_fixup", "agg_accum_lds"):
+        ms, cnt = dev.prof_get(k)
+        if cnt:
+            kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
+    a.close()
+    return {"case": "Q1 full, fused: WHERE shipdate <= c and the 2 projections evaluated inside the aggregation kernel, GROUP BY 2 bytes keys, 4 SUM + 3 AVG + COUNT_ROWS",
+            "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt, "alg_GBps": n * 42.0 / dt / 1e9,
+            "frac_of_8TBps": n * 42.0 / dt / 8e12, "kernels": kern, "cpu_baseline": None}
+
+
 def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
     """Yields one result dict per case (bench.py reports a few of them beside the join line)."""
     global CPU_SAMPLE
@@ -150,6 +191,8 @@ def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):
         yield run("Q1 shape: 2 bytes keys, <=6 groups, 4 SUM + 3 AVG + COUNT_ROWS", cols, types, [0, 1], aggs, n, n * 34.0, reps=reps)
     if only is None or "q1full" in only:
         yield run_q1_full(n, dv, g, rf, ls, offs, f, reps)
+    if only is None or "q1fused" in only:
+        yield run_q1_fused(n, dv, g, rf, ls, offs, f, reps)
     del cols, f, rf, ls
     for groups in (1 << 10, 1 << 13, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 21, 1 << 22, 1 << 24, n):
         if groups > n or (only is not None and str(groups) not in only):

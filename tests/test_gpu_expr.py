@@ -100,6 +100,90 @@ def test_q1_plan_select_project_aggregate_vs_oracle(oracle):
     del where, g_charge
 
 
+def _q1_inputs(rng, n, null_frac=0.02):
+    ship = rng.integers(8000, 10600, size=n, dtype=np.int64)
+    rf = rng.integers(0, 3, size=n)
+    ls = rng.integers(0, 2, size=n)
+    ship[(rf == 2) & (ls == 1)] = 11_000  # this group never passes
+    nulls = (lambda: rng.random(n) > null_frac) if null_frac else (lambda: None)
+    return [cd.Vec.from_numpy(cd.INT64, ship, nulls()),
+            cd.Vec.from_values(cd.BYTES, [b"ANR"[i:i + 1] for i in rf]), cd.Vec.from_values(cd.BYTES, [b"FO"[i:i + 1] for i in ls]),
+            cd.Vec.from_numpy(cd.FLOAT64, rng.integers(1, 51, size=n).astype(np.float64)),
+            cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.random(n) * 1e5, 2), nulls()),
+            cd.Vec.from_numpy(cd.FLOAT64, rng.integers(0, 11, size=n) / 100.0, nulls()),
+            cd.Vec.from_numpy(cd.FLOAT64, rng.integers(0, 9, size=n) / 100.0, nulls())]
+
+
+@pytest.mark.parametrize("null_frac", [0.0, 0.03])
+def test_q1_plan_fused_into_the_aggregation_vs_oracle(oracle, null_frac):
+    """The same Q1 plan (tpch_vec:20537-20546) through crgpu_dev_agg_create_fused: the selection and both projections are
+    evaluated inside the aggregation kernels, nothing is materialised.  Compared with the reference's order of
+    operations on the CPU (select, project with separate roundings, aggregate), MIN / MAX / COUNT over the computed
+    columns and NULL operands included; fed in three chunks so that the first one goes through find-or-insert (the
+    claimants' first rows evaluate the expressions in the fixup kernel) and the later ones through the fused pass."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(80)
+    n = 300_000
+    cols = _q1_inputs(rng, n, null_frac)
+    cutoff = 10_471
+    # ordinals: 0 ship, 1 rf, 2 ls, 3 qty, 4 price, 5 disc, 6 tax | computed: 7 disc_price, 8 charge, 9 where
+    aggs = [(0, 1, -1), (0, 2, -1), (10, 3, -1), (10, 4, -1), (10, 7, -1), (10, 8, -1), (1, 3, -1), (1, 4, -1), (1, 5, -1), (14, -1, -1),
+            (7, 8, -1), (8, 7, -1), (5, 8, -1), (1, 8, -1)]
+    keep = oracle.select_i64_const("LE", cols[0], cutoff)
+    sel = [v.take(keep) for v in cols]
+    disc_price = oracle.project_f64("*", sel[4], oracle.project_f64("-", 1.0, sel[5]))
+    charge = oracle.project_f64("*", disc_price, oracle.project_f64("+", 1.0, sel[6]))
+    want = oracle.hash_agg(sel + [disc_price, charge], [1, 2], aggs)
+    vcols = [("project", "*(1-)", 4, 5), ("project", "*(1+)", 7, 6), ("select", "LE", 0, cutoff)]
+    fa = dev.FusedAgg([v.type for v in cols], [1, 2], aggs, vcols, where=9)
+    for lo, hi in ((0, 1000), (1000, 100_000), (100_000, n)):
+        fa.consume([dev.upload(v.slice(lo, hi)) for v in cols], hi - lo)
+    got = fa.finish_vecs()
+    assert len(got[0]) == 5, "the group whose rows all fail the WHERE must be dropped"
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "Q1 plan, fused")
+    # Reset and once more in one piece
+    fa.reset()
+    fa.consume([dev.upload(v) for v in cols], n)
+    H.assert_same_multiset(H.vecs_to_tuples(fa.finish_vecs()), H.vecs_to_tuples(want), "Q1 plan, fused, after Reset")
+    fa.close()
+
+
+def test_fused_agg_many_groups_and_per_aggregate_filters(oracle):
+    """Computed inputs beyond the fused LDS pass: 50 000 groups (index lookup + HBM atomics), two different selections
+    as FILTERs of different aggregates (no common filter), every projection operator."""
+    from cockroach_amd import device as dev
+    from cockroach_amd import _lib
+    rng = np.random.default_rng(81)
+    n = 400_000
+    k = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 50_000, size=n, dtype=np.int64))
+    d = cd.Vec.from_numpy(cd.INT64, rng.integers(-50, 50, size=n, dtype=np.int64), rng.random(n) > 0.05)
+    x = cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(n) * 100)
+    y = cd.Vec.from_numpy(cd.FLOAT64, rng.random(n), rng.random(n) > 0.05)
+    cols = [k, d, x, y]
+    # computed: 4 x+y, 5 x-y, 6 x*y, 7 (x+y)*y, 8 d < 0, 9 d >= 10
+    vcols = [("project", "+", 2, 3), ("project", "-", 2, 3), ("project", "*", 2, 3), ("project", "*", 4, 3),
+             ("select", "LT", 1, 0), ("select", "GE", 1, 10)]
+    aggs = [(0, 0, -1), (10, 4, -1), (10, 5, 8), (10, 6, 9), (1, 7, -1), (14, -1, 8), (5, 6, 9), (8, 7, 8)]
+    pf = oracle.project_f64
+    host = cols + [pf("+", x, y), pf("-", x, y), pf("*", x, y), pf("*", pf("+", x, y), y)]
+    for cmp, c in (("LT", 0), ("GE", 10)):
+        m = np.zeros(n, dtype=np.uint8)
+        m[oracle.select_i64_const(cmp, d, c)] = 1
+        host.append(cd.Vec.from_numpy(cd.BOOL, m))
+    want = oracle.hash_agg(host, [0], aggs)
+    fa = dev.FusedAgg([v.type for v in cols], [0], aggs, vcols)
+    for lo, hi in ((0, 150_000), (150_000, n)):
+        fa.consume([dev.upload(v.slice(lo, hi)) for v in cols], hi - lo)
+    H.assert_same_multiset(H.vecs_to_tuples(fa.finish_vecs()), H.vecs_to_tuples(want), "fused, many groups")
+    fa.close()
+    with pytest.raises(_lib.CrgpuError) as e:  # three chained projections
+        dev.FusedAgg([cd.FLOAT64, cd.FLOAT64], [], [(10, 4, -1)], [("project", "+", 0, 1), ("project", "*", 2, 1), ("project", "-", 3, 1)])
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.CrgpuError) as e:  # grouping by a computed column
+        dev.FusedAgg([cd.FLOAT64, cd.FLOAT64], [2], [(14, -1, -1)], [("project", "+", 0, 1)])
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+
+
 def test_select_bytes_const_vs_oracle(oracle):
     """selEQBytesBytesConstOp / selNEBytesBytesConstOp / selContainsBytesBytesConstOp (Q3: c_mktsegment = 'BUILDING',
     Q9: p_name LIKE '%green%').  The reference holds no literal vectors for the BYTES overloads (its selection tests
