@@ -124,6 +124,10 @@ SYMBOLS = [
     ("crgpu_dev_project_f64", _I32, [_I32, C.POINTER(DCol), C.c_double, C.POINTER(DCol), C.c_double, _I64, _VP, _VP]),
     ("crgpu_dev_select_bytes_const", _I32, [_I32, C.POINTER(DCol), C.c_char_p, _I32, _I64, _VP]),
     ("crgpu_dev_extract_year", _I32, [C.POINTER(DCol), _I64, _VP]),
+    ("crgpu_dev_arrow_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_VP)]),
+    ("crgpu_dev_arrow_read", _I32, [_VP, _VP, _I64, C.POINTER(DevResult)]),
+    ("crgpu_dev_arrow_write", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(_VP), C.POINTER(_I64)]),
+    ("crgpu_dev_arrow_destroy", None, [_VP]),
     ("crgpu_dev_deselector_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_VP)]),
     ("crgpu_dev_deselect", _I32, [_VP, C.POINTER(DCol), _I64, _VP, C.POINTER(DevResult)]),
     ("crgpu_dev_deselector_destroy", None, [_VP]),

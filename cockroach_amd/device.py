@@ -350,6 +350,38 @@ class Deselector:
             pass
 
 
+class ArrowSerde:
+    """crgpu_arrow handle: serialized RecordBatch messages (colserde wire format) <-> device columns."""
+
+    def __init__(self, types):
+        self._types = _i32arr(types)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_arrow_create(self._types, len(types), C.byref(self.h)))
+
+    def read(self, msg: bytes) -> _lib.DevResult:
+        buf = np.frombuffer(msg, dtype=np.uint8)
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_arrow_read(self.h, buf.ctypes.data if buf.size else None, buf.size, C.byref(res)))
+        return res
+
+    def write(self, cols, n=None) -> bytes:
+        n = (cols[0].n if cols else 0) if n is None else n
+        out, ln = C.c_void_p(), C.c_int64()
+        _lib.check(_lib.load().crgpu_dev_arrow_write(self.h, dcol_array(cols), n, C.byref(out), C.byref(ln)))
+        return C.string_at(out.value, ln.value)
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_arrow_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FilteredAgg:
     """Hash aggregation under a WHERE clause without moving rows: the selection's BOOL column becomes the FILTER of
     every aggregate (group-key ANY_NOT_NULLs excepted) plus a hidden COUNT_ROWS, and groups that no passing row

@@ -346,6 +346,25 @@ crgpu_status crgpu_dev_deselect(crgpu_deselector *d, const crgpu_dcol *cols, int
                                 crgpu_dev_result *out);
 void crgpu_dev_deselector_destroy(crgpu_deselector *d);
 
+/* ---- the batch wire format: replaces colserde.RecordBatchSerializer.Serialize / Deserialize
+ * (col/colserde/record_batch.go:96-314), colserde.ArrowBatchConverter.BatchToArrow / ArrowToBatch
+ * (col/colserde/arrowbatchconverter.go:130-470) and coldata.Bytes.Serialize / Deserialize (col/coldata/bytes.go:560-640)
+ * for the column families of the GPU path.  crgpu_dev_arrow_read takes one serialized RecordBatch message in HOST
+ * memory -- what colfetcher.cFetcherWrapper.NextBatch returns for a direct columnar scan (cfetcher_wrapper.go:85-143,
+ * storage/col_mvcc.go:112-166) and what colrpc.Inbox receives -- and returns library-owned device columns (valid
+ * until the next call on the handle): validity bitmaps and fixed-width values are copied as they are, BYTES columns
+ * are converted on the device from the reference's [elements | buffer] form to {offsets, payload}.
+ * crgpu_dev_arrow_write is the inverse (device columns, e.g. crgpu_dev_decode_kv's result, to a message in
+ * library-owned HOST memory valid until the next call): with it the device decoder is a storage.CFetcherWrapper whose
+ * NextBatch serializes.  Other families (Decimal, Interval, TimestampTZ, JSON, datum-backed) =>
+ * CRGPU_ERR_UNSUPPORTED at create: the CPU converter stays for such schemas. */
+typedef struct crgpu_arrow crgpu_arrow;
+crgpu_status crgpu_dev_arrow_create(const int32_t *types, int32_t n_cols, crgpu_arrow **out);
+crgpu_status crgpu_dev_arrow_read(crgpu_arrow *h, const uint8_t *msg, int64_t msg_len, crgpu_dev_result *out);
+crgpu_status crgpu_dev_arrow_write(crgpu_arrow *h, const crgpu_dcol *cols, int64_t n, const uint8_t **msg_out,
+                                   int64_t *msg_len_out);
+void crgpu_dev_arrow_destroy(crgpu_arrow *h);
+
 /* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for indexes that store one KV per
  * row (MaxKeysPerRow == 1 fast path, sql/colfetcher/cfetcher.go:758-1093,937-941) together with
  * colencoding.DecodeKeyValsToCols (colencoding/key_encoding.go:43), processValueBytes
