@@ -52,6 +52,16 @@ class AggVcol(C.Structure):  # crgpu_agg_vcol
     _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("cst", C.c_int64)]
 
 
+class GraceOpts(C.Structure):  # crgpu_grace_opts
+    _fields_ = [("mem_limit", C.c_int64), ("host_limit", C.c_int64), ("spill_dir", C.c_char_p), ("num_buckets", C.c_int32),
+                ("max_repartitions", C.c_int32)]
+
+
+class GraceStats(C.Structure):  # crgpu_grace_stats
+    _fields_ = [("partitions_processed", C.c_int64), ("repartitions", C.c_int64), ("fallback_partitions", C.c_int64),
+                ("bytes_spilled", C.c_int64), ("bytes_spilled_disk", C.c_int64)]
+
+
 class FetchSpec(C.Structure):  # crgpu_fetch_spec
     _fields_ = [("key_prefix_len", C.c_int32), ("n_key_cols", C.c_int32), ("key_types", C.POINTER(C.c_int32)),
                 ("key_dirs", C.POINTER(C.c_int32)), ("key_out", C.POINTER(C.c_int32)), ("n_val_cols", C.c_int32),
@@ -124,6 +134,12 @@ SYMBOLS = [
     ("crgpu_dev_project_f64", _I32, [_I32, C.POINTER(DCol), C.c_double, C.POINTER(DCol), C.c_double, _I64, _VP, _VP]),
     ("crgpu_dev_select_bytes_const", _I32, [_I32, C.POINTER(DCol), C.c_char_p, _I32, _I64, _VP]),
     ("crgpu_dev_extract_year", _I32, [C.POINTER(DCol), _I64, _VP]),
+    ("crgpu_dev_grace_join_create", _I32, [C.POINTER(JoinSpec), C.POINTER(GraceOpts), C.POINTER(_VP)]),
+    ("crgpu_dev_grace_agg_create", _I32, [C.POINTER(AggSpec), C.POINTER(GraceOpts), C.POINTER(_VP)]),
+    ("crgpu_dev_grace_add", _I32, [_VP, _I32, C.POINTER(DCol), _I64]),
+    ("crgpu_dev_grace_next", _I32, [_VP, C.POINTER(DevResult), C.POINTER(_I32)]),
+    ("crgpu_dev_grace_stats", _I32, [_VP, C.POINTER(GraceStats)]),
+    ("crgpu_dev_grace_destroy", None, [_VP]),
     ("crgpu_dev_arrow_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_VP)]),
     ("crgpu_dev_arrow_read", _I32, [_VP, _VP, _I64, C.POINTER(DevResult)]),
     ("crgpu_dev_arrow_write", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(_VP), C.POINTER(_I64)]),

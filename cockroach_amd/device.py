@@ -350,6 +350,70 @@ class Deselector:
             pass
 
 
+class Grace:
+    """crgpu_grace handle: the Grace-partitioned (external) hash join / hash aggregation (hashBasedPartitioner).
+    add() partitions device rows and spills them; results() yields the output piece by piece as host Vecs."""
+
+    def __init__(self, handle, keep):
+        self.h, self._keep = handle, keep
+
+    @staticmethod
+    def _opts(mem_limit, num_buckets, host_limit, spill_dir, max_repartitions):
+        return _lib.GraceOpts(int(mem_limit), int(host_limit), spill_dir.encode() if spill_dir else None, int(num_buckets),
+                              int(max_repartitions))
+
+    @classmethod
+    def join(cls, join_type, left_types, right_types, left_eq, right_eq, right_eq_cols_are_key=False, mem_limit=0,
+             num_buckets=0, host_limit=0, spill_dir=None, max_repartitions=0):
+        keep = (_i32arr(left_types), _i32arr(right_types), _i32arr(left_eq), _i32arr(right_eq), _i32arr([]))
+        spec = _lib.JoinSpec(join_type, int(bool(right_eq_cols_are_key)), len(left_types), len(right_types), keep[0], keep[1],
+                             len(left_eq), -1, keep[2], keep[3], keep[4])
+        opts = cls._opts(mem_limit, num_buckets, host_limit, spill_dir, max_repartitions)
+        h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_grace_join_create(C.byref(spec), C.byref(opts), C.byref(h)))
+        return cls(h, keep)
+
+    @classmethod
+    def agg(cls, types, group_cols, aggs, mem_limit=0, num_buckets=0, host_limit=0, spill_dir=None, max_repartitions=0):
+        descs = (_lib.AggDesc * max(len(aggs), 1))()
+        for i, a in enumerate(aggs):
+            descs[i] = _lib.AggDesc(a[0], a[1], a[2] if len(a) > 2 else -1, 0)
+        keep = (_i32arr(types), _i32arr(group_cols), descs)
+        spec = _lib.AggSpec(len(types), len(group_cols), keep[0], keep[1], len(aggs), 0, descs)
+        opts = cls._opts(mem_limit, num_buckets, host_limit, spill_dir, max_repartitions)
+        h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_grace_agg_create(C.byref(spec), C.byref(opts), C.byref(h)))
+        return cls(h, keep)
+
+    def add(self, input_idx, cols, n=None):
+        n = (cols[0].n if cols else 0) if n is None else n
+        _lib.check(_lib.load().crgpu_dev_grace_add(self.h, input_idx, dcol_array(cols), n))
+
+    def results(self):
+        while True:
+            res, done = _lib.DevResult(), C.c_int32(0)
+            _lib.check(_lib.load().crgpu_dev_grace_next(self.h, C.byref(res), C.byref(done)))
+            if done.value:
+                return
+            yield result_to_vecs(res)
+
+    def stats(self) -> _lib.GraceStats:
+        st = _lib.GraceStats()
+        _lib.check(_lib.load().crgpu_dev_grace_stats(self.h, C.byref(st)))
+        return st
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_grace_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ArrowSerde:
     """crgpu_arrow handle: serialized RecordBatch messages (colserde wire format) <-> device columns."""
 

@@ -346,6 +346,39 @@ crgpu_status crgpu_dev_deselect(crgpu_deselector *d, const crgpu_dcol *cols, int
                                 crgpu_dev_result *out);
 void crgpu_dev_deselector_destroy(crgpu_deselector *d);
 
+/* ---- Grace-partitioned (external) hash join / hash aggregation: HBM -> host memory -> disk.
+ * Replaces colexecdisk.hashBasedPartitioner (sql/colexec/colexecdisk/hash_based_partitioner.go:143-717) around the
+ * in-memory hash joiner (external_hash_joiner.go:62-143) or hash aggregator (external_hash_aggregator.go:32-95): what
+ * the disk spiller (disk_spiller.go:81-200) switches to when the in-memory operator reports CRGPU_ERR_OOM / exceeds its
+ * budget (feed it the operator's ExportBuffered tuples, then the rest of the input).
+ *   crgpu_dev_grace_add    hbpInitialPartitioning: distribute device rows of input 0 (left / the aggregator's input)
+ *                          or 1 (right = build side) over num_buckets partitions by the reference's
+ *                          TupleHashDistributor hash (seed DefaultInitHashValue + 1) and move them out of HBM
+ *   crgpu_dev_grace_next   the first call ends the partitioning phase; every call returns the next piece of output
+ *                          (library-owned device columns, valid until the next call): partitions whose build side fits
+ *                          mem_limit run through the in-memory operator, larger ones are repartitioned with the next
+ *                          seed, children that shrink by < 5 % run with the budget lifted (the reference's sort-based
+ *                          fallback; a real device OOM is returned as CRGPU_ERR_OOM).  *done = 1 after the last piece.
+ * Output rows are those of the in-memory operator on the whole input, in partition order. */
+typedef struct crgpu_grace crgpu_grace;
+typedef struct crgpu_grace_opts {
+  int64_t mem_limit;        /* maxPartitionSizeToProcessUsingMain: bytes of last-input rows a partition may hold (>= 64 KiB; 0: 64 MiB) */
+  int64_t host_limit;       /* bytes of spilled rows kept in host memory; beyond it chunks go to files (0: unlimited) */
+  const char *spill_dir;    /* directory for the disk tier, or NULL: host memory only */
+  int32_t num_buckets;      /* partitions per (re)partitioning step (0: 16) */
+  int32_t max_repartitions; /* recursion bound (0: 64) */
+} crgpu_grace_opts;
+typedef struct crgpu_grace_stats {
+  int64_t partitions_processed, repartitions, fallback_partitions;
+  int64_t bytes_spilled, bytes_spilled_disk;
+} crgpu_grace_stats;
+crgpu_status crgpu_dev_grace_join_create(const crgpu_join_spec *spec, const crgpu_grace_opts *opts, crgpu_grace **out);
+crgpu_status crgpu_dev_grace_agg_create(const crgpu_agg_spec *spec, const crgpu_grace_opts *opts, crgpu_grace **out);
+crgpu_status crgpu_dev_grace_add(crgpu_grace *g, int32_t input, const crgpu_dcol *cols, int64_t n);
+crgpu_status crgpu_dev_grace_next(crgpu_grace *g, crgpu_dev_result *out, int32_t *done);
+crgpu_status crgpu_dev_grace_stats(crgpu_grace *g, crgpu_grace_stats *out);
+void crgpu_dev_grace_destroy(crgpu_grace *g);
+
 /* ---- the batch wire format: replaces colserde.RecordBatchSerializer.Serialize / Deserialize
  * (col/colserde/record_batch.go:96-314), colserde.ArrowBatchConverter.BatchToArrow / ArrowToBatch
  * (col/colserde/arrowbatchconverter.go:130-470) and coldata.Bytes.Serialize / Deserialize (col/coldata/bytes.go:560-640)
