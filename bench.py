@@ -86,6 +86,74 @@ def cpu_baseline(lb, lp):
                       f"1024-tuple batches), {dt:.1f} s"}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline_pway(lb, lp, P):
+    """SURVEY.md 8(d) baseline (2): the reference's distributed shape on the host cores -- P "nodes", each routing its
+    1/P share of both inputs through a HashRouter (TupleHashDistributor over P outputs, oracle/crdb_oracle.c
+    ora_distribute) to P hash joiners, one thread each (ora_hash_join on its bucket).  The routing is inside the timed
+    region.  Threads, not processes: the oracle's calls release the GIL."""
+    import threading
+    import numpy as np
+    from oracle import oracle as O
+    from cockroach_amd import coldata as cd
+    rng = np.random.default_rng(42)
+    nb, npr = 1 << lb, 1 << lp
+    bk = rng.permutation(nb).astype(np.int64)
+    bv = bk * 3 + 1
+    pk = rng.integers(0, nb, size=npr, dtype=np.int64)
+    pw = np.arange(npr, dtype=np.int64)
+    sides = {"L": [pk, pw], "R": [bk, bv]}
+    routed = {(s_, i): None for s_ in sides for i in range(P)}
+
+    def route(i):  # node i: its 1/P share of both inputs through a HashRouter each (physical_plan.go:1120-1157)
+        for name, (k, v) in sides.items():
+            lo, hi = len(k) * i // P, len(k) * (i + 1) // P
+            ks_, vs_ = k[lo:hi], v[lo:hi]
+            dest, counts = O.distribute([cd.Vec.from_numpy(cd.INT64, ks_)], [0], P)
+            order = np.argsort(dest, kind="stable")  # the router's per-output row copies
+            ks, vs = ks_[order], vs_[order]
+            ends = np.cumsum(counts)
+            routed[(name, i)] = [(ks[e - c:e], vs[e - c:e]) for c, e in zip(counts, ends)]
+
+    outs = [0] * P
+
+    def join(p):  # node p's joiner: what the P routers sent to bucket p
+        lk, lw = (np.concatenate([routed[("L", i)][p][j] for i in range(P)]) for j in (0, 1))
+        rk, rv = (np.concatenate([routed[("R", i)][p][j] for i in range(P)]) for j in (0, 1))
+        L = [cd.Vec.from_numpy(cd.INT64, lk), cd.Vec.from_numpy(cd.INT64, lw)]
+        R = [cd.Vec.from_numpy(cd.INT64, rk), cd.Vec.from_numpy(cd.INT64, rv)]
+        cl, _k1 = O.make_cols(L)
+        cr, _k2 = O.make_cols(R)
+        eq = np.array([0], dtype=np.int32)
+        res = O.lib().ora_hash_join(0, cl, 2, len(lk), cr, 2, len(rk), eq.ctypes.data, eq.ctypes.data, 1, 1, 1024, 256)
+        outs[p] = O.lib().ora_result_nrows(res)
+        O.lib().ora_result_free(res)
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=route, args=(i,)) for i in range(P)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    t_route = time.perf_counter() - t0
+    ts = [threading.Thread(target=join, args=(p,)) for p in range(P)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    dt = time.perf_counter() - t0
+    assert sum(outs) == npr
+    return {"value": (nb + npr) / dt, "unit": "rows/s", "cores": P, "kind": "port", "cpu": cpu_model(),
+            "sample": f"same workload at 2^{lb} build x 2^{lp} probe rows: {P} threads route their share of both inputs "
+                      f"(ora_distribute, {t_route:.1f} s), then {P} joiner threads (ora_hash_join per bucket), {dt:.1f} s in all"}
+
+
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_J_radix_pmc_summary.txt")
 KERNEL_SYMBOL = {"join_probe": "radix_probe_kernel<0, 0", "radix_build_split": "radix_split_kernel",
                  "radix_build_table": "radix_table_kernel"}
@@ -285,6 +353,9 @@ def main(argv=None):
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_log2_build, args.cpu_log2_probe)
+            # SURVEY.md 8(d) baseline (2): HashRouter + P joiners on the host cores this job may use (16 on the GPU box)
+            P = max(2, min(16, len(os.sched_getaffinity(0))))
+            line["cpu_baseline_partitioned"] = cpu_baseline_pway(args.cpu_log2_build, args.cpu_log2_probe, P)
     join.close()
     if distributed:
         gb = distributed_group_by(args, torch, dist, dev, cd, _lib, xch_b, world, rank, device)

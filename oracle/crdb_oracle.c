@@ -1090,9 +1090,10 @@ static int64_t hj_emit_right(hash_joiner *hj, int matched) {
   return n_results;
 }
 
-static hash_joiner *g_last_join = NULL;
-static uint32_t g_dbg_head[64];
-static int g_dbg_nhead = 0;
+/* (thread-local: bench.py's P-way CPU baseline runs one joiner per host thread) */
+static _Thread_local hash_joiner *g_last_join = NULL;
+static _Thread_local uint32_t g_dbg_head[64];
+static _Thread_local int g_dbg_nhead = 0;
 static void hj_destroy(hash_joiner *hj) {
   if (!hj) return;
   ht_free(&hj->ht);
@@ -1449,7 +1450,7 @@ typedef struct hash_aggregator {
   int err;
 } hash_aggregator;
 
-static hash_aggregator *g_last_agg = NULL;
+static _Thread_local hash_aggregator *g_last_agg = NULL;
 
 /* aggregatorHelper.performAggregation (aggregators_util.go:102-108) and its
  * FILTER flavour (:216-234, filter = rows whose BOOL filter column is true). */
