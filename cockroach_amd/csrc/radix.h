@@ -67,6 +67,10 @@ struct RadixTable {
   DevBuf table, special;  // kRadixSlots slots per sub-partition
   DevBuf hist, totals, starts, sub_count, flag;
   DevBuf p_rows, p_hist, p_totals, p_starts;  // probe-side partition buffers
+  // probe side partitioned without a histogram pass: fixed-capacity (partition, chunk) cells in p_rows
+  DevBuf p_cell_cnt, p_cell_pref;
+  uint32_t p_nchunks = 0, p_cell_cap = 0;
+  bool cells_failed = false;  // a cell overflowed once (skewed keys): this table's probes use the histogram form
 };
 
 // Level 1 only: t.rows_a holds partition p's rows in [starts[p], starts[p] + totals[p]) (uint32 arrays of kRadixP1).

@@ -10,6 +10,7 @@
 //   radix_split_kernel     per partition: refine into <=64 sub-partitions
 //   radix_table_kernel     per sub-partition: open-addressing table built in LDS, written out coalesced
 //   radix_probe_kernel     partition-at-a-time probe out of the XCD's L2
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -160,16 +161,28 @@ __global__ __launch_bounds__(1024) void radix_offs_kernel(uint32_t *__restrict__
 // adjacent lanes, further complete lines of the same tile go out straight from registers,
 // the remainder waits in the buffer.  Every HBM write is therefore a whole line (random
 // 64-byte writes run at 3.4 TB/s, 16-byte ones at 2.0, whole lines at 4.7).
-template <bool FAST>
+// CELLS: no histogram pass ran.  Chunk c writes its rows of partition p into the fixed-capacity cell (p, c) of
+// `cell_cap` rows (a multiple of 8: every cell starts on a line) and reports how many it held in cell_cnt[p][c]; rows
+// beyond the capacity are dropped and the flag is raised (skewed keys: the caller repeats the pass with offsets from a
+// histogram).  For hashed keys a cell holds chunk_rows / 1024 rows on average with a standard deviation of its square
+// root, so a capacity eight deviations above the mean practically never overflows.
+template <bool FAST, bool CELLS>
 __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64_t n, int64_t chunk_rows,
                                                              const uint32_t *__restrict__ offs,
-                                                             ulonglong2 *__restrict__ out) {
+                                                             ulonglong2 *__restrict__ out, uint32_t cell_cap,
+                                                             uint32_t *__restrict__ cell_cnt, uint32_t *__restrict__ flag) {
   constexpr int P = kRadixP1, THREADS = 1024, ROWS = 4, TILE = THREADS * ROWS;
   __shared__ ulonglong2 bins[P * 8];
   __shared__ uint32_t cnt[P];    // rows pending in the buffer (incl. phantom slots before the first flush)
   __shared__ uint32_t gbase[P];  // line-aligned absolute row position of buffer slot 0
   __shared__ uint8_t first[P];   // first real slot: chunk-start misalignment, 0 after the first flush
-  {
+  // CELLS: first row position past the cell of partition p
+#define RADIX_CELL_END(p) ((static_cast<uint32_t>(p) * gridDim.x + blockIdx.x + 1u) * cell_cap)
+  if (CELLS) {
+    gbase[threadIdx.x] = (threadIdx.x * gridDim.x + blockIdx.x) * cell_cap;
+    cnt[threadIdx.x] = 0;
+    first[threadIdx.x] = 0;
+  } else {
     const uint32_t g0 = offs[static_cast<int64_t>(blockIdx.x) * P + threadIdx.x];
     const uint32_t a = g0 & 7u;
     gbase[threadIdx.x] = g0 - a;
@@ -208,14 +221,15 @@ __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64
       if (pp[j] != 0xFFFFFFFFu) {
         nfl[j] = cnt[pp[j]] & ~7u;
         if (rk[j] < 8u) bins[pp[j] * 8 + rk[j]] = make_ulonglong2(kk[j], vv[j]);
-        else if (rk[j] < nfl[j]) out[gbase[pp[j]] + rk[j]] = make_ulonglong2(kk[j], vv[j]);
+        else if (rk[j] < nfl[j] && (!CELLS || gbase[pp[j]] + rk[j] < RADIX_CELL_END(pp[j])))
+          out[gbase[pp[j]] + rk[j]] = make_ulonglong2(kk[j], vv[j]);
       }
     }
     __syncthreads();
     // C: flush every complete first line, 8 lanes per line
     for (int i = threadIdx.x; i < P * 8; i += THREADS) {
       const int p = i >> 3, sl = i & 7;
-      if (cnt[p] >= 8u && sl >= static_cast<int>(first[p])) out[gbase[p] + sl] = bins[i];
+      if (cnt[p] >= 8u && sl >= static_cast<int>(first[p]) && (!CELLS || gbase[p] < RADIX_CELL_END(p))) out[gbase[p] + sl] = bins[i];
     }
     __syncthreads();
     // D: rows past the last complete line are the new buffer content
@@ -235,7 +249,54 @@ __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64
   }
   for (int i = threadIdx.x; i < P * 8; i += THREADS) {
     const int p = i >> 3, sl = i & 7;
-    if (sl >= static_cast<int>(first[p]) && sl < static_cast<int>(cnt[p])) out[gbase[p] + sl] = bins[i];
+    if (sl >= static_cast<int>(first[p]) && sl < static_cast<int>(cnt[p]) && (!CELLS || gbase[p] < RADIX_CELL_END(p)))
+      out[gbase[p] + sl] = bins[i];
+  }
+  if (CELLS) {
+    const uint32_t held = gbase[threadIdx.x] - (threadIdx.x * gridDim.x + blockIdx.x) * cell_cap + cnt[threadIdx.x];
+    cell_cnt[threadIdx.x * gridDim.x + blockIdx.x] = held < cell_cap ? held : cell_cap;
+    if (held > cell_cap) atomicOr(flag, 1u);
+  }
+#undef RADIX_CELL_END
+}
+
+// Before the cells form is chosen: the partition histogram of kSkewSample rows taken at a fixed stride.  A partition
+// that draws more than kSkewLimit of them (64 expected, standard deviation 8) holds well over its share of the rows
+// -- a hot key -- and would overflow its cells; the probe then partitions with the full histogram instead.
+static constexpr int kSkewSample = 65536, kSkewLimit = 100;
+template <bool FAST>
+__global__ __launch_bounds__(1024) void radix_skew_sample_kernel(RadixSrc src, int64_t n, int64_t stride,
+                                                                 uint32_t *__restrict__ hist) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x) * stride;
+  if (i >= n) return;
+  uint64_t kk = 0;
+  bool ok = true;
+  if (FAST) kk = reinterpret_cast<const uint64_t *>(src.kp.c[0].data)[i];
+  else ok = key_pack(src.kp, i, kk);
+  if (ok) atomicAdd(&hist[rpart(fmix64(kk))], 1u);
+}
+__global__ __launch_bounds__(1024) void radix_skew_check_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ flag) {
+  if (hist[threadIdx.x] > static_cast<uint32_t>(kSkewLimit)) atomicOr(flag, 1u);
+}
+
+// cell counts -> per partition: pref[p][c] = rows of the cells before c (pref[p][nchunks] = rows of the partition)
+__global__ __launch_bounds__(512) void radix_cell_prefix_kernel(const uint32_t *__restrict__ cell_cnt, uint32_t nchunks,
+                                                                uint32_t *__restrict__ pref, uint32_t *__restrict__ totals) {
+  __shared__ uint32_t wsum[8];
+  const uint32_t p = blockIdx.x, c = threadIdx.x;
+  const uint32_t v = c < nchunks ? cell_cnt[p * nchunks + c] : 0;
+  const uint32_t incl = wave_incl_scan_u32(v);
+  if (lane_id() == 63) wsum[c >> 6] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (uint32_t w = 0; w < 8; w++) {
+    if (w < (c >> 6)) base += wsum[w];
+    total += wsum[w];
+  }
+  if (c < nchunks) pref[p * (nchunks + 1) + c] = base + incl - v;
+  if (c == 0) {
+    pref[p * (nchunks + 1) + nchunks] = total;
+    totals[p] = total;
   }
 }
 
@@ -621,6 +682,9 @@ struct RadixProbeArgs {
   int32_t sub_bits;
   int32_t wg_per_part;
   int32_t _pad;
+  // CELLS (MODE 0): the partitioned rows live in fixed-capacity cells (radix_scatter_kernel<.., true>)
+  const uint32_t *cell_pref;  // [partition][nchunks + 1]
+  uint32_t nchunks, cell_cap;
   RadixEmit emit;
 };
 
@@ -629,13 +693,15 @@ struct RadixProbeArgs {
 //         read from HBM once and then served by that XCD's L2);
 // MODE 1: direct lookups of unpartitioned probe rows (small probes);
 // MODE 2: only the rows whose key is NULL, as unmatched (LEFT OUTER / LEFT ANTI).
-template <int JT, int MODE, int TB, int RPT, bool CHD>
+template <int JT, int MODE, int TB, int RPT, bool CHD, bool CELLS = false>
 __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
   constexpr int kWaves = TB / 64;
   constexpr int kTile = TB * RPT;
   __shared__ uint32_t s_cnt[RPT * kWaves];
   __shared__ uint32_t s_pre[RPT * kWaves];
   __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_pref[CELLS ? 513 : 1];  // CELLS: rows of the partition's cells before each cell
+  float cell_guess = 0.f;
   extern __shared__ __align__(16) uint8_t s_disp[];  // CHD, MODE 0: the partition's displacement bytes [nsub][kRadixBuckets]
   const int tid = threadIdx.x, wave = tid >> 6;
   const uint32_t nsub = a.smask + 1;
@@ -647,10 +713,15 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
     part = (i / a.wg_per_part) * 8u + x;
     const uint32_t slice = i % a.wg_per_part;
     // the workgroup takes tiles slice, slice + W, ... of its partition: no undersized slices
-    const int64_t pbeg = a.pstart[part];
+    const int64_t pbeg = CELLS ? 0 : a.pstart[part];  // CELLS: positions are virtual (the partition's rows, cell after cell)
     lo = pbeg + static_cast<int64_t>(slice) * kTile;
     hi = pbeg + a.pcount[part];
     step = static_cast<int64_t>(a.wg_per_part) * kTile;
+    if (CELLS) {
+      for (uint32_t i = tid; i <= a.nchunks; i += TB) s_pref[i] = a.cell_pref[part * (a.nchunks + 1) + i];
+      cell_guess = hi > 0 ? static_cast<float>(a.nchunks) / static_cast<float>(hi) : 0.f;
+      __syncthreads();
+    }
     if (CHD && lo < hi) {  // stage the partition's displacement bytes: every lookup below then costs ONE table read
       const uint4 *src = reinterpret_cast<const uint4 *>(a.disp + static_cast<int64_t>(part) * nsub * kRadixBuckets);
       uint4 *dst = reinterpret_cast<uint4 *>(s_disp);
@@ -675,7 +746,16 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
       k[j] = 0, pay[j] = 0, val[j] = 0;
       if (MODE == 0) {
         if (inb[j]) {  // (prefetching the next tile here was measured: no gain, the kernel is L2-request bound)
-          const ull2 row = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(a.prow) + r);
+          int64_t phys = r;
+          if (CELLS) {  // the cell holding virtual row r: cells are nearly equal, so a proportional guess is off by <= 1-2
+            const uint32_t v = static_cast<uint32_t>(r);
+            uint32_t c = static_cast<uint32_t>(static_cast<float>(v) * cell_guess);
+            if (c >= a.nchunks) c = a.nchunks - 1;
+            while (v < s_pref[c]) c--;
+            while (v >= s_pref[c + 1]) c++;
+            phys = static_cast<int64_t>(part * a.nchunks + c) * a.cell_cap + (v - s_pref[c]);
+          }
+          const ull2 row = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(a.prow) + phys);
           k[j] = row.x, pay[j] = row.y;
           look[j] = true;
         }
@@ -1167,6 +1247,10 @@ __global__ __launch_bounds__(TB) void radix_dup_emit_kernel(RadixDupArgs a) {
 }
 
 // ------------------------------------------------------------------ host side
+static bool env_flag_default_on(const char *name) {
+  const char *v = std::getenv(name);
+  return v == nullptr || v[0] != '0';
+}
 static void chunking(int64_t n, int *nchunks, int64_t *chunk_rows) {
   int64_t want = (n + 65535) / 65536;  // >= 64 rows per partition and chunk on average
   if (want < 1) want = 1;
@@ -1207,13 +1291,69 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
   {
     ProfScope prof(prof_scatter);
     if (src.fast)
-      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
-                         hist.as<uint32_t>(), rows.as<ulonglong2>());
+      hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+                         hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
     else
-      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
-                         hist.as<uint32_t>(), rows.as<ulonglong2>());
+      hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+                         hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
     CRGPU_HIP(hipGetLastError());
   }
+  return CRGPU_OK;
+}
+
+// The probe side without the histogram pass: one scatter into fixed-capacity (partition, chunk) cells, then the cells'
+// prefix sums per partition.  *ok = false when a cell overflowed (keys whose hash bits are skewed): the caller then
+// partitions with the histogram.  Costs one 4-byte flag read-back instead of a pass over the key column.
+static crgpu_status radix_partition_cells(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok) {
+  hipStream_t st = stream();
+  *ok = false;
+  int nchunks;
+  int64_t chunk_rows;
+  chunking(n, &nchunks, &chunk_rows);
+  const double mean = static_cast<double>(chunk_rows) / kRadixP1;
+  uint32_t cap = static_cast<uint32_t>(mean + 8.0 * std::sqrt(mean) + 16.0);
+  cap = (cap + 7u) & ~7u;
+  if (static_cast<uint64_t>(kRadixP1) * nchunks * cap > 0xFFFFFFF0ull) return CRGPU_OK;  // 32-bit row positions
+  CRGPU_TRY(t.p_rows.ensure(static_cast<size_t>(kRadixP1) * nchunks * cap * 16 + 256));
+  CRGPU_TRY(t.p_cell_cnt.ensure(static_cast<size_t>(kRadixP1) * nchunks * 4));
+  CRGPU_TRY(t.p_cell_pref.ensure(static_cast<size_t>(kRadixP1) * (nchunks + 1) * 4));
+  CRGPU_TRY(t.p_totals.ensure(kRadixP1 * 4));
+  CRGPU_TRY(t.flag.ensure(4));
+  CRGPU_HIP(hipMemsetAsync(t.flag.p, 0, 4, st));
+  {  // hot keys?  (a 4-byte read-back: ~25 us against the 4 ms a failed cells pass would cost)
+    CRGPU_TRY(t.p_hist.ensure(kRadixP1 * 4));
+    CRGPU_HIP(hipMemsetAsync(t.p_hist.p, 0, kRadixP1 * 4, st));
+    const int64_t stride = n / kSkewSample > 0 ? n / kSkewSample : 1;
+    if (src.fast)
+      hipLaunchKernelGGL(radix_skew_sample_kernel<true>, dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(radix_skew_sample_kernel<false>, dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
+    hipLaunchKernelGGL(radix_skew_check_kernel, dim3(1), dim3(1024), 0, st, t.p_hist.as<uint32_t>(), t.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+    uint32_t skewed = 0;
+    CRGPU_HIP(hipMemcpyAsync(&skewed, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (skewed) return CRGPU_OK;  // *ok stays false
+  }
+  {
+    ProfScope prof("radix_probe_scatter");
+    if (src.fast)
+      hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
+                         t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
+    else
+      hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
+                         t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_cell_prefix_kernel, dim3(kRadixP1), dim3(512), 0, st, t.p_cell_cnt.as<uint32_t>(),
+                       static_cast<uint32_t>(nchunks), t.p_cell_pref.as<uint32_t>(), t.p_totals.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  uint32_t overflow = 0;
+  CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  t.p_nchunks = static_cast<uint32_t>(nchunks);
+  t.p_cell_cap = cap;
+  *ok = overflow == 0;
   return CRGPU_OK;
 }
 
@@ -1271,6 +1411,7 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   uint32_t overflow = 0;
   t.chd = false;
   t.dup = false;
+  t.cells_failed = false;
   // The perfect-hash form takes 1.06 ms off the probe of config J (6.78 -> 5.72 ms: one slot read per row instead of 1.5)
   // but its build costs 3.8 ms against the cuckoo kernel's 1.7 (size-ordered displacement searches are latency chains
   // of LDS atomics), so it only pays when the probe side is >~ 14 x the build side: opt-in, CRGPU_RADIX_TABLE=chd.
@@ -1315,6 +1456,11 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
 template <int JT, int MODE, int TB, int RPT>
 static crgpu_status launch_probe_jt(const RadixProbeArgs &a, int grid) {
   hipStream_t st = stream();
+  if (MODE == 0 && a.cell_pref != nullptr && a.disp == nullptr) {  // rows in cells (cuckoo tables)
+    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE == 0 ? 0 : MODE, TB, RPT, false, MODE == 0>), dim3(grid), dim3(TB), 0, st, a);
+    CRGPU_HIP(hipGetLastError());
+    return CRGPU_OK;
+  }
   if (a.disp != nullptr) {  // perfect-hash tables; MODE 0 stages the partition's displacement bytes in dynamic LDS
     const size_t lds = MODE == 0 ? static_cast<size_t>(a.smask + 1) * kRadixBuckets : 0;
     if (lds > 48 * 1024) {
@@ -1366,7 +1512,20 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
   a.emit = emit;
   const bool keeps_unmatched = jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_ANTI;
   if (partitioned) {
-    CRGPU_TRY(radix_partition(src, n, t.p_hist, t.p_totals, t.p_starts, t.p_rows, 0, "radix_probe_hist", "radix_probe_scatter"));
+    // large probes skip the histogram pass (fixed-capacity cells); skewed keys and perfect-hash tables take the classic form
+    static const bool cells_on = env_flag_default_on("CRGPU_RADIX_CELLS");
+    bool cells = false;
+    if (cells_on && !t.chd && !t.cells_failed && n >= (int64_t(1) << 22) && n <= (int64_t(1) << 30)) {
+      CRGPU_TRY(radix_partition_cells(t, src, n, &cells));
+      if (!cells) t.cells_failed = true;  // the following probe chunks of this join go straight to the histogram form
+    }
+    if (cells) {
+      a.cell_pref = t.p_cell_pref.as<uint32_t>();
+      a.nchunks = t.p_nchunks;
+      a.cell_cap = t.p_cell_cap;
+    } else {
+      CRGPU_TRY(radix_partition(src, n, t.p_hist, t.p_totals, t.p_starts, t.p_rows, 0, "radix_probe_hist", "radix_probe_scatter"));
+    }
     a.prow = t.p_rows.as<ulonglong2>();
     a.pstart = t.p_starts.as<uint32_t>();
     a.pcount = t.p_totals.as<uint32_t>();
