@@ -52,6 +52,15 @@ class AggVcol(C.Structure):  # crgpu_agg_vcol
     _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("cst", C.c_int64)]
 
 
+class GjoinAgg(C.Structure):  # crgpu_gjoin_agg
+    _fields_ = [("func", C.c_int32), ("input", C.c_int32)]
+
+
+class GjoinSpec(C.Structure):  # crgpu_gjoin_spec
+    _fields_ = [("join_type", C.c_int32), ("key_type", C.c_int32), ("probe_payload_type", C.c_int32),
+                ("build_payload_type", C.c_int32), ("n_aggs", C.c_int32), ("_pad", C.c_int32), ("aggs", C.POINTER(GjoinAgg))]
+
+
 class GraceOpts(C.Structure):  # crgpu_grace_opts
     _fields_ = [("mem_limit", C.c_int64), ("host_limit", C.c_int64), ("spill_dir", C.c_char_p), ("num_buckets", C.c_int32),
                 ("max_repartitions", C.c_int32)]
@@ -134,6 +143,10 @@ SYMBOLS = [
     ("crgpu_dev_project_f64", _I32, [_I32, C.POINTER(DCol), C.c_double, C.POINTER(DCol), C.c_double, _I64, _VP, _VP]),
     ("crgpu_dev_select_bytes_const", _I32, [_I32, C.POINTER(DCol), C.c_char_p, _I32, _I64, _VP]),
     ("crgpu_dev_extract_year", _I32, [C.POINTER(DCol), _I64, _VP]),
+    ("crgpu_dev_gjoin_create", _I32, [C.POINTER(GjoinSpec), C.POINTER(_VP)]),
+    ("crgpu_dev_gjoin_build", _I32, [_VP, C.POINTER(DCol), C.POINTER(DCol), _I64]),
+    ("crgpu_dev_gjoin_probe", _I32, [_VP, C.POINTER(DCol), C.POINTER(DCol), _I64, C.POINTER(DevResult)]),
+    ("crgpu_dev_gjoin_destroy", None, [_VP]),
     ("crgpu_dev_grace_join_create", _I32, [C.POINTER(JoinSpec), C.POINTER(GraceOpts), C.POINTER(_VP)]),
     ("crgpu_dev_grace_agg_create", _I32, [C.POINTER(AggSpec), C.POINTER(GraceOpts), C.POINTER(_VP)]),
     ("crgpu_dev_grace_add", _I32, [_VP, _I32, C.POINTER(DCol), _I64]),

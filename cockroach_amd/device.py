@@ -350,6 +350,45 @@ class Deselector:
             pass
 
 
+class GroupJoin:
+    """crgpu_gjoin handle: the fused hash group-join (aggregate while probing).  aggs: [(func, input)] with input
+    0 = the key, 1 = the probe side's payload, 2 = the build side's payload.  Raises CrgpuError(ERR_UNSUPPORTED) for
+    shapes outside the fused form: compose Join -> Agg then."""
+
+    def __init__(self, aggs, probe_payload_type=0, build_payload_type=0, join_type=0, key_type=cd.INT64):
+        self._aggs = (_lib.GjoinAgg * max(len(aggs), 1))()
+        for i, (f, inp) in enumerate(aggs):
+            self._aggs[i] = _lib.GjoinAgg(f, inp)
+        spec = _lib.GjoinSpec(join_type, key_type, probe_payload_type, build_payload_type, len(aggs), 0, self._aggs)
+        self.h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_gjoin_create(C.byref(spec), C.byref(self.h)))
+
+    def build(self, key, payload=None, n=None):
+        n = key.n if n is None else n
+        self._keep = (key, payload)
+        pd = payload.dcol() if payload is not None else None
+        _lib.check(_lib.load().crgpu_dev_gjoin_build(self.h, C.byref(key.dcol()), C.byref(pd) if pd is not None else None, n))
+
+    def probe(self, key, payload=None, n=None) -> _lib.DevResult:
+        n = key.n if n is None else n
+        res = _lib.DevResult()
+        pd = payload.dcol() if payload is not None else None
+        _lib.check(_lib.load().crgpu_dev_gjoin_probe(self.h, C.byref(key.dcol()), C.byref(pd) if pd is not None else None, n,
+                                                     C.byref(res)))
+        return res
+
+    def close(self):
+        if self.h:
+            _lib.load().crgpu_dev_gjoin_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Grace:
     """crgpu_grace handle: the Grace-partitioned (external) hash join / hash aggregation (hashBasedPartitioner).
     add() partitions device rows and spills them; results() yields the output piece by piece as host Vecs."""

@@ -346,6 +346,37 @@ crgpu_status crgpu_dev_deselect(crgpu_deselector *d, const crgpu_dcol *cols, int
                                 crgpu_dev_result *out);
 void crgpu_dev_deselector_destroy(crgpu_deselector *d);
 
+/* ---- hash group-join, fused: replaces colexec.hashGroupJoiner (sql/colexec/hash_group_joiner.go:20-76, planned at
+ * colbuilder/execplan.go:1385-1530 from execinfrapb.HashGroupJoinerSpec, processors_sql.proto:1035-1072: "the join's
+ * equality columns are exactly the same as the aggregation's grouping columns").  The reference composes joiner ->
+ * aggregator ("TODO: add optimized implementation"); this form aggregates while probing and materialises no joined
+ * row.  Scope of the fused form: INNER join on ONE INT64 equality column with unique build keys (a duplicate-heavy
+ * build side => CRGPU_ERR_UNSUPPORTED at build), at most one 8-byte payload column per side (INT64 or FLOAT64, no
+ * NULLs), aggregations COUNT_ROWS / COUNT, SUM / AVG (FLOAT64), SUM_INT, MIN, MAX over the probe payload and
+ * ANY_NOT_NULL of the key or the build payload, within four accumulator words per group.  Anything else =>
+ * CRGPU_ERR_UNSUPPORTED: the caller composes crgpu_dev_join_probe -> crgpu_dev_agg_consume (device-resident too).
+ * One probe call takes the whole probe side and returns one row per group that has a match (arbitrary order):
+ * column f = aggregation f. */
+typedef struct crgpu_gjoin_agg {
+  int32_t func;  /* crgpu_agg_func */
+  int32_t input; /* 0 the key, 1 the probe side's payload column, 2 the build side's payload column */
+} crgpu_gjoin_agg;
+typedef struct crgpu_gjoin_spec {
+  int32_t join_type;          /* CRGPU_INNER */
+  int32_t key_type;           /* CRGPU_INT64 */
+  int32_t probe_payload_type; /* 0: none */
+  int32_t build_payload_type; /* 0: none */
+  int32_t n_aggs;
+  int32_t _pad;
+  const crgpu_gjoin_agg *aggs;
+} crgpu_gjoin_spec;
+typedef struct crgpu_gjoin crgpu_gjoin;
+crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crgpu_gjoin **out);
+crgpu_status crgpu_dev_gjoin_build(crgpu_gjoin *g, const crgpu_dcol *key, const crgpu_dcol *payload, int64_t n);
+crgpu_status crgpu_dev_gjoin_probe(crgpu_gjoin *g, const crgpu_dcol *key, const crgpu_dcol *payload, int64_t n,
+                                   crgpu_dev_result *out);
+void crgpu_dev_gjoin_destroy(crgpu_gjoin *g);
+
 /* ---- Grace-partitioned (external) hash join / hash aggregation: HBM -> host memory -> disk.
  * Replaces colexecdisk.hashBasedPartitioner (sql/colexec/colexecdisk/hash_based_partitioner.go:143-717) around the
  * in-memory hash joiner (external_hash_joiner.go:62-143) or hash aggregator (external_hash_aggregator.go:32-95): what

@@ -141,6 +141,46 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4, two_cols=False):
     return r
 
 
+def bench_group_join_fused(reps, dv, g, lg_b=24, lg_p=27):
+    """The same group-join through the fused form (crgpu_dev_gjoin_*: aggregate while probing, no joined row is
+    materialised), same inputs and the same torch check as bench_join_then_agg."""
+    nb, npr = 1 << lg_b, 1 << lg_p
+    okeys = torch.randperm(nb, generator=g, device=dv, dtype=torch.int64)[: nb // 2].contiguous() * 7 + 3
+    lkey = torch.randint(0, nb, (npr,), generator=g, device=dv, dtype=torch.int64) * 7 + 3
+    price = torch.randint(1, 100000, (npr,), generator=g, device=dv, dtype=torch.int64).to(torch.float64) / 100.0
+    bk, pk, pv = dev.from_torch(cd.INT64, okeys), dev.from_torch(cd.INT64, lkey), dev.from_torch(cd.FLOAT64, price)
+    gj = dev.GroupJoin([(0, 0), (10, 1), (14, 0)], probe_payload_type=cd.FLOAT64)
+    out = {}
+
+    def go():
+        gj.build(bk, None, nb // 2)
+        out["res"] = gj.probe(pk, pv, npr)
+    dt = _timed(go, reps)
+    kern = _kernels(["radix_build_hist", "radix_build_scatter", "radix_build_split", "radix_build_table", "gjoin_fused"], reps)
+    res = out["res"]
+    ng = int(res.n)
+    rc = dev.result_columns(res)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import wrap_torch
+    gk = wrap_torch(rc[0], ng, torch.int64, dv).clone()
+    gs = wrap_torch(rc[1], ng, torch.float64, dv).clone()
+    gc = wrap_torch(rc[2], ng, torch.int64, dv).clone()
+    hit = torch.isin(lkey, okeys)
+    uk, inv = torch.unique(lkey[hit], return_inverse=True)
+    want_s = torch.zeros(uk.numel(), device=dv, dtype=torch.float64).index_add_(0, inv, price[hit])
+    want_c = torch.bincount(inv, minlength=uk.numel())
+    order = torch.argsort(gk)
+    ok = ng == uk.numel() and torch.equal(gk[order], uk) and torch.equal(gc[order], want_c) and \
+        bool(torch.allclose(gs[order], want_s, rtol=1e-9, atol=1e-6))
+    if not ok:
+        raise SystemExit("fused group-join: result check failed")
+    gj.close()
+    r = _line(f"hash group-join, FUSED (aggregate while probing): 2^{lg_b - 1} built orders x 2^{lg_p} lineitems -> GROUP BY key: SUM + COUNT_ROWS, {ng} groups",
+              nb // 2 + npr, dt, 16.0 * (nb // 2) + 16.0 * npr + 24.0 * ng, kern, None)
+    r["result_check"] = "ok"
+    return r
+
+
 def bench_join_then_agg(reps, dv, g, lg_b=24, lg_p=27):
     """Hash group-join as the reference runs it (colexec/hash_group_joiner.go:20-76: hash joiner -> hash aggregator),
     device-resident: the join's output columns go straight into crgpu_dev_agg_consume.  Q3/Q18-like shape: 2^lg_b
@@ -315,6 +355,8 @@ def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_r
         yield bench_build(lg_rows, reps, dv, g)
     if want("join_agg"):
         yield bench_join_then_agg(reps, dv, g)
+    if want("join_agg_fused"):
+        yield bench_group_join_fused(reps, dv, g)
     if want("general_join"):
         yield bench_general_join(reps, dv, g)
     if want("general_join2"):

@@ -34,3 +34,79 @@ def test_hash_group_join_vs_oracle(oracle, jt):
     joined = oracle.hash_join(jt, left, right, [0], [0], True)
     want = oracle.hash_agg(joined, [1], aggs)
     H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "group-join")
+
+
+# ---------------------------------------------------------------- the fused form (csrc/gjoin.hip)
+F = H.AGG_FUNC
+
+
+def _fused_vs_oracle(oracle, bk, bv, pk, pv, aggs_fused, aggs_oracle):
+    """aggs_oracle name the columns of the join's output (pk, pv, bk, bv); grouping by the key (column 0)."""
+    from cockroach_amd import device as dev
+    gj = dev.GroupJoin(aggs_fused, probe_payload_type=pv.type, build_payload_type=bv.type)
+    gj.build(dev.upload(bk), dev.upload(bv))
+    got = dev.result_to_vecs(gj.probe(dev.upload(pk), dev.upload(pv)))
+    gj.close()
+    joined = oracle.hash_join(0, [pk, pv], [bk, bv], [0], [0], True)
+    want = oracle.hash_agg(joined, [0], aggs_oracle)
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "fused group-join")
+    return len(got[0])
+
+
+@pytest.mark.parametrize("nb,npr", [(50_000, 300_000), (300_000, 2_000_000)])
+def test_fused_group_join_float_payload_vs_oracle(oracle, nb, npr):
+    """GROUP BY the join key, aggregates over the probe payload and the build payload, INNER: against the reference's
+    composition joiner -> aggregator on the oracle.  A third of the build keys has no probe row (no group), probe keys
+    miss the build side and carry NULLs, the key ~0 (the tables' empty marker) is a real key."""
+    rng = np.random.default_rng(nb)
+    keys = rng.permutation(nb * 3)[:nb].astype(np.int64)
+    keys[0] = -1  # == the empty marker of the partitioned tables
+    bk = cd.Vec.from_numpy(cd.INT64, keys)
+    bv = cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.random(nb) * 10, 2))
+    p = rng.integers(0, nb * 2, size=npr, dtype=np.int64)
+    p[rng.random(npr) < 0.001] = -1
+    pk = cd.Vec.from_numpy(cd.INT64, p, rng.random(npr) > 0.02)
+    pv = cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.standard_normal(npr) * 100, 2))
+    fused = [(F["ANY_NOT_NULL"], 0), (F["ANY_NOT_NULL"], 2), (F["SUM"], 1), (F["AVG"], 1), (F["MIN"], 1), (F["MAX"], 1),
+             (F["COUNT_ROWS"], 0), (F["COUNT"], 1)]
+    ora = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 3, -1), (F["SUM"], 1, -1), (F["AVG"], 1, -1), (F["MIN"], 1, -1),
+           (F["MAX"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["COUNT"], 1, -1)]
+    ng = _fused_vs_oracle(oracle, bk, bv, pk, pv, fused, ora)
+    assert 0 < ng < nb
+
+
+def test_fused_group_join_int_payload_overflow_and_unsupported(oracle):
+    from cockroach_amd import _lib
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(9)
+    nb, npr = 20_000, 400_000
+    bk = cd.Vec.from_numpy(cd.INT64, np.arange(nb, dtype=np.int64) * 7)
+    bv = cd.Vec.from_numpy(cd.INT64, rng.integers(-5, 5, nb, dtype=np.int64))
+    pk = cd.Vec.from_numpy(cd.INT64, rng.integers(0, nb, npr, dtype=np.int64) * 7)
+    pv = cd.Vec.from_numpy(cd.INT64, rng.integers(-2**62, 2**62, npr, dtype=np.int64) // 64)
+    fused = [(F["ANY_NOT_NULL"], 0), (F["SUM_INT"], 1), (F["MIN"], 1), (F["ANY_NOT_NULL"], 2), (F["COUNT_ROWS"], 0)]
+    ora = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["MIN"], 1, -1), (F["ANY_NOT_NULL"], 3, -1), (F["COUNT_ROWS"], -1, -1)]
+    _fused_vs_oracle(oracle, bk, bv, pk, pv, fused, ora)
+    # a group whose exact total leaves int64
+    big = cd.Vec.from_numpy(cd.INT64, np.full(npr, 2**62, dtype=np.int64))
+    one = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 100_000, npr, dtype=np.int64))  # ~4 rows of 2^62 per key
+    gj = dev.GroupJoin([(F["SUM_INT"], 1)], probe_payload_type=cd.INT64)
+    gj.build(dev.upload(cd.Vec.from_numpy(cd.INT64, np.arange(100_000, dtype=np.int64))))
+    with pytest.raises(_lib.CrgpuError) as e:
+        gj.probe(dev.upload(one), dev.upload(big))
+    assert e.value.code == _lib.ERR_INT_OUT_OF_RANGE
+    gj.close()
+    # outside the fused form: the caller composes join -> aggregate
+    for kwargs, aggs in ((dict(join_type=1), [(F["COUNT_ROWS"], 0)]),                      # LEFT OUTER
+                         (dict(probe_payload_type=cd.INT64), [(F["SUM"], 1)]),            # SUM over INT => DECIMAL
+                         (dict(probe_payload_type=cd.FLOAT64), [(F["ANY_NOT_NULL"], 1)]),  # arrival order
+                         (dict(probe_payload_type=cd.INT64), [(F["SUM_INT"], 1), (F["MIN"], 1), (F["MAX"], 1)])):  # 5 words
+        with pytest.raises(_lib.CrgpuError) as e:
+            dev.GroupJoin(aggs, **kwargs)
+        assert e.value.code == _lib.ERR_UNSUPPORTED
+    # duplicate-heavy build side
+    gj = dev.GroupJoin([(F["COUNT_ROWS"], 0)])
+    with pytest.raises(_lib.CrgpuError) as e:
+        gj.build(dev.upload(cd.Vec.from_numpy(cd.INT64, np.zeros(100_000, dtype=np.int64))))
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    gj.close()
