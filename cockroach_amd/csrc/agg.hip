@@ -161,6 +161,8 @@ __device__ __forceinline__ bool sel_apply(int cmp, long long v, long long c) {
 
 // total-order map for float MIN/MAX: NaN is the smallest value
 // (hash_min_max_agg.eg.go:966-981) -> 0; everything else order-preserving and > 0.
+// -0 ranks below +0 here; the reference's comparison treats them as equal and keeps the one it saw first.  Which zero
+// comes out therefore differs by sign only (documented in DESIGN.md "divergences"; the oracle compares with ==).
 __device__ __forceinline__ unsigned long long f64_to_ordered(double f) {
   if (f != f) return 0ull;
   unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(f));

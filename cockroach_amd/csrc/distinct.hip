@@ -246,7 +246,10 @@ static crgpu_status distinct_ensure(crgpu_distinct *d, size_t need_groups) {
   }
   uint64_t want = 1024;
   while (want < 2 * static_cast<uint64_t>(need_groups)) want *= 2;
-  if (want > kDMaxCap) return fail(CRGPU_ERR_OOM, "crgpu_dev_distinct_consume: more than 2^29 distinct keys on one GPU");
+  // (the bound counts STORED rows: a mostly-new batch joins the key store whole, duplicates included, and the index is
+  // sized for the store plus the incoming batch before the batch has been looked at)
+  if (want > kDMaxCap)
+    return fail(CRGPU_ERR_OOM, "crgpu_dev_distinct_consume: the index bound of 2^29 stored rows + incoming batch is reached on this GPU (spill: ExportBuffered)");
   if (want > d->cap) {
     CRGPU_TRY(d->meta.ensure(static_cast<size_t>(want) * 8));
     CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(want) * 8, st));
@@ -314,7 +317,8 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
   if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null argument");
   CRGPU_ENTER(d);
   CRGPU_CHECK_CANCEL(d);
-  if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_consume: at most 2^31 rows per call");
+  // one batch may not use up the whole index bound by itself (the index is sized for stored rows + n): 2^28 rows per call
+  if (n < 0 || n > (int64_t(1) << 28)) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_distinct_consume: at most 2^28 rows per call; feed the input in smaller batches");
   if (n > 0 && cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null columns");
   const int nc = static_cast<int>(d->types.size());
   hipStream_t st = stream();

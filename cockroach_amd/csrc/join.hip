@@ -15,10 +15,17 @@
 //    rows per workgroup tile, ballot-compacted, one returning atomicAdd per
 //    8192-row tile to claim output space.
 //  * CHAINED table (multi-column / BYTES keys, duplicate build keys, RIGHT
-//    SEMI/ANTI, INTERSECT/EXCEPT ALL): first[nb]/next[n] chains built with
-//    atomicExch head insertion; probing is count -> exclusive scan -> fill
-//    (deterministic output offsets, no per-row atomics), then columns are
-//    materialised through (probe row, build row) pairs.
+//    SEMI/ANTI, INTERSECT/EXCEPT ALL): where the reference links rows through
+//    First/Next, the build rows are counting-sorted by hash bucket: cstart[nb+1]
+//    bucket boundaries, grp[n] row ids bucket by bucket and -- one integer key
+//    column -- gkey[n] 16-byte {key value, row id} entries, so a bucket walk reads
+//    consecutive memory; for other keys rep8[n] holds, per entry, the offset in its
+//    bucket of the first entry with an equal key (its representative: a probe row
+//    verifies one entry per distinct key).  The handle's `first` / `next` buffers
+//    hold the per-bucket counters and every row's bucket number while the table is
+//    built.  Probing is count -> exclusive scan -> fill (deterministic output
+//    offsets, no per-row atomics), then columns are materialised through
+//    (probe row, build row) pairs.
 //
 // Roofline: HBM-bound (random 16-byte slot reads + streaming columns).
 #include <cstring>

@@ -409,7 +409,10 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
 #pragma unroll
       for (int c = 0; c < 3 && !placed; c++) {
         const uint32_t old = atomicCAS(&tab[s[c]], kNone, cur);
-        if (old == kNone || srow[old].x == kcur) placed = true;  // free slot, or a duplicate key: first writer wins
+        // free slot, or a duplicate key: first writer wins.  (An eviction racing with this test can still leave two
+        // entries of one key in the table: harmless, because every lookup stops at the FIRST slot holding its key and
+        // the unique-key join paths need only one match.)
+        if (old == kNone || srow[old].x == kcur) placed = true;
       }
       if (placed) break;
       rnd = rnd * 1664525u + 1013904223u;

@@ -292,7 +292,9 @@ crgpu_status crgpu_dev_partition_noalloc(const int32_t *types, int32_t n_cols, c
  * batch and returns, in input order, all columns of the rows whose `distinct_cols` tuple was not seen before (in an
  * earlier call or earlier in this batch): the first occurrence is the one emitted, as in the reference.  NULLs
  * compare equal unless nulls_are_distinct (then a row with a NULL distinct column is always emitted).  With
- * error_on_dup the call returns CRGPU_ERR_DUPLICATE when it dropped a row (the result is still valid). */
+ * error_on_dup the call returns CRGPU_ERR_DUPLICATE when it dropped a row (the result is still valid).  At most 2^28
+ * rows per call (CRGPU_ERR_UNSUPPORTED beyond: feed smaller batches); CRGPU_ERR_OOM once the stored rows plus the
+ * incoming batch exceed 2^29 (a mostly-new batch is stored whole, so the bound counts rows, not distinct keys). */
 typedef struct crgpu_distinct crgpu_distinct;
 crgpu_status crgpu_dev_distinct_create(const int32_t *types, int32_t n_cols, const int32_t *distinct_cols,
                                        int32_t n_distinct, int32_t nulls_are_distinct, int32_t error_on_dup,

@@ -204,6 +204,28 @@ def agg_cases():
     return out
 
 
+def dropped_agg_pairs():
+    """(case id, aggregation ordinal, function, reason) of everything the GPU harness leaves out of the reference's
+    aggregation tables -- the list DESIGN.md section 6 prints; tests/test_oracle_agg.py pins it."""
+    out = []
+    for f in ("aggregator_cases.json", "hash_aggregator_cases.json"):
+        for c in load_cases(f):
+            cid = f.split("_cases")[0] + ":" + c["name"]
+            if c["has_unsupported_values"]:
+                out.append((cid, -1, "*", "value types outside the GPU path: " + ",".join(c["types"])))
+                continue
+            for i, fn in enumerate(c["agg_fns"]):
+                col = c["agg_cols"][i][0] if c["agg_cols"][i] else -1
+                t = c["types"][col] if col >= 0 else None
+                if fn not in SUPPORTED_AGGS:
+                    out.append((cid, i, fn, "function outside the GPU path"))
+                elif c.get("agg_distinct") and c["agg_distinct"][i]:
+                    out.append((cid, i, fn, "DISTINCT aggregation"))
+                elif fn in ("SUM", "AVG") and t != "float64" and type_id(t) != cd.FLOAT64:
+                    out.append((cid, i, fn, f"{fn} over {t}: DECIMAL result (apd)"))
+    return out
+
+
 def prepare_agg_case(c):
     """Returns (cols, group_cols, aggs[(func, col, filter)], expected_rows) keeping
     only the aggregations in scope (no DISTINCT, no CONCAT_AGG, SUM/AVG over
@@ -222,6 +244,7 @@ def prepare_agg_case(c):
         flt = c["agg_filter"][i] if c.get("agg_filter") else -1
         keep.append(i)
         aggs.append((AGG_FUNC[fn], col, flt))
+    c.setdefault("_dropped", [(i, fn) for i, fn in enumerate(c["agg_fns"]) if i not in keep])
     expected = []
     for r in c["expected"]:
         row = []

@@ -398,3 +398,26 @@ def test_agg_min_max_bytes_group_key_and_empty(oracle):
     assert len(G.gpu_agg(empty, [0], aggs)[0]) == 0
     nulls = [cd.Vec.from_values(cd.BYTES, [b"g"] * 5), cd.Vec.from_values(cd.BYTES, [None] * 5)]
     assert H.vecs_to_tuples(G.gpu_agg(nulls, [0], aggs)) == [(b"g", None, None, 5)]
+
+
+def test_agg_dropped_reference_columns_are_exactly_the_unsupported_specs():
+    """The (case, aggregation) pairs the harness leaves out of the reference's tables (helpers.dropped_agg_pairs, listed in
+    DESIGN.md section 6) are the ones crgpu_dev_agg_create answers with CRGPU_ERR_UNSUPPORTED -- the boundary at which the
+    planner keeps the CPU operator -- and nothing else is dropped."""
+    from cockroach_amd import _lib
+    from cockroach_amd import device as dev
+    dropped = H.dropped_agg_pairs()
+    assert len(dropped) == 11 and sum(1 for d in dropped if d[1] < 0) == 2
+    reasons = {d[3].split(":")[0] for d in dropped if d[1] >= 0}
+    assert reasons == {"function outside the GPU path", "DISTINCT aggregation"}
+    with pytest.raises(_lib.CrgpuError) as e:  # DISTINCT
+        dev.Agg([cd.INT64, cd.INT64], [0], [(F["COUNT"], 1, -1, True)])
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.CrgpuError) as e:  # CONCAT_AGG (execinfrapb.AggregatorSpec_CONCAT_AGG = 4)
+        dev.Agg([cd.INT64, cd.BYTES], [0], [(4, 1, -1)])
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    with pytest.raises(_lib.CrgpuError) as e:  # SUM over INT => DECIMAL
+        dev.Agg([cd.INT64, cd.INT64], [0], [(F["SUM"], 1, -1)])
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    for c in CASES:  # every surviving case keeps at least one aggregation
+        assert H.prepare_agg_case(c)[2], c["id"]
