@@ -154,7 +154,7 @@ def cpu_baseline_pway(lb, lp, P):
                       f"(ora_distribute, {t_route:.1f} s), then {P} joiner threads (ora_hash_join per bucket), {dt:.1f} s in all"}
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01", "bench_J_radix_pmc_summary.txt")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_J_pmc_summary.txt")
 KERNEL_SYMBOL = {"join_probe": "radix_probe_kernel<0, 0", "radix_build_split": "radix_split_kernel",
                  "radix_build_table": "radix_table_kernel"}
 
