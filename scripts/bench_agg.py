@@ -55,7 +55,7 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
     if expect is not None and expect != ngroups:
         raise SystemExit(f"{name}: {ngroups} groups, expected {expect}")
     kern = {}
-    for k in ("agg_fused_lds", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
+    for k in ("agg_fused_lds", "agg_fused_sumfam", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
               "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_part", "radix_build_hist",
               "radix_build_scatter", "radix_build_split"):
         ms, cnt = dev.prof_get(k)
@@ -104,7 +104,7 @@ def run_q1_full(n, dv, g, rf, ls, offs, f, reps):
     _lib.load().crgpu_dev_synchronize()
     dt = (time.perf_counter() - t0) / reps
     kern = {}
-    for k in ("expr_select", "expr_project", "agg_fused_lds", "agg_resolve", "agg_fixup", "agg_accum_lds"):
+    for k in ("expr_select", "expr_project", "agg_fused_lds", "agg_fused_sumfam", "agg_resolve", "agg_fixup", "agg_accum_lds"):
         ms, cnt = dev.prof_get(k)
         if cnt:
             kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
@@ -159,7 +159,7 @@ def run_q1_fused(n, dv, g, rf, ls, offs, f, reps):
     _lib.load().crgpu_dev_synchronize()
     dt = (time.perf_counter() - t0) / reps
     kern = {}
-    for k in ("agg_fused_lds", "agg_resolve", "agg_fixup", "agg_accum_lds"):
+    for k in ("agg_fused_lds", "agg_fused_sumfam", "agg_resolve", "agg_fixup", "agg_accum_lds"):
         ms, cnt = dev.prof_get(k)
         if cnt:
             kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}

@@ -256,7 +256,7 @@ def bench_router(lg, reps, dv, g, outputs):
     return _line(f"router repartition: (int64 key, int64 payload) into {outputs} outputs, 2^{lg} rows", n, dt, n * 32.0, kern, cpu)
 
 
-AGG_KERNELS = ["agg_fused_lds", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
+AGG_KERNELS = ["agg_fused_lds", "agg_fused_sumfam", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
                "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_part", "radix_build_hist",
                "radix_build_scatter", "radix_build_split"]
 
