@@ -2308,11 +2308,16 @@ struct crgpu_agg : crgpu::Handle {
   DevBuf p_cols[kMaxPartCols];
   std::vector<OutCol> out;
   std::vector<crgpu_dcol> views;
+  std::vector<AggOpDev> ops_stage;  // host staging of upload_descriptors
+  std::vector<void *> ptrs_stage;
 };
 
 // upload device descriptors (ops + key store) for the current buffers and the given chunk columns
 static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *chunk) {
-  std::vector<AggOpDev> ops(a->ops.size());
+  // (the staging vectors live in the handle, so the copies need not be waited for: they are rewritten by the next
+  // upload only, which every caller reaches after having waited for the stream)
+  std::vector<AggOpDev> &ops = a->ops_stage;
+  ops.assign(a->ops.size(), AggOpDev());
   for (size_t f = 0; f < a->ops.size(); f++) {
     const AggOpHost &h = a->ops[f];
     AggOpDev &d = ops[f];
@@ -2355,7 +2360,8 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
   }
   // pointer table of the BYTES ANY_NOT_NULL value stores: [off | len | buf] x naggs
   const size_t nops = a->ops.size();
-  std::vector<void *> ptrs(nops * 3, nullptr);
+  std::vector<void *> &ptrs = a->ptrs_stage;
+  ptrs.assign(nops * 3, nullptr);
   for (size_t f = 0; f < nops; f++) {
     ptrs[f] = a->ops[f].any_off.p;
     ptrs[nops + f] = a->ops[f].any_len.p;
@@ -2363,7 +2369,6 @@ static crgpu_status upload_descriptors(crgpu_agg *a, const std::vector<DCol> *ch
   }
   CRGPU_TRY(a->any_ptrs_dev.ensure(ptrs.size() * 8));
   CRGPU_HIP(hipMemcpyAsync(a->any_ptrs_dev.p, ptrs.data(), ptrs.size() * 8, hipMemcpyHostToDevice, stream()));
-  CRGPU_HIP(hipStreamSynchronize(stream()));  // the sources are stack/heap temporaries
   a->descriptors_dirty = false;
   return CRGPU_OK;
 }
@@ -3177,26 +3182,33 @@ static crgpu_status read_counters(crgpu_agg *a, unsigned int *out2) {
 static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, int64_t remaining) {
   hipStream_t st = stream();
   // BYTES key payload / BYTES ANY_NOT_NULL values: reserve room for every byte of the chunk
-  for (size_t k = 0; k < a->ks.size(); k++) {
-    const DCol &c = cols[a->group_cols[k]];
-    if (c.type != CRGPU_BYTES) continue;
-    uint32_t ends[1] = {0}, begins[1] = {0};
-    CRGPU_HIP(hipMemcpyAsync(begins, c.offsets, 4, hipMemcpyDeviceToHost, st));
-    CRGPU_HIP(hipMemcpyAsync(ends, c.offsets + n, 4, hipMemcpyDeviceToHost, st));
-    CRGPU_HIP(hipStreamSynchronize(st));
-    const size_t before = a->ks[k].b_buf.cap;
-    CRGPU_TRY(a->ks[k].b_buf.ensure(static_cast<size_t>(a->ks[k].tail + (ends[0] - begins[0]) + 16), true));
-    if (a->ks[k].b_buf.cap != before) a->descriptors_dirty = true;
-  }
-  for (size_t f = 0; f < a->ops.size(); f++) {
-    AggOpHost &op = a->ops[f];
-    if (!op.uses_any_store()) continue;
-    const DCol &c = cols[op.col];
-    uint32_t ends[1] = {0}, begins[1] = {0};
-    CRGPU_HIP(hipMemcpyAsync(begins, c.offsets, 4, hipMemcpyDeviceToHost, st));
-    CRGPU_HIP(hipMemcpyAsync(ends, c.offsets + n, 4, hipMemcpyDeviceToHost, st));
-    CRGPU_HIP(hipStreamSynchronize(st));
-    CRGPU_TRY(op.any_buf.ensure(static_cast<size_t>(op.any_tail + (ends[0] - begins[0]) + 16), true));
+  // (all the boundary offsets are requested together: one wait per chunk, not one per column)
+  {
+    std::vector<const DCol *> bcols;
+    for (size_t k = 0; k < a->ks.size(); k++)
+      if (cols[a->group_cols[k]].type == CRGPU_BYTES) bcols.push_back(&cols[a->group_cols[k]]);
+    for (size_t f = 0; f < a->ops.size(); f++)
+      if (a->ops[f].uses_any_store()) bcols.push_back(&cols[a->ops[f].col]);
+    std::vector<uint32_t> bounds(bcols.size() * 2 + 2, 0);
+    for (size_t i = 0; i < bcols.size(); i++) {
+      CRGPU_HIP(hipMemcpyAsync(&bounds[2 * i], bcols[i]->offsets, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(&bounds[2 * i + 1], bcols[i]->offsets + n, 4, hipMemcpyDeviceToHost, st));
+    }
+    if (!bcols.empty()) CRGPU_HIP(hipStreamSynchronize(st));
+    size_t i = 0;
+    for (size_t k = 0; k < a->ks.size(); k++) {
+      if (cols[a->group_cols[k]].type != CRGPU_BYTES) continue;
+      const size_t before = a->ks[k].b_buf.cap;
+      CRGPU_TRY(a->ks[k].b_buf.ensure(static_cast<size_t>(a->ks[k].tail + (bounds[2 * i + 1] - bounds[2 * i]) + 16), true));
+      if (a->ks[k].b_buf.cap != before) a->descriptors_dirty = true;
+      i++;
+    }
+    for (size_t f = 0; f < a->ops.size(); f++) {
+      AggOpHost &op = a->ops[f];
+      if (!op.uses_any_store()) continue;
+      CRGPU_TRY(op.any_buf.ensure(static_cast<size_t>(op.any_tail + (bounds[2 * i + 1] - bounds[2 * i]) + 16), true));
+      i++;
+    }
   }
   CRGPU_TRY(upload_descriptors(a, &cols));  // the chunk's column pointers are part of the op descriptors
 
@@ -3342,7 +3354,7 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
     in.m = ndef;
   }
   // the BYTES append positions live on the device; the host copy sizes the next reservation
-  if (a->bytes_keys) {
+  if (a->bytes_keys && a->ngroups != groups_before) {  // (no new group: no key bytes were appended)
     unsigned long long tails[kMaxKeyCols];
     CRGPU_HIP(hipMemcpyAsync(tails, a->tails_dev.p, kMaxKeyCols * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
