@@ -1074,17 +1074,27 @@ __global__ __launch_bounds__(1024) void agg_accum_kernel(AccArgs a) {
   }
 }
 
-// ------------------------------------------------------------------ the sum family, deduplicated (fused pass, LDS, packed keys)
+// ------------------------------------------------------------------ deduplicated inputs (fused pass, LDS, packed keys)
 // Q1-style aggregation lists name few INPUTS many times: SUM(qty) and AVG(qty), SUM(price) and AVG(price), every AVG
 // with its own count, COUNT_ROWS -- eleven accumulator words over five distinct NULL-free FLOAT64 inputs under one
-// WHERE.  When every aggregation of the handle is COUNT_ROWS / COUNT / SUM / AVG over NULL-free FLOAT64 inputs (plain
-// or computed) and they share their FILTER, the generic pass (one load + one or two LDS atomics + a uniform switch PER
-// AGGREGATION and row) is replaced by this one: every distinct input is loaded and summed ONCE per row (NIN LDS
-// f64 atomics + one row count), with the inputs unrolled at compile time, and the aggregations are told apart only
-// when the partial table is merged: SUM / AVG take their input's sum, AVG and the counts the row count.
+// WHERE; SUM_INT(x), MIN(x), MAX(x), COUNT_ROWS is one input with four.  When every aggregation of the handle is
+// COUNT_ROWS / COUNT / SUM / AVG / SUM_INT / MIN / MAX / BOOL_AND / BOOL_OR over NULL-free inputs (plain columns or
+// computed FLOAT64 ones) and they share their FILTER, the generic pass (one load + one or two LDS atomics + a uniform
+// switch PER AGGREGATION and row) is replaced by this one: every distinct input is loaded ONCE per row, with the inputs
+// unrolled at compile time, and feeds only the accumulations somebody needs of it (sum, min, max: one LDS atomic each)
+// beside ONE row count; the aggregations are told apart only when the partial table is merged: SUM / AVG take their
+// input's sum, AVG and the counts the row count, BOOL_AND / BOOL_OR the min / max of a 0/1 input.
 static constexpr int kSfMaxIn = 8;
+static constexpr int kSfMaxPlanes = 24;
+struct SfIn {
+  const void *x;        // typed by `type`
+  const double *y, *z;  // computed FLOAT64 inputs: value = op2(op1(x, y), z)
+  int8_t op1, op2, type;
+  int8_t p_sum, p_hi, p_min, p_max;  // planes of the partial table (-1: nobody needs that accumulation of this input)
+  int8_t _pad;
+};
 struct SfOp {
-  int8_t kind, in;  // in: index of the distinct input (SUM / AVG)
+  int8_t kind, in;  // in: index of the distinct input
   int8_t _p[6];
   unsigned long long *w0, *w1;
   uint8_t *seen;
@@ -1093,7 +1103,7 @@ struct SfArgs {
   KeyCols keys;
   KeyStore store;
   PackSpec pack;
-  VExpr in[kSfMaxIn];  // op1 < 0: the plain column x
+  SfIn in[kSfMaxIn];
   VSel cf_sel;
   const uint8_t *cf_data, *cf_valid;
   int32_t cf_kind;     // 0 none, 1 BOOL column, 2 cf_sel
@@ -1102,6 +1112,8 @@ struct SfArgs {
   int64_t m;
   const unsigned long long *meta;
   uint32_t mask, G, R, C;
+  uint32_t nplanes, _pad;
+  unsigned long long plane_init[kSfMaxPlanes];
   uint32_t *miss_list;
   unsigned int *counters;
 };
@@ -1111,14 +1123,16 @@ template <int NIN>
 __global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
   extern __shared__ unsigned long long lds_words[];
   const uint32_t plane = (a.G + 1) * a.R;  // G groups + the trash group, R replicas each
-  unsigned long long *cnt = lds_words;                                   // [plane]
-  double *sums = reinterpret_cast<double *>(lds_words + plane);          // [NIN][plane]
-  unsigned long long *t_k0 = lds_words + static_cast<size_t>(NIN + 1) * plane;
+  unsigned long long *cnt = lds_words;     // plane 0: rows; planes 1..: [nplanes][plane]
+  unsigned long long *t_k0 = lds_words + static_cast<size_t>(a.nplanes) * plane;
   unsigned long long *t_k1 = t_k0 + a.C;
   uint32_t *t_gid = reinterpret_cast<uint32_t *>(a.pack.two_words ? t_k1 + a.C : t_k1);
   const KeyStore &store = a.store;
   for (uint32_t i = threadIdx.x; i < a.C; i += blockDim.x) t_gid[i] = kGidDefer;
-  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NIN + 1) * plane; i += blockDim.x) lds_words[i] = 0ull;
+  for (uint32_t p = 0; p < a.nplanes; p++) {
+    const unsigned long long init = a.plane_init[p];
+    for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(p) * plane + i] = init;
+  }
   __syncthreads();
   for (uint32_t g = threadIdx.x; g < a.G; g += blockDim.x) {
     unsigned long long k0, k1;
@@ -1145,24 +1159,43 @@ __global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
       row[k] = ok[k] ? i : 0;
       gid[k] = kGidDefer;
     }
-    // every input column of the rows is requested before the key lookup resolves
-    double v[NIN][kAccRows];
+    // every input column of the rows is requested before the key lookup resolves; values travel as 64-bit words
+    // (FLOAT64 bits, sign-extended integers, 0/1)
+    unsigned long long v[NIN][kAccRows];
 #pragma unroll
     for (int c = 0; c < NIN; c++) {
-      const VExpr &e = a.in[c];
+      const SfIn &e = a.in[c];
+      switch (e.type) {
+        case CRGPU_BOOL:
 #pragma unroll
-      for (int k = 0; k < kAccRows; k++) v[c][k] = e.x[row[k]];
+          for (int k = 0; k < kAccRows; k++) v[c][k] = reinterpret_cast<const uint8_t *>(e.x)[row[k]] != 0;
+          break;
+        case CRGPU_INT16:
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) v[c][k] = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int16_t *>(e.x)[row[k]]));
+          break;
+        case CRGPU_INT32:
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) v[c][k] = static_cast<unsigned long long>(static_cast<long long>(reinterpret_cast<const int32_t *>(e.x)[row[k]]));
+          break;
+        default:
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) v[c][k] = reinterpret_cast<const unsigned long long *>(e.x)[row[k]];
+          break;
+      }
       if (e.op1 >= 0) {
         double y[kAccRows];
 #pragma unroll
         for (int k = 0; k < kAccRows; k++) y[k] = e.y[row[k]];
 #pragma unroll
-        for (int k = 0; k < kAccRows; k++) v[c][k] = ex_apply(e.op1, v[c][k], y[k]);
+        for (int k = 0; k < kAccRows; k++)
+          v[c][k] = static_cast<unsigned long long>(__double_as_longlong(ex_apply(e.op1, __longlong_as_double(static_cast<long long>(v[c][k])), y[k])));
         if (e.op2 >= 0) {
 #pragma unroll
           for (int k = 0; k < kAccRows; k++) y[k] = e.z[row[k]];
 #pragma unroll
-          for (int k = 0; k < kAccRows; k++) v[c][k] = ex_apply(e.op2, v[c][k], y[k]);
+          for (int k = 0; k < kAccRows; k++)
+            v[c][k] = static_cast<unsigned long long>(__double_as_longlong(ex_apply(e.op2, __longlong_as_double(static_cast<long long>(v[c][k])), y[k])));
         }
       }
     }
@@ -1241,8 +1274,39 @@ __global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
     for (int k = 0; k < kAccRows; k++) atomicAdd(cnt + at[k], 1ull);
 #pragma unroll
     for (int c = 0; c < NIN; c++) {
+      const SfIn &e = a.in[c];
+      const bool f64 = e.type == CRGPU_FLOAT64;
+      if (e.p_sum >= 0) {
+        unsigned long long *ps = lds_words + static_cast<size_t>(e.p_sum) * plane;
+        if (f64) {
 #pragma unroll
-      for (int k = 0; k < kAccRows; k++) unsafeAtomicAdd(sums + static_cast<size_t>(c) * plane + at[k], v[c][k]);
+          for (int k = 0; k < kAccRows; k++) unsafeAtomicAdd(reinterpret_cast<double *>(ps + at[k]), __longlong_as_double(static_cast<long long>(v[c][k])));
+        } else {
+          unsigned long long *ph = lds_words + static_cast<size_t>(e.p_hi) * plane;
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) add_i128(ps + at[k], ph + at[k], v[c][k], (v[c][k] >> 63) ? ~0ull : 0ull);
+        }
+      }
+      if (e.p_min >= 0) {
+        unsigned long long *pm = lds_words + static_cast<size_t>(e.p_min) * plane;
+        if (f64) {
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) atomicMin(pm + at[k], f64_to_ordered(__longlong_as_double(static_cast<long long>(v[c][k]))));
+        } else {
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) atomicMin(reinterpret_cast<long long *>(pm + at[k]), static_cast<long long>(v[c][k]));
+        }
+      }
+      if (e.p_max >= 0) {
+        unsigned long long *pm = lds_words + static_cast<size_t>(e.p_max) * plane;
+        if (f64) {
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) atomicMax(pm + at[k], f64_to_ordered(__longlong_as_double(static_cast<long long>(v[c][k]))));
+        } else {
+#pragma unroll
+          for (int k = 0; k < kAccRows; k++) atomicMax(reinterpret_cast<long long *>(pm + at[k]), static_cast<long long>(v[c][k]));
+        }
+      }
     }
   }
   __syncthreads();
@@ -1254,22 +1318,61 @@ __global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
     unsigned long long c = 0;
     for (uint32_t r = 0; r < a.R; r++) c += cnt[g * a.R + r];
     if (c == 0) continue;
-    double sm = 0;
-    if (op.kind == ACC_SUM_F64 || op.kind == ACC_AVG_F64) {
-      const double *ps = sums + static_cast<size_t>(op.in) * plane + g * a.R;
-      for (uint32_t r = 0; r < a.R; r++) sm += ps[r];
-    }
+    const SfIn &e = a.in[op.in >= 0 ? op.in : 0];
     switch (op.kind) {
       case ACC_COUNT_ROWS:
       case ACC_COUNT: atomicAdd(&op.w0[g], c); break;
       case ACC_SUM_F64:
+      case ACC_AVG_F64: {
+        const unsigned long long *ps = lds_words + static_cast<size_t>(e.p_sum) * plane + g * a.R;
+        double sm = 0;
+        for (uint32_t r = 0; r < a.R; r++) sm += __longlong_as_double(static_cast<long long>(ps[r]));
         unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[g]), sm);
+        if (op.kind == ACC_AVG_F64) atomicAdd(&op.w1[g], c);
+        else op.seen[g] = 1;
+        break;
+      }
+      case ACC_SUM_I128: {
+        const unsigned long long *pl = lds_words + static_cast<size_t>(e.p_sum) * plane + g * a.R;
+        const unsigned long long *ph = lds_words + static_cast<size_t>(e.p_hi) * plane + g * a.R;
+        unsigned long long lo = 0, hi = 0;
+        for (uint32_t r = 0; r < a.R; r++) {
+          const unsigned long long sl = lo + pl[r];
+          hi += ph[r] + (sl < lo ? 1ull : 0ull);
+          lo = sl;
+        }
+        add_i128(&op.w0[g], &op.w1[g], lo, hi);
         op.seen[g] = 1;
         break;
-      default:  // AVG
-        unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[g]), sm);
-        atomicAdd(&op.w1[g], c);
+      }
+      case ACC_MIN_I64:
+      case ACC_MAX_I64:
+      case ACC_BOOL_AND:
+      case ACC_BOOL_OR: {
+        const bool is_min = op.kind == ACC_MIN_I64 || op.kind == ACC_BOOL_AND;
+        const unsigned long long *pm = lds_words + static_cast<size_t>(is_min ? e.p_min : e.p_max) * plane + g * a.R;
+        long long m = static_cast<long long>(pm[0]);
+        for (uint32_t r = 1; r < a.R; r++) {
+          const long long x = static_cast<long long>(pm[r]);
+          m = is_min ? (x < m ? x : m) : (x > m ? x : m);
+        }
+        if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(&op.w0[g]), m);
+        else if (op.kind == ACC_MAX_I64) atomicMax(reinterpret_cast<long long *>(&op.w0[g]), m);
+        else if (op.kind == ACC_BOOL_AND) { if (m == 0) atomicAnd(&op.w0[g], 0ull); }
+        else { if (m != 0) atomicOr(&op.w0[g], 1ull); }
+        op.seen[g] = 1;
         break;
+      }
+      default: {  // MIN / MAX over FLOAT64 (ordered words)
+        const bool is_min = op.kind == ACC_MIN_F64;
+        const unsigned long long *pm = lds_words + static_cast<size_t>(is_min ? e.p_min : e.p_max) * plane + g * a.R;
+        unsigned long long m = pm[0];
+        for (uint32_t r = 1; r < a.R; r++) m = is_min ? (pm[r] < m ? pm[r] : m) : (pm[r] > m ? pm[r] : m);
+        if (is_min) atomicMin(&op.w0[g], m);
+        else atomicMax(&op.w0[g], m);
+        op.seen[g] = 1;
+        break;
+      }
     }
   }
 }
@@ -3072,12 +3175,12 @@ static crgpu_status try_sumfam(crgpu_agg *a, const PassInput &in, uint32_t *miss
   if (!enabled || !plan.lds || !plan.pk || plan.sweeps != 1 || in.list != nullptr) return CRGPU_OK;
   SfArgs args;
   std::memset(&args, 0, sizeof(args));
-  int nin = 0, nops = 0;
+  int nin = 0, nops = 0, nplanes = 1;  // plane 0: rows
   int cf_col = -2, cf_cmp = -2;
   long long cf_cst = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
-    if (h.kind != ACC_COUNT_ROWS && h.kind != ACC_COUNT && h.kind != ACC_SUM_F64 && h.kind != ACC_AVG_F64) return CRGPU_OK;
+    if (h.kind == ACC_ANY_ROW || is_minmax_bytes(h.kind)) return CRGPU_OK;
     if (nops == kMaxOpsPerLaunch) return CRGPU_OK;
     if (cf_col == -2) cf_col = h.filter_col, cf_cmp = h.f_cmp, cf_cst = h.f_cst;
     if (h.filter_col != cf_col || h.f_cmp != cf_cmp || h.f_cst != cf_cst) return CRGPU_OK;  // one FILTER for all
@@ -3093,23 +3196,63 @@ static crgpu_status try_sumfam(crgpu_agg *a, const PassInput &in, uint32_t *miss
     for (int c : cs)
       if (c >= 0 && (*in.cols)[c].valid != nullptr) return CRGPU_OK;
     if (h.kind == ACC_COUNT) continue;
-    if (h.in_type != CRGPU_FLOAT64) return CRGPU_OK;
-    VExpr e;
+    if (h.in_type == CRGPU_BYTES) return CRGPU_OK;
+    SfIn e;
     std::memset(&e, 0, sizeof(e));
-    e.x = static_cast<const double *>((*in.cols)[h.col].data);
+    e.x = (*in.cols)[h.col].data;
+    e.type = static_cast<int8_t>(h.in_type);
     e.op1 = static_cast<int8_t>(h.e_op1 >= 0 ? h.e_op1 : -1);
     e.op2 = static_cast<int8_t>(h.e_op1 >= 0 && h.e_op2 >= 0 ? h.e_op2 : -1);
     if (e.op1 >= 0) e.y = static_cast<const double *>((*in.cols)[h.col2].data);
     if (e.op2 >= 0) e.z = static_cast<const double *>((*in.cols)[h.col3].data);
+    e.p_sum = e.p_hi = e.p_min = e.p_max = -1;
     int at = -1;
     for (int i = 0; i < nin && at < 0; i++)
-      if (std::memcmp(&args.in[i], &e, sizeof(e)) == 0) at = i;
+      if (args.in[i].x == e.x && args.in[i].y == e.y && args.in[i].z == e.z && args.in[i].op1 == e.op1 && args.in[i].op2 == e.op2 &&
+          args.in[i].type == e.type)
+        at = i;
     if (at < 0) {
       if (nin == kSfMaxIn) return CRGPU_OK;
       at = nin;
       args.in[nin++] = e;
     }
     op.in = static_cast<int8_t>(at);
+    SfIn &si = args.in[at];
+    const bool f64 = h.in_type == CRGPU_FLOAT64;
+    auto new_plane = [&](unsigned long long init) -> int8_t {
+      if (nplanes >= kSfMaxPlanes) return -1;
+      args.plane_init[nplanes] = init;
+      return static_cast<int8_t>(nplanes++);
+    };
+    switch (h.kind) {
+      case ACC_SUM_F64:
+      case ACC_AVG_F64:
+        if (si.p_sum < 0) si.p_sum = new_plane(0);
+        break;
+      case ACC_SUM_I128:
+        if (si.p_sum < 0) { si.p_sum = new_plane(0); si.p_hi = new_plane(0); }
+        break;
+      case ACC_MIN_I64:
+      case ACC_BOOL_AND:
+        if (si.p_min < 0) si.p_min = new_plane(0x7FFFFFFFFFFFFFFFull);
+        break;
+      case ACC_MAX_I64:
+      case ACC_BOOL_OR:
+        if (si.p_max < 0) si.p_max = new_plane(0x8000000000000000ull);
+        break;
+      case ACC_MIN_F64:
+        if (si.p_min < 0) si.p_min = new_plane(~0ull);
+        break;
+      case ACC_MAX_F64:
+        if (si.p_max < 0) si.p_max = new_plane(0ull);
+        break;
+      default: return CRGPU_OK;
+    }
+    (void)f64;
+    if ((h.kind == ACC_SUM_F64 || h.kind == ACC_AVG_F64) && si.p_sum < 0) return CRGPU_OK;
+    if (h.kind == ACC_SUM_I128 && (si.p_sum < 0 || si.p_hi < 0)) return CRGPU_OK;
+    if ((h.kind == ACC_MIN_I64 || h.kind == ACC_BOOL_AND || h.kind == ACC_MIN_F64) && si.p_min < 0) return CRGPU_OK;
+    if ((h.kind == ACC_MAX_I64 || h.kind == ACC_BOOL_OR || h.kind == ACC_MAX_F64) && si.p_max < 0) return CRGPU_OK;
   }
   if (nops == 0 || nin == 0) return CRGPU_OK;
   if (cf_col >= 0) {
@@ -3126,10 +3269,10 @@ static crgpu_status try_sumfam(crgpu_agg *a, const PassInput &in, uint32_t *miss
       args.cf_valid = fc.valid;
     }
   }
-  // partial table: (nin + 1) planes of (G + 1) x R words + the key table
+  // partial table: nplanes planes of (G + 1) x R words + the key table
   const size_t G = plan.G;
   const size_t table = static_cast<size_t>(plan.C) * (a->pack.two_words ? 20 : 12) + 8;
-  const size_t per_rep = static_cast<size_t>(nin + 1) * (G + 1) * 8;
+  const size_t per_rep = static_cast<size_t>(nplanes) * (G + 1) * 8;
   if (per_rep + table > kLdsLarge) return CRGPU_OK;
   uint32_t R = 1;
   while (R < static_cast<uint32_t>(kMaxReplicas) && per_rep * (R * 2) + table <= kLdsReplicated) R *= 2;
@@ -3141,6 +3284,7 @@ static crgpu_status try_sumfam(crgpu_agg *a, const PassInput &in, uint32_t *miss
   args.store = a->store_host;
   args.pack = a->pack;
   args.nops = nops;
+  args.nplanes = static_cast<uint32_t>(nplanes);
   args.m = in.m;
   args.meta = a->meta.as<unsigned long long>();
   args.mask = a->cap - 1;
