@@ -48,10 +48,18 @@ struct Special {  // the one build key whose packed value equals kEmptyKey
   unsigned long long val;
 };
 
+// Key bitmap in front of a packed table that does not fit the L2 (tables of 2 MiB ... 128 MiB: build sides below the
+// radix threshold): one bit per hash value, 16 bits per build key, at most 2 MiB -- L2-resident.  A probe row whose bit
+// is clear has no match and never touches the table; a selective join (TPC-H Q9: 5 % of the lineitems find their
+// part) then reads ~one random HBM / Infinity-Cache line per SURVIVING row instead of one per row.  The bit index uses
+// hash bits the slot index does not.
+__device__ __forceinline__ uint32_t bloom_bit(uint64_t h, uint32_t bmask) { return static_cast<uint32_t>(h >> 36) & bmask; }
+
 // ------------------------------------------------------------------ PACKED build
 __global__ __launch_bounds__(256) void packed_build_kernel(KeyPack kp, int64_t n, Slot *__restrict__ slots,
                                                            uint64_t mask, const uint64_t *__restrict__ payload,
-                                                           Special *__restrict__ special) {
+                                                           Special *__restrict__ special, uint32_t *__restrict__ bloom,
+                                                           uint32_t bmask) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
     uint64_t k;
@@ -61,7 +69,12 @@ __global__ __launch_bounds__(256) void packed_build_kernel(KeyPack kp, int64_t n
       if (atomicCAS(&special->present, 0u, 1u) == 0u) special->val = v;
       continue;
     }
-    uint64_t idx = fmix64(k) & mask;
+    const uint64_t hk = fmix64(k);
+    if (bloom != nullptr) {
+      const uint32_t bit = bloom_bit(hk, bmask);
+      atomicOr(&bloom[bit >> 5], 1u << (bit & 31));
+    }
+    uint64_t idx = hk & mask;
     while (true) {
       unsigned long long old = atomicCAS(&slots[idx].key, kEmptyKey, static_cast<unsigned long long>(k));
       if (old == kEmptyKey) {
@@ -98,6 +111,8 @@ struct ProbeArgs {
   int32_t *pair_b;
   uint8_t *matched;  // optional build-row matched flags (RIGHT/FULL OUTER)
   unsigned long long *out_count;
+  const uint32_t *bloom;  // optional key bitmap (bloom_bit): a clear bit = no match, the table is not read
+  uint32_t bmask, _pad2;
 };
 
 __device__ __forceinline__ void store_width(uint8_t *dst, int64_t pos, int width, uint64_t v) {
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
     uint64_t k[RPT];
     unsigned long long val[RPT];
     bool found[RPT], inb[RPT], emit[RPT];
-    uint64_t idx[RPT];
+    uint64_t idx[RPT], hk[RPT];
     Slot s[RPT];
     // issue every first-step slot load of the tile before resolving any (memory-level parallelism)
 #pragma unroll
@@ -151,7 +166,19 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
           val[j] = a.special->val;
         }
       }
-      idx[j] = fmix64(k[j]) & a.mask;
+      hk[j] = fmix64(k[j]);
+      idx[j] = hk[j] & a.mask;
+    }
+    if (a.bloom != nullptr) {  // all bitmap words of the tile's rows first (L2 hits), then the table for the survivors
+      uint32_t w[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) w[j] = k[j] != kEmptyKey ? a.bloom[bloom_bit(hk[j], a.bmask) >> 5] : 0u;
+#pragma unroll
+      for (int j = 0; j < RPT; j++)
+        if (k[j] != kEmptyKey && !((w[j] >> (bloom_bit(hk[j], a.bmask) & 31)) & 1u)) k[j] = kEmptyKey;  // (found stays false)
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
       if (k[j] != kEmptyKey) {
         const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&a.slots[idx[j]]);
         s[j].key = raw.x;
@@ -703,6 +730,9 @@ struct crgpu_join : crgpu::Handle {
 
   // packed table
   DevBuf slots, special;
+  DevBuf bloom;             // key bitmap in front of a packed table larger than the L2 (bloom_bit)
+  uint32_t bloom_mask = 0;
+  bool bloom_on = false;    // built with the table; switched off after a probe chunk in which most rows matched
   DevBuf mcache;  // chained probe: first matches of every probe row (pass 1 -> pass 3)
   uint64_t cap = 0;
   bool covering = false;
@@ -995,6 +1025,17 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
       CRGPU_TRY(j->special.ensure(sizeof(Special)));
       CRGPU_HIP(hipMemsetAsync(j->slots.p, 0xFF, j->cap * sizeof(Slot), st));
       CRGPU_HIP(hipMemsetAsync(j->special.p, 0, sizeof(Special), st));
+      j->bloom_on = false;
+      const char *bloom_env = std::getenv("CRGPU_JOIN_BLOOM");  // "0": no key bitmap (tests, measurements)
+      const bool bloom_enabled = bloom_env == nullptr || bloom_env[0] != '0';
+      if (bloom_enabled && n > 0 && j->cap * sizeof(Slot) > (size_t(2) << 20)) {  // the table will not stay in an XCD's L2
+        uint64_t bits = 1u << 16;
+        while (bits < static_cast<uint64_t>(n) * 16 && bits < (uint64_t(1) << 24)) bits <<= 1;
+        CRGPU_TRY(j->bloom.ensure(bits / 8));
+        CRGPU_HIP(hipMemsetAsync(j->bloom.p, 0, bits / 8, st));
+        j->bloom_mask = static_cast<uint32_t>(bits - 1);
+        j->bloom_on = true;
+      }
     }
     if (n > 0 && !j->use_radix) {
       const uint64_t *payload = (j->covering && j->cover_col >= 0)
@@ -1002,7 +1043,8 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
                                     : nullptr;
       ProfScope prof("join_build");
       hipLaunchKernelGGL(packed_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, j->kp, n,
-                         j->slots.as<Slot>(), j->cap - 1, payload, j->special.as<Special>());
+                         j->slots.as<Slot>(), j->cap - 1, payload, j->special.as<Special>(),
+                         j->bloom_on ? j->bloom.as<uint32_t>() : nullptr, j->bloom_mask);
       CRGPU_HIP(hipGetLastError());
     }
   }
@@ -1133,6 +1175,8 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
   a.mask = j->cap - 1;
   a.special = j->special.as<Special>();
   a.matched = j->track_build_matches ? j->matched.as<uint8_t>() : nullptr;
+  a.bloom = j->bloom_on ? j->bloom.as<uint32_t>() : nullptr;
+  a.bmask = j->bloom_mask;
   CRGPU_TRY(j->counter.ensure(8));
   CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
   a.out_count = j->counter.as<unsigned long long>();
@@ -1202,6 +1246,8 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
     }
     CRGPU_HIP(hipMemcpyAsync(&nout, j->counter.p, 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
+    // where most probe rows match the bitmap only adds a read per row: the following chunks go straight to the table
+    if (j->bloom_on && (jt == CRGPU_INNER || jt == CRGPU_LEFT_SEMI) && n >= 4096 && nout * 10 > static_cast<uint64_t>(n) * 7) j->bloom_on = false;
   }
   for (int c = 0; c < a.ncopy; c++)  // pack the validity bytes of fused nullable columns into bitmaps
     if (a.copy[c].dst_valid != nullptr)

@@ -29,17 +29,22 @@ def gpu_join(join_type, left, right, left_eq, right_eq, right_key=False, probe_c
     return rows
 
 
-def gpu_join_vecs(join_type, left, right, left_eq, right_eq, right_key=False):
-    """Same, but returns host Vecs of the probe result and of emit_right (for large inputs)."""
+def gpu_join_vecs(join_type, left, right, left_eq, right_eq, right_key=False, probe_chunks=1):
+    """Same, but returns host Vecs of the probe result (probe_chunks > 1: one list of Vecs per chunk) and of emit_right
+    (for large inputs)."""
     jt = H.JOIN_TYPE[join_type] if isinstance(join_type, str) else join_type
     j = dev.Join(jt, [v.type for v in left], [v.type for v in right], left_eq, right_eq, right_key)
     rcols = [dev.upload(v) for v in right]
     j.build(rcols, len(right[0]))
-    lcols = [dev.upload(v) for v in left]
-    a = dev.result_to_vecs(j.probe(lcols, len(left[0])))
+    nleft = len(left[0])
+    bounds = np.linspace(0, nleft, probe_chunks + 1).astype(np.int64)
+    parts = []
+    for s, e in zip(bounds[:-1], bounds[1:]):
+        chunk = [v.slice(int(s), int(e)) for v in left] if probe_chunks > 1 else left
+        parts.append(dev.result_to_vecs(j.probe([dev.upload(v) for v in chunk], int(e - s))))
     b = dev.result_to_vecs(j.emit_right())
     j.close()
-    return a, b
+    return (parts[0] if probe_chunks == 1 else parts), b
 
 
 def rows_as_sorted_array(vecs, n=None):

@@ -162,6 +162,37 @@ def test_join_packed_covering_large():
     j.close()
 
 
+@pytest.mark.parametrize("bitmap", ["1", "0"])
+@pytest.mark.parametrize("two_cols", [False, True])
+def test_join_packed_key_bitmap_selective_probe(oracle, bitmap, two_cols, monkeypatch):
+    """A packed table beyond 2 MiB gets a key bitmap in front of it (join.hip, bloom_bit): a probe row whose bit is clear
+    never reads the table.  Selective probes (5 % hits), then a chunk of hits only (which switches the bitmap off for
+    INNER / LEFT_SEMI), with the key equal to the table's empty marker on both sides; two handles in a row."""
+    monkeypatch.setenv("CRGPU_JOIN_BLOOM", bitmap)
+    rng = np.random.default_rng(17)
+    nb, npr = 150_000, 400_000
+    space = nb * 20
+    bk = rng.permutation(space)[:nb].astype(np.int64)
+    pk = rng.integers(0, space, size=npr, dtype=np.int64)
+    pk[150_000:200_000] = rng.choice(bk, size=50_000)  # the 4th of 8 chunks: hits only
+    if not two_cols:
+        bk[0], pk[5], pk[-7] = -1, -1, -1
+        lkeys, rkeys = [cd.Vec.from_numpy(cd.INT64, pk, rng.random(npr) >= 0.02)], [cd.Vec.from_numpy(cd.INT64, bk)]
+    else:
+        lkeys = [cd.Vec.from_numpy(cd.INT64, pk // 1000), cd.Vec.from_numpy(cd.INT32, (pk % 1000).astype(np.int32), rng.random(npr) >= 0.02)]
+        rkeys = [cd.Vec.from_numpy(cd.INT64, bk // 1000), cd.Vec.from_numpy(cd.INT32, (bk % 1000).astype(np.int32))]
+    nk = len(lkeys)
+    left = lkeys + [cd.Vec.from_numpy(cd.INT64, np.arange(npr, dtype=np.int64))]
+    right = rkeys + [cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(nb))]
+    eq = list(range(nk))
+    for jt in ("INNER", "LEFT_SEMI", "LEFT_ANTI", "LEFT_OUTER"):
+        want = G.rows_as_sorted_array(oracle.hash_join(H.JOIN_TYPE[jt], left, right, eq, eq, True))
+        parts, got_right = G.gpu_join_vecs(jt, left, right, eq, eq, True, probe_chunks=8)
+        assert len(got_right) == 0 or len(got_right[0]) == 0
+        got = np.concatenate([G.rows_as_sorted_array(p) for p in parts])
+        assert np.array_equal(got[np.lexsort(got.T[::-1])], want), (jt, bitmap, two_cols)
+
+
 # ---------------------------------------------------------------------------
 # radix-partitioned path (csrc/radix.hip): forced on for small inputs through the
 # CRGPU_RADIX_MIN_BUILD / CRGPU_RADIX_MIN_PROBE environment overrides
