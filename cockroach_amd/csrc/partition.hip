@@ -7,12 +7,14 @@
 // (pkg/sql/colflow/routers.go:683-715).  Instead of P selection vectors over
 // 1024-row batches, the whole input is regrouped in two streaming passes into
 // P contiguous regions (the send buffers of the all-to-all):
-//   pass 1: dest = hash64 % P per row (cached as uint16) + per-tile histograms in LDS;
+//   pass 1: dest = hash64 % P per row + per-tile histograms in LDS (dest kept as uint16 only for BYTES hash columns);
 //   scan  : exclusive scan of the P x ntiles histogram (partition-major);
-//   pass 2: each 4096-row tile scatters its rows to base[p][tile] + rank.
+//   pass 2: each 4096-row tile counting-sorts its rows by destination in LDS, column by column, and writes every
+//           destination's run base[p][tile] + 0.. as whole lines (part_scatter_lds_kernel).
 // Same hash as the reference, so a mixed CPU/GPU cluster co-locates equal keys.
 //
 // Roofline: HBM streaming; algorithmic bytes/row = row width read + row width written.
+#include <cstdlib>
 #include <cstring>
 
 #include "device.h"
@@ -34,15 +36,23 @@ __global__ __launch_bounds__(kPartBlock) void part_hist_kernel(KeyCols keys, int
   const int64_t tile = blockIdx.x;
   const int64_t base = tile * kPartTile;
   const bool pow2 = (P & (P - 1)) == 0;
+  // all of a thread's rows are requested before the first is hashed (LDS atomics per row are not the bound: counting in
+  // registers and adding up per wave measured slower)
+  uint32_t dd[kPartItems];
 #pragma unroll 4
   for (int k = 0; k < kPartItems; k++) {
     const int64_t i = base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x;
+    dd[k] = 0xFFFFFFFFu;
     if (i < n) {
       const uint64_t h = hash_row64(keys, i, init);
-      const uint32_t d = pow2 ? static_cast<uint32_t>(h & (P - 1)) : static_cast<uint32_t>(h % P);  // finalizeHash
-      dest[i] = static_cast<uint16_t>(d);
-      atomicAdd(&s_hist[d], 1u);
+      dd[k] = pow2 ? static_cast<uint32_t>(h & (P - 1)) : static_cast<uint32_t>(h % P);  // finalizeHash
     }
+  }
+#pragma unroll
+  for (int k = 0; k < kPartItems; k++) {
+    if (dd[k] == 0xFFFFFFFFu) continue;
+    if (dest != nullptr) dest[base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x] = static_cast<uint16_t>(dd[k]);
+    atomicAdd(&s_hist[dd[k]], 1u);
   }
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < P; p += kPartBlock) tile_hist[static_cast<int64_t>(p) * ntiles + tile] = s_hist[p];
@@ -60,10 +70,12 @@ struct ScatterArgs {
   int64_t n, ntiles;
   uint32_t P;
   int32_t ncols;
-  const uint16_t *dest;
+  const uint16_t *dest;    // null (part_scatter_lds_kernel only): the destination is recomputed from `keys`
   const uint64_t *bases;  // [P * ntiles + 1]
   int32_t *src_of_pos;    // optional: inverse map for columns not scattered here
   ScatterCol cols[kMaxScatter];
+  KeyCols keys;
+  uint64_t init;
 };
 
 __global__ __launch_bounds__(kPartBlock) void part_scatter_kernel(ScatterArgs a) {
@@ -102,6 +114,143 @@ __global__ __launch_bounds__(kPartBlock) void part_scatter_kernel(ScatterArgs a)
 #pragma unroll
     for (int k = 0; k < kPartItems; k++)
       if (pos[k] >= 0) a.src_of_pos[pos[k]] = static_cast<int32_t>(base + static_cast<int64_t>(k) * kPartBlock + threadIdx.x);
+  }
+}
+
+// The scatter of crgpu_dev_partition: a tile's rows are counting-sorted by destination in LDS first, column by column,
+// and leave in sorted order -- lane l writes position base[d] + l of its destination's run, so every store instruction
+// covers whole lines (the per-row form above writes P partial lines per wave).  With fixed-width hash columns the
+// destination is recomputed here instead of being written by the histogram pass and read back (4 B/row less traffic).
+static constexpr int kLdsBlock = 1024;                     // 16 waves: 4 rows per thread keep the kernel at < 64 VGPRs
+static constexpr int kLdsItems = kPartTile / kLdsBlock;
+static constexpr size_t part_lds_bytes(uint32_t P) {
+  return static_cast<size_t>(kPartTile) * (8 + 2 + 1) + static_cast<size_t>((P + 1) & ~1u) * 4 + static_cast<size_t>(P) * 8;
+}
+__device__ __forceinline__ void part_load_col(const ScatterCol &sc, int64_t base, uint32_t rows, uint32_t tid,
+                                              uint64_t *v, uint8_t *b) {
+#pragma unroll
+  for (int k = 0; k < kLdsItems; k++) {
+    const uint32_t s = k * kLdsBlock + tid;
+    v[k] = 0, b[k] = 1;
+    if (s >= rows) continue;
+    const int64_t i = base + s;
+    switch (sc.width) {
+      case 1: v[k] = sc.src[i]; break;
+      case 2: v[k] = reinterpret_cast<const uint16_t *>(sc.src)[i]; break;
+      case 4: v[k] = reinterpret_cast<const uint32_t *>(sc.src)[i]; break;
+      default: v[k] = reinterpret_cast<const uint64_t *>(sc.src)[i]; break;
+    }
+    if (sc.dst_valid) b[k] = (sc.src_valid[i >> 3] >> (i & 7)) & 1;
+  }
+}
+__global__ __launch_bounds__(kLdsBlock) void part_scatter_lds_kernel(ScatterArgs a) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_raw);                  // [kPartTile] one column's values, sorted
+  uint16_t *s_sdest = reinterpret_cast<uint16_t *>(s_stage + kPartTile);    // [kPartTile] destination of sorted slot s
+  uint8_t *s_vbyte = reinterpret_cast<uint8_t *>(s_sdest + kPartTile);      // [kPartTile] validity of the staged column
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_vbyte + kPartTile);      // [P] rows per destination, then first slots
+  long long *s_gbase = reinterpret_cast<long long *>(s_cnt + ((a.P + 1) & ~1u));  // [P] output position of slot s = s_gbase[d] + s
+  __shared__ uint32_t s_wsum[4];
+  const uint32_t tid = threadIdx.x, P = a.P;
+  for (uint32_t p = tid; p < P; p += kLdsBlock) s_cnt[p] = 0;
+  __syncthreads();
+  const int64_t tile = blockIdx.x;
+  const int64_t base = tile * kPartTile;
+  const uint32_t rows = a.n - base < kPartTile ? static_cast<uint32_t>(a.n - base) : static_cast<uint32_t>(kPartTile);
+  const bool pow2 = (P & (P - 1)) == 0;
+  uint32_t d[kLdsItems], lpos[kLdsItems];
+#pragma unroll
+  for (int k = 0; k < kLdsItems; k++) {
+    const uint32_t s = k * kLdsBlock + tid;
+    d[k] = 0, lpos[k] = 0;
+    if (s < rows) {
+      const int64_t i = base + s;
+      if (a.dest != nullptr) {
+        d[k] = a.dest[i];
+      } else {
+        const uint64_t h = hash_row64(a.keys, i, a.init);
+        d[k] = pow2 ? static_cast<uint32_t>(h & (P - 1)) : static_cast<uint32_t>(h % P);
+      }
+      lpos[k] = atomicAdd(&s_cnt[d[k]], 1u);  // rank among the tile's rows of this destination
+    }
+  }
+  __syncthreads();
+  // exclusive scan of s_cnt by the first 256 threads: thread t owns entries [4t, 4t + 4)  (P <= 1024)
+  uint32_t c4[4] = {0, 0, 0, 0}, sum = 0, incl = 0;
+  if (tid < 256) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t idx = 4 * tid + e;
+      c4[e] = idx < P ? s_cnt[idx] : 0u;
+      sum += c4[e];
+    }
+    incl = wave_incl_scan_u32(sum);
+    if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t run = incl - sum;
+    for (uint32_t w = 0; w < (tid >> 6); w++) run += s_wsum[w];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t idx = 4 * tid + e;
+      if (idx < P) {
+        s_cnt[idx] = run;
+        s_gbase[idx] = static_cast<long long>(a.bases[static_cast<int64_t>(idx) * a.ntiles + tile]) - static_cast<long long>(run);
+        run += c4[e];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kLdsItems; k++) {
+    if (k * kLdsBlock + tid < rows) {
+      lpos[k] += s_cnt[d[k]];
+      s_sdest[lpos[k]] = static_cast<uint16_t>(d[k]);
+    }
+  }
+  __syncthreads();
+  // column c + 1 is requested before column c is staged and written: one exposed load latency per tile, not one per column
+  uint64_t vn[kLdsItems];
+  uint8_t bn[kLdsItems];
+  part_load_col(a.cols[0], base, rows, tid, vn, bn);
+  for (int c = 0; c < a.ncols; c++) {
+    const ScatterCol sc = a.cols[c];
+#pragma unroll
+    for (int k = 0; k < kLdsItems; k++) {
+      if (k * kLdsBlock + tid >= rows) continue;
+      s_stage[lpos[k]] = vn[k];
+      if (sc.dst_valid) s_vbyte[lpos[k]] = bn[k];
+    }
+    if (c + 1 < a.ncols) part_load_col(a.cols[c + 1], base, rows, tid, vn, bn);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLdsItems; k++) {
+      const uint32_t s = k * kLdsBlock + tid;
+      if (s >= rows) continue;
+      const int64_t g = static_cast<int64_t>(s_gbase[s_sdest[s]] + static_cast<long long>(s));
+      const uint64_t v = s_stage[s];
+      switch (sc.width) {
+        case 1: sc.dst[g] = static_cast<uint8_t>(v); break;
+        case 2: reinterpret_cast<uint16_t *>(sc.dst)[g] = static_cast<uint16_t>(v); break;
+        case 4: __builtin_nontemporal_store(static_cast<uint32_t>(v), reinterpret_cast<uint32_t *>(sc.dst) + g); break;
+        default: __builtin_nontemporal_store(v, reinterpret_cast<uint64_t *>(sc.dst) + g); break;
+      }
+      if (sc.dst_valid) sc.dst_valid[g] = s_vbyte[s];
+    }
+    __syncthreads();
+  }
+  if (a.src_of_pos != nullptr) {
+    uint32_t *s_row = reinterpret_cast<uint32_t *>(s_stage);
+#pragma unroll
+    for (int k = 0; k < kLdsItems; k++)
+      if (k * kLdsBlock + tid < rows) s_row[lpos[k]] = k * kLdsBlock + tid;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLdsItems; k++) {
+      const uint32_t s = k * kLdsBlock + tid;
+      if (s < rows) a.src_of_pos[s_gbase[s_sdest[s]] + static_cast<long long>(s)] = static_cast<int32_t>(base + s_row[s]);
+    }
   }
 }
 
@@ -233,7 +382,13 @@ extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dc
   keys.n = static_cast<int>(p->hash_cols.size());
   keys._pad = 0;
   for (int k = 0; k < keys.n; k++) keys.c[k] = in[p->hash_cols[k]];
-  CRGPU_TRY(p->dest.ensure(static_cast<size_t>(n) * 2));
+  // BYTES hash columns: the destination is computed once and kept (2 B/row); fixed-width ones are hashed again by the scatter
+  bool keep_dest = false;
+  for (int k = 0; k < keys.n; k++) keep_dest = keep_dest || keys.c[k].type == CRGPU_BYTES;
+  const char *lds_env = std::getenv("CRGPU_PARTITION_LDS");  // "0": the per-row scatter (tests, measurements)
+  const bool lds_scatter = lds_env == nullptr || lds_env[0] != '0';
+  if (!lds_scatter) keep_dest = true;
+  if (keep_dest) CRGPU_TRY(p->dest.ensure(static_cast<size_t>(n) * 2));
   CRGPU_TRY(p->tile_hist.ensure(static_cast<size_t>(ntiles) * P * 4));
   CRGPU_TRY(p->bases.ensure((static_cast<size_t>(ntiles) * P + 1) * 8));
   CRGPU_TRY(p->counts_dev.ensure(static_cast<size_t>(P) * 8));
@@ -243,8 +398,10 @@ extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dc
   a.n = n;
   a.ntiles = ntiles;
   a.P = P;
-  a.dest = p->dest.as<uint16_t>();
+  a.dest = keep_dest ? p->dest.as<uint16_t>() : nullptr;
   a.bases = p->bases.as<uint64_t>();
+  a.keys = keys;
+  a.init = p->init;
   std::vector<int> later;
   std::vector<int> scattered;
   for (int c = 0; c < nc; c++) {
@@ -276,10 +433,13 @@ extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dc
   {
     ProfScope prof("partition");
     hipLaunchKernelGGL(part_hist_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, keys, n, p->init, P, ntiles,
-                       p->dest.as<uint16_t>(), p->tile_hist.as<uint32_t>());
+                       keep_dest ? p->dest.as<uint16_t>() : nullptr, p->tile_hist.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
     CRGPU_TRY(exclusive_scan_u32(p->tile_hist.as<uint32_t>(), ntiles * P, p->bases.as<uint64_t>(), p->scratch, nullptr));
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, a);
+    if (lds_scatter)
+      hipLaunchKernelGGL(part_scatter_lds_kernel, dim3(ntiles), dim3(kLdsBlock), part_lds_bytes(P), st, a);
+    else
+      hipLaunchKernelGGL(part_scatter_kernel, dim3(ntiles), dim3(kPartBlock), P * 4, st, a);
     CRGPU_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(part_counts_kernel, dim3(1), dim3(256), 0, st, p->bases.as<uint64_t>(), ntiles, P,

@@ -362,7 +362,7 @@ def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_r
     if want("general_join2"):
         yield bench_general_join(reps, dv, g, two_cols=True)
     if want("router"):
-        yield bench_router(lg_rows, reps, dv, g, 8)
+        yield bench_router(lg_rows, reps, dv, g, int(os.environ.get("ROUTER_OUTPUTS", "8")))
     if want("g_distinct"):
         yield bench_config_g(lg_rows, reps, dv, g, "distinct")
     if want("g_x4"):
