@@ -79,8 +79,8 @@ def gpu_agg(cols, group_cols, aggs, chunks=1):
     return out
 
 
-def wrap_torch(col, n, dtype, device):
-    """torch view (no copy) of the data buffer of a device column (library-owned result or input)."""
+def wrap_torch_ptr(ptr, n, dtype, device):
+    """torch view (no copy) of `n` elements of device memory at `ptr`."""
     import torch
 
     class _Holder:
@@ -88,5 +88,10 @@ def wrap_torch(col, n, dtype, device):
 
     h = _Holder()
     typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
-    h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(col.data_ptr), False), "version": 3}
+    h.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 3}
     return torch.as_tensor(h, device=device)
+
+
+def wrap_torch(col, n, dtype, device):
+    """torch view (no copy) of the data buffer of a device column (library-owned result or input)."""
+    return wrap_torch_ptr(col.data_ptr, n, dtype, device)

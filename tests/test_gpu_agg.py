@@ -248,6 +248,73 @@ def test_agg_full_size_invariants(ngroups):
     a.close()
 
 
+@pytest.mark.parametrize("ngroups", [1000, 3_000_000, 1 << 25])
+def test_agg_full_size_invariants_bytes_keys(ngroups):
+    """The BYTES-key variant of the high-cardinality GROUP BY (BASELINE config G) at 2^25 rows resident in HBM: 16-byte
+    keys (the hex digits of an int64), so every property can be checked against an independent torch reduction over the
+    integers the keys spell -- one output row per distinct key, the key bytes returned intact, COUNT_ROWS and SUM_INT per
+    group, and two passes over halves equal to one pass."""
+    import torch
+    from cockroach_amd import device as dev
+    n = 1 << 25
+    dv = torch.device("cuda", 0)
+    g = torch.Generator(device=dv)
+    g.manual_seed(ngroups)
+    mix = 0x9E3779B97F4A7C15 >> 2
+    if ngroups == n:
+        k = (torch.randperm(n, generator=g, device=dv, dtype=torch.int64) * mix) & (2**62 - 1)
+    else:
+        k = (torch.randint(0, ngroups, (n,), generator=g, device=dv, dtype=torch.int64) * mix) & (2**62 - 1)
+    x = torch.randint(-10**9, 10**9, (n,), generator=g, device=dv, dtype=torch.int64)
+    hexd = torch.tensor(list(b"0123456789abcdef"), device=dv, dtype=torch.uint8)
+    data = torch.empty((n, 16), device=dv, dtype=torch.uint8)
+    for d in range(16):
+        data[:, d] = hexd[(k >> (60 - 4 * d)) & 15]
+    offs = torch.arange(n + 1, device=dv, dtype=torch.int32) * 16
+    torch.cuda.synchronize()
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    a = dev.Agg([cd.BYTES, cd.INT64], [0], aggs)
+
+    def unhex(col, m):
+        o = G.wrap_torch_ptr(col.offsets_ptr, m + 1, torch.int32, dv)
+        assert torch.equal(o, torch.arange(m + 1, device=dv, dtype=torch.int32) * 16)  # every key is 16 bytes long
+        c = G.wrap_torch(col, m * 16, torch.uint8, dv).view(m, 16).to(torch.int64)
+        dig = torch.where(c >= 97, c - 87, c - 48)
+        assert bool(((dig >= 0) & (dig < 16)).all())
+        out = torch.zeros(m, dtype=torch.int64, device=dv)
+        for d in range(16):
+            out |= dig[:, d] << (60 - 4 * d)
+        return out
+
+    def result():
+        res = a.finish()
+        cols = dev.result_columns(res)
+        m = int(res.n)
+        return unhex(cols[0], m), G.wrap_torch(cols[1], m, torch.int64, dv).clone(), G.wrap_torch(cols[2], m, torch.int64, dv).clone()
+
+    def rows(lo, hi):
+        return [dev.from_torch(cd.BYTES, data[lo:hi].reshape(-1), offsets=offs[:hi - lo + 1]), dev.from_torch(cd.INT64, x[lo:hi])]
+
+    a.consume(rows(0, n), n)
+    keys, sums, cnts = result()
+    uk, inv = torch.unique(k, return_inverse=True)
+    assert keys.numel() == uk.numel()
+    order = torch.argsort(keys)
+    assert torch.equal(keys[order], uk)
+    assert int(cnts.sum().item()) == n
+    assert torch.equal(cnts[order], torch.bincount(inv, minlength=uk.numel()))
+    ref_sum = torch.zeros(uk.numel(), dtype=torch.int64, device=dv).index_add_(0, inv, x)
+    assert torch.equal(sums[order], ref_sum)
+    a.reset()
+    h = n // 2
+    a.consume(rows(0, h), h)
+    a.consume(rows(h, n), n - h)
+    keys2, sums2, cnts2 = result()
+    o2 = torch.argsort(keys2)
+    assert torch.equal(keys2[o2], uk) and torch.equal(sums2[o2], ref_sum) and torch.equal(cnts2[o2], cnts[order])
+    a.close()
+
+
 def test_agg_bulk_path_then_more_input_vs_oracle(oracle):
     """A fresh table fed >= 2^23 mostly distinct INT64 keys takes the bulk path (radix partition, grouping in LDS, no
     hash index); the second, small input forces the index to be rebuilt from the groups' hash words and then goes
