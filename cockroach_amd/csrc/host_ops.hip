@@ -20,16 +20,31 @@ static constexpr int kElemSize = 32;                     // coldata.ElementSize 
 static constexpr int kMaxInline = 30;                    // coldata.BytesMaxInlineLength (bytes.go:80-82)
 
 // ------------------------------------------------------------------ host-side staging
+// std::vector<uint8_t>::resize zero-fills, which doubles the memory traffic of a buffer that is overwritten at once
+// (a D2H copy, a memcpy): this allocator default-initialises instead, i.e. leaves the bytes alone.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+  template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+using ByteVec = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
+
 struct HostCol {
   int type = 0;
-  std::vector<uint8_t> data;      // fixed-width values or BYTES payload
+  ByteVec data;                   // fixed-width values or BYTES payload
   std::vector<uint32_t> offsets;  // BYTES: n+1
-  std::vector<uint8_t> present;   // one byte per row
+  std::vector<uint8_t> present;   // one byte per row; may be shorter than n (missing rows are present) while !any_null
   bool any_null = false;
   int64_t n = 0;
   void init(int t) {
     type = t;
     clear();
+  }
+  void fill_present() {
+    if (present.size() < static_cast<size_t>(n)) present.resize(static_cast<size_t>(n), 1);
   }
   void clear() {
     data.clear();
@@ -72,14 +87,20 @@ static crgpu_status stage_batch(std::vector<HostCol> &cols, const crgpu_batch *b
     HostCol &h = cols[ci];
     if (c.type != h.type) return fail(CRGPU_ERR_INVALID, "batch column type differs from the spec");
     if (c.data == nullptr) return fail(CRGPU_ERR_INVALID, "batch column without data");
-    const size_t old = h.present.size();
-    h.present.resize(old + n);
+    // the per-row present bytes are kept only from the first NULL on (a Go batch without NULLs costs one memcpy per column)
+    const bool no_nulls = !c.maybe_has_nulls || c.nulls == nullptr;
+    const size_t old = static_cast<size_t>(h.n);
+    const bool track = !no_nulls || h.any_null;
+    if (track) {
+      h.fill_present();
+      h.present.resize(old + n, 1);
+    }
     if (h.type == CRGPU_BYTES) {
       for (int64_t r = 0; r < n; r++) {
         const int64_t i = b->sel ? b->sel[r] : r;
-        const bool isnull = host_is_null(c, i);
-        h.present[old + r] = !isnull;
+        const bool isnull = !no_nulls && host_is_null(c, i);
         if (isnull) {
+          h.present[old + r] = 0;
           h.any_null = true;
         } else {
           uint32_t len;
@@ -92,17 +113,20 @@ static crgpu_status stage_batch(std::vector<HostCol> &cols, const crgpu_batch *b
     } else {
       const int w = type_width(h.type);
       const size_t oldb = h.data.size();
-      h.data.resize(oldb + static_cast<size_t>(n) * w);
+      h.data.resize(oldb + static_cast<size_t>(n) * w);  // (ByteVec: not zero-filled)
       const uint8_t *src = static_cast<const uint8_t *>(c.data);
       if (b->sel == nullptr) {
         std::memcpy(h.data.data() + oldb, src, static_cast<size_t>(n) * w);
       } else {
         for (int64_t r = 0; r < n; r++) std::memcpy(h.data.data() + oldb + r * w, src + b->sel[r] * w, w);
       }
-      for (int64_t r = 0; r < n; r++) {
-        const bool isnull = host_is_null(c, b->sel ? b->sel[r] : r);
-        h.present[old + r] = !isnull;
-        if (isnull) h.any_null = true;
+      if (!no_nulls) {
+        for (int64_t r = 0; r < n; r++) {
+          if (host_is_null(c, b->sel ? b->sel[r] : r)) {
+            h.present[old + r] = 0;
+            h.any_null = true;
+          }
+        }
       }
     }
     h.n += n;
@@ -171,8 +195,8 @@ static crgpu_status download_result(const crgpu_dev_result &r, HostResult &out) 
     HostCol &h = out.cols[c];
     h.init(d.type);
     h.n = r.n;
-    h.present.assign(static_cast<size_t>(r.n), 1);
     if (d.valid != nullptr && r.n > 0) {
+      h.present.assign(static_cast<size_t>(r.n), 1);
       bitmap.resize(static_cast<size_t>((r.n + 7) / 8));
       CRGPU_HIP(hipMemcpy(bitmap.data(), d.valid, bitmap.size(), hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < r.n; i++) {
@@ -225,7 +249,7 @@ static crgpu_status emit_rows(HostResult &src, crgpu_out_batch *out, bool *emitt
     if (o.data == nullptr) return fail(CRGPU_ERR_INVALID, "output column without data buffer");
     o.has_nulls = 0;
     if (o.nulls != nullptr) std::memset(o.nulls, 0xFF, static_cast<size_t>((out->capacity + 7) / 8));
-    for (int64_t r = 0; r < k; r++) {
+    for (int64_t r = 0; h.any_null && r < k; r++) {
       if (!h.present[src.cursor + r]) {
         if (o.nulls == nullptr) return fail(CRGPU_ERR_INVALID, "output column needs a null bitmap");
         o.nulls[r >> 3] &= static_cast<uint8_t>(~(1u << (r & 7)));
@@ -281,9 +305,13 @@ static void append_cols(std::vector<HostCol> &dst, const std::vector<HostCol> &s
       for (int64_t i = 1; i <= s.n; i++) d.offsets.push_back(base + s.offsets[i]);
     }
     d.data.insert(d.data.end(), s.data.begin(), s.data.end());
-    d.present.insert(d.present.end(), s.present.begin(), s.present.end());
-    d.any_null = d.any_null || s.any_null;
+    if (d.any_null || s.any_null) {
+      d.fill_present();
+      d.present.insert(d.present.end(), s.present.begin(), s.present.end());
+      d.any_null = true;
+    }
     d.n += s.n;
+    if (d.any_null) d.fill_present();  // (s.present may have been shorter than s.n)
   }
 }
 
@@ -783,7 +811,10 @@ static crgpu_status route_flush(crgpu_router *r) {
         HostCol &d = hr->cols[c];
         d.init(s.type);
         d.n = k;
-        d.present.assign(s.present.begin() + start, s.present.begin() + start + k);
+        if (s.any_null) {  // (conservative: this slice may hold none of the NULLs)
+          d.present.assign(s.present.begin() + start, s.present.begin() + start + k);
+          d.any_null = true;
+        }
         if (s.type == CRGPU_BYTES) {
           const uint32_t a = s.offsets[start], b = s.offsets[start + k];
           d.data.assign(s.data.begin() + a, s.data.begin() + b);
