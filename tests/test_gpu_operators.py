@@ -367,3 +367,69 @@ def test_unordered_distinct_export_buffered(oracle):
     ud.state = "draining"
     ordered_equal(got + drain(ud), want, "whole input")
     ud.close()
+
+
+def _late_null_batches(vecs, batch_size, first_null_row):
+    """Batches whose columns carry no null bitmap at all (Nulls.MaybeHasNulls() false) until `first_null_row`, and bitmaps
+    from there on: the staging area keeps per-row present bytes only from the first NULL on (host_ops.hip, stage_batch),
+    so the rows staged before it must still come out present."""
+    n = len(vecs[0])
+    out = []
+    for a in range(0, n, batch_size):
+        b = min(n, a + batch_size)
+        cols = []
+        for v in vecs:
+            s = v.slice(a, b)
+            if b <= first_null_row:
+                assert s.valid is None or s.present().all()
+                s = cd.Vec(s.type, s.data, None, s.offsets)
+            cols.append(s)
+        out.append(cd.Batch(cols, b - a))
+    return out
+
+
+def test_operators_nulls_appear_after_null_free_batches(oracle):
+    rng = np.random.default_rng(2024)
+    n, first = 6000, 3500
+    pres = np.ones(n, dtype=bool)
+    pres[first:] = rng.random(n - first) > 0.2
+    k = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 500, n, dtype=np.int64), pres)
+    x = cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(n), np.roll(pres, 7) | (np.arange(n) < first))
+    s = cd.Vec.from_values(cd.BYTES, [None if (i >= first and i % 5 == 0) else b"v%d" % (i % 50) * (1 + i % 3) for i in range(n)])
+    cols, types = [k, x, s], [cd.INT64, cd.FLOAT64, cd.BYTES]
+    # join: both sides arrive that way; the right side is the same table shifted
+    right = [cd.Vec.from_numpy(cd.INT64, k.data[::-1].copy(), pres), cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64))]
+    rt = [cd.INT64, cd.INT64]
+    for jt in ("INNER", "LEFT_OUTER", "FULL_OUTER"):
+        want = H.vecs_to_tuples(oracle.hash_join(H.JOIN_TYPE[jt], cols, right, [0], [0], False))
+        hj = ops.HashJoiner(H.JOIN_TYPE[jt], types, rt, [0], [0], False, ops.BatchSource(_late_null_batches(cols, 512, first), types),
+                            ops.BatchSource(_late_null_batches(right, 512, first), rt), capacity=1024, lookahead=4)
+        hj.init()
+        H.assert_same_multiset(drain(hj), want, jt)
+        hj.close()
+    # aggregation
+    aggs = [(0, 0, -1), (5, 1, -1), (10, 1, -1), (7, 2, -1), (14, -1, -1)]
+    want = H.vecs_to_tuples(oracle.hash_agg(cols, [0], aggs))
+    ha = ops.HashAggregator(types, [0], aggs, ops.BatchSource(_late_null_batches(cols, 512, first), types))
+    ha.init()
+    H.assert_same_multiset(drain(ha), want)
+    ha.close()
+    # router: rows and their NULLs reach the right outputs
+    dest, counts = oracle.distribute(cols, [0], 3)
+    r = ops.HashRouter(types, [0], 3, ops.BatchSource(_late_null_batches(cols, 512, first), types))
+    r.run()
+    all_rows = H.vecs_to_tuples(cols)
+    for p, out in enumerate(r.outputs):
+        H.assert_same_multiset(drain(out), [all_rows[i] for i in np.nonzero(dest == p)[0]], f"output {p}")
+    r.close()
+    # distinct on (k, s)
+    ud = ops.UnorderedDistinct(types, [0, 2], ops.BatchSource(_late_null_batches(cols, 512, first), types))
+    ud.init()
+    got = drain(ud)
+    seen, want = set(), []
+    for row in all_rows:
+        if (row[0], row[2]) not in seen:
+            seen.add((row[0], row[2]))
+            want.append(row)
+    assert got == want
+    ud.close()
