@@ -113,6 +113,7 @@ struct ProbeArgs {
   unsigned long long *out_count;
   const uint32_t *bloom;  // optional key bitmap (bloom_bit): a clear bit = no match, the table is not read
   uint32_t bmask, _pad2;
+  const int32_t *list;    // optional: the probe rows to look at (bloom_filter_kernel's survivors); n counts list entries
 };
 
 __device__ __forceinline__ void store_width(uint8_t *dst, int64_t pos, int width, uint64_t v) {
@@ -148,12 +149,15 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
     unsigned long long val[RPT];
     bool found[RPT], inb[RPT], emit[RPT];
     uint64_t idx[RPT], hk[RPT];
+    int32_t rowl[RPT];  // with a row list: the probe row of list entry tbase + j * TB + tid
     Slot s[RPT];
     // issue every first-step slot load of the tile before resolving any (memory-level parallelism)
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
-      const int64_t row = tbase + static_cast<int64_t>(j) * TB + tid;
-      inb[j] = row < a.n;
+      const int64_t at = tbase + static_cast<int64_t>(j) * TB + tid;
+      inb[j] = at < a.n;
+      rowl[j] = a.list != nullptr && inb[j] ? a.list[at] : 0;
+      const int64_t row = a.list != nullptr ? static_cast<int64_t>(rowl[j]) : at;
       found[j] = false;
       val[j] = 0;
       k[j] = kEmptyKey;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
 #pragma unroll
       for (int j = 0; j < RPT; j++) {
         if (!emit[j]) continue;
-        const int64_t row = tbase + static_cast<int64_t>(j) * TB + tid;
+        const int64_t row = a.list != nullptr ? static_cast<int64_t>(rowl[j]) : tbase + static_cast<int64_t>(j) * TB + tid;
         uint64_t v = 0;
         uint32_t present = 1;
         if (cc.side == SIDE_PROBE) {
@@ -272,11 +276,65 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
 #pragma unroll
       for (int j = 0; j < RPT; j++) {
         if (!emit[j]) continue;
-        a.pair_p[pos[j]] = static_cast<int32_t>(tbase + static_cast<int64_t>(j) * TB + tid);
+        a.pair_p[pos[j]] = a.list != nullptr ? rowl[j] : static_cast<int32_t>(tbase + static_cast<int64_t>(j) * TB + tid);
         a.pair_b[pos[j]] = found[j] ? static_cast<int32_t>(val[j]) : -1;
       }
     }
     __syncthreads();  // s_cnt / s_pre / s_base are reused by the next tile
+  }
+}
+
+// A probe side of which only a few per cent can match (TPC-H Q9: 60M lineitems against the 5 % of parts that are green)
+// is mostly rows the key bitmap rejects, and the probe kernel is a heavy place to reject them: ~80 VGPRs, two barriers
+// and an output-position atomic per tile whatever the rows do.  This pass only evaluates the bitmap -- key columns in,
+// the surviving row numbers out -- and the probe kernel then runs over the survivors alone (ProbeArgs::list).
+__global__ __launch_bounds__(1024) void bloom_filter_kernel(KeyPack kp, int64_t n, const uint32_t *__restrict__ bloom, uint32_t bmask,
+                                                           int32_t *__restrict__ list, unsigned long long *__restrict__ count) {
+  constexpr int TB = 1024, RPT = 8, kWaves = TB / 64, kTile = TB * RPT;  // 8192-row tiles: one reservation atomic each
+  __shared__ uint32_t s_cnt[RPT * kWaves];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tbase = tile * kTile;
+    uint32_t bit[RPT], w[RPT];
+    bool keep[RPT], look[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const int64_t row = tbase + static_cast<int64_t>(j) * TB + tid;
+      uint64_t kk = kEmptyKey;
+      const bool has = row < n && key_pack(kp, row, kk);
+      keep[j] = has && kk == kEmptyKey;  // the key equal to the empty marker lives beside the table: let the probe decide
+      look[j] = has && kk != kEmptyKey;
+      bit[j] = bloom_bit(fmix64(kk), bmask);
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) w[j] = look[j] ? bloom[bit[j] >> 5] : 0u;
+    uint32_t rank[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      keep[j] = keep[j] || (look[j] && ((w[j] >> (bit[j] & 31)) & 1u));
+      const uint64_t m = __ballot(keep[j]);
+      rank[j] = rank_in_mask(m);
+      if (lane_id() == 0) s_cnt[j * kWaves + wave] = popc64(m);
+    }
+    __syncthreads();
+    if (tid < 64) {  // RPT * kWaves = 128 counts: exclusive scan by the first wave (two each), one reservation per tile
+      const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+      const uint32_t incl = wave_incl_scan_u32(c0 + c1);
+      const uint32_t total = __shfl(incl, 63, 64);
+      unsigned long long base = 0;
+      if (tid == 0 && total) base = atomicAdd(count, static_cast<unsigned long long>(total));
+      if (tid == 0) s_base = base;
+      s_cnt[2 * tid] = incl - c0 - c1;
+      s_cnt[2 * tid + 1] = incl - c1;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+#pragma unroll
+    for (int j = 0; j < RPT; j++)
+      if (keep[j]) list[base + s_cnt[j * kWaves + wave] + rank[j]] = static_cast<int32_t>(tbase + static_cast<int64_t>(j) * TB + tid);
+    __syncthreads();  // s_cnt / s_base are reused by the next tile
   }
 }
 
@@ -731,6 +789,7 @@ struct crgpu_join : crgpu::Handle {
   // packed table
   DevBuf slots, special;
   DevBuf bloom;             // key bitmap in front of a packed table larger than the L2 (bloom_bit)
+  DevBuf cand;              // bloom_filter_kernel's survivors (probe row numbers) of the current probe chunk
   uint32_t bloom_mask = 0;
   bool bloom_on = false;    // built with the table; switched off after a probe chunk in which most rows matched
   DevBuf mcache;  // chained probe: first matches of every probe row (pass 1 -> pass 3)
@@ -1164,7 +1223,7 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
   const int jt = j->join_type;
   const bool outer_nulls = left_or_full_outer(jt);
   hipStream_t st = stream();
-  const int64_t cap_rows = n > 0 ? n : 1;  // first-match joins emit at most one row per probe row
+  int64_t cap_rows = n > 0 ? n : 1;  // first-match joins emit at most one row per probe row
 
   ProbeArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -1174,11 +1233,37 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
   a.mask = j->cap - 1;
   a.special = j->special.as<Special>();
   a.matched = j->track_build_matches ? j->matched.as<uint8_t>() : nullptr;
-  a.bloom = j->bloom_on ? j->bloom.as<uint32_t>() : nullptr;
-  a.bmask = j->bloom_mask;
   CRGPU_TRY(j->counter.ensure(8));
   CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
   a.out_count = j->counter.as<unsigned long long>();
+  // Large probe chunks of joins that drop unmatched rows: the bitmap is evaluated by a pass of its own and the probe kernel
+  // sees the survivors only (bloom_filter_kernel); outputs are then sized for the survivors, not for the chunk.
+  const char *pf_env = std::getenv("CRGPU_JOIN_PREFILTER_MIN");  // rows per probe chunk from which the pass pays (tests: 0)
+  const int64_t prefilter_min = pf_env != nullptr ? std::atoll(pf_env) : int64_t(1) << 21;
+  if (j->bloom_on && (jt == CRGPU_INNER || jt == CRGPU_LEFT_SEMI) && n >= prefilter_min && n <= 0x7FFFFFF0ll) {
+    CRGPU_TRY(j->cand.ensure(static_cast<size_t>(n) * 4));
+    {
+      ProfScope prof("join_probe");
+      hipLaunchKernelGGL(bloom_filter_kernel, dim3(grid_for(n, 1024 * 8)), dim3(1024), 0, st, a.kp, n, j->bloom.as<uint32_t>(),
+                         j->bloom_mask, j->cand.as<int32_t>(), j->counter.as<unsigned long long>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    uint64_t ncand = 0;
+    CRGPU_HIP(hipMemcpyAsync(&ncand, j->counter.p, 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (ncand * 2 <= static_cast<uint64_t>(n)) {
+      a.list = j->cand.as<int32_t>();
+      a.n = static_cast<int64_t>(ncand);
+      cap_rows = ncand > 0 ? static_cast<int64_t>(ncand) : 1;
+    } else {
+      j->bloom_on = false;  // most rows pass: the bitmap only adds a read per row, here and in the chunks that follow
+    }
+  }
+  if (a.list == nullptr && j->bloom_on) {
+    a.bloom = j->bloom.as<uint32_t>();
+    a.bmask = j->bloom_mask;
+  }
 
   // Decide per output column: fused into the probe kernel, or materialised afterwards through pairs.
   struct Later { int out_idx; bool is_left; int src; };
@@ -1234,12 +1319,12 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
   }
 
   uint64_t nout = 0;
-  if (n > 0) {
+  if (a.n > 0) {
     // 512 threads x 4 rows: 78 VGPRs, three workgroups per CU.  Measured against 1024 x 8 (128 VGPRs, one workgroup per
     // CU: every barrier and the tile's output-position atomic stall the whole CU): 5 % hit probe of 60M rows 0.95 -> 0.86 ms,
     // TPC-H Q9's probes 2.27 -> 2.13 ms; 512 x 8 and 256 x 8 (3 waves per SIMD) were 1.3-1.5 x slower.
     constexpr int TB = 512, RPT = 4;
-    int64_t ntiles = (n + TB * RPT - 1) / (TB * RPT);
+    int64_t ntiles = (a.n + TB * RPT - 1) / (TB * RPT);
     int64_t cap_grid = static_cast<int64_t>(num_cus()) * 8;
     int grid = static_cast<int>(ntiles < cap_grid ? ntiles : cap_grid);
     {

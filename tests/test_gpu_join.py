@@ -162,13 +162,15 @@ def test_join_packed_covering_large():
     j.close()
 
 
-@pytest.mark.parametrize("bitmap", ["1", "0"])
+@pytest.mark.parametrize("bitmap", ["1", "0", "prefilter"])
 @pytest.mark.parametrize("two_cols", [False, True])
 def test_join_packed_key_bitmap_selective_probe(oracle, bitmap, two_cols, monkeypatch):
     """A packed table beyond 2 MiB gets a key bitmap in front of it (join.hip, bloom_bit): a probe row whose bit is clear
     never reads the table.  Selective probes (5 % hits), then a chunk of hits only (which switches the bitmap off for
     INNER / LEFT_SEMI), with the key equal to the table's empty marker on both sides; two handles in a row."""
-    monkeypatch.setenv("CRGPU_JOIN_BLOOM", bitmap)
+    monkeypatch.setenv("CRGPU_JOIN_BLOOM", "0" if bitmap == "0" else "1")
+    if bitmap == "prefilter":  # the bitmap evaluated by a pass of its own, the probe kernel over the survivors (large chunks)
+        monkeypatch.setenv("CRGPU_JOIN_PREFILTER_MIN", "1")
     rng = np.random.default_rng(17)
     nb, npr = 150_000, 400_000
     space = nb * 20
