@@ -121,6 +121,7 @@ SYMBOLS = [
     ("crgpu_dev_join_create", _I32, [C.POINTER(JoinSpec), C.POINTER(_VP)]),
     ("crgpu_dev_join_build", _I32, [_VP, C.POINTER(DCol), _I64]),
     ("crgpu_dev_join_probe", _I32, [_VP, C.POINTER(DCol), _I64, C.POINTER(DevResult)]),
+    ("crgpu_dev_join_probe_selected", _I32, [_VP, C.POINTER(DCol), _I64, _VP, C.POINTER(DevResult)]),
     ("crgpu_dev_join_emit_right", _I32, [_VP, C.POINTER(DevResult)]),
     ("crgpu_dev_join_reset", _I32, [_VP]),
     ("crgpu_dev_join_destroy", None, [_VP]),

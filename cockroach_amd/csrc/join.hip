@@ -114,6 +114,7 @@ struct ProbeArgs {
   const uint32_t *bloom;  // optional key bitmap (bloom_bit): a clear bit = no match, the table is not read
   uint32_t bmask, _pad2;
   const int32_t *list;    // optional: the probe rows to look at (bloom_filter_kernel's survivors); n counts list entries
+  const uint8_t *keep;    // optional selection (a BOOL column): rows whose byte is 0 are not part of the probe side
 };
 
 __device__ __forceinline__ void store_width(uint8_t *dst, int64_t pos, int width, uint64_t v) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const int64_t at = tbase + static_cast<int64_t>(j) * TB + tid;
-      inb[j] = at < a.n;
+      inb[j] = at < a.n && (a.keep == nullptr || a.list != nullptr || a.keep[at] != 0);  // (a list holds selected rows only)
       rowl[j] = a.list != nullptr && inb[j] ? a.list[at] : 0;
       const int64_t row = a.list != nullptr ? static_cast<int64_t>(rowl[j]) : at;
       found[j] = false;
@@ -288,8 +289,9 @@ __global__ __launch_bounds__(TB) void packed_probe_kernel(ProbeArgs a) {
 // is mostly rows the key bitmap rejects, and the probe kernel is a heavy place to reject them: ~80 VGPRs, two barriers
 // and an output-position atomic per tile whatever the rows do.  This pass only evaluates the bitmap -- key columns in,
 // the surviving row numbers out -- and the probe kernel then runs over the survivors alone (ProbeArgs::list).
-__global__ __launch_bounds__(1024) void bloom_filter_kernel(KeyPack kp, int64_t n, const uint32_t *__restrict__ bloom, uint32_t bmask,
-                                                           int32_t *__restrict__ list, unsigned long long *__restrict__ count) {
+__global__ __launch_bounds__(1024) void bloom_filter_kernel(KeyPack kp, int64_t n, const uint8_t *__restrict__ sel,
+                                                            const uint32_t *__restrict__ bloom, uint32_t bmask,
+                                                            int32_t *__restrict__ list, unsigned long long *__restrict__ count) {
   constexpr int TB = 1024, RPT = 8, kWaves = TB / 64, kTile = TB * RPT;  // 8192-row tiles: one reservation atomic each
   __shared__ uint32_t s_cnt[RPT * kWaves];
   __shared__ unsigned long long s_base;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(1024) void bloom_filter_kernel(KeyPack kp, int64_t 
     for (int j = 0; j < RPT; j++) {
       const int64_t row = tbase + static_cast<int64_t>(j) * TB + tid;
       uint64_t kk = kEmptyKey;
-      const bool has = row < n && key_pack(kp, row, kk);
+      const bool has = row < n && (sel == nullptr || sel[row] != 0) && key_pack(kp, row, kk);
       keep[j] = has && kk == kEmptyKey;  // the key equal to the empty marker lives beside the table: let the probe decide
       look[j] = has && kk != kEmptyKey;
       bit[j] = bloom_bit(fmix64(kk), bmask);
@@ -790,6 +792,8 @@ struct crgpu_join : crgpu::Handle {
   DevBuf slots, special;
   DevBuf bloom;             // key bitmap in front of a packed table larger than the L2 (bloom_bit)
   DevBuf cand;              // bloom_filter_kernel's survivors (probe row numbers) of the current probe chunk
+  DevBuf sel_idx;           // crgpu_dev_join_probe_selected on the partitioned / chained tables: the selected rows, copied out
+  std::vector<OutCol> sel_cols;
   uint32_t bloom_mask = 0;
   bool bloom_on = false;    // built with the table; switched off after a probe chunk in which most rows matched
   DevBuf mcache;  // chained probe: first matches of every probe row (pass 1 -> pass 3)
@@ -1219,7 +1223,8 @@ static crgpu_status launch_packed_probe(int jt, const ProbeArgs &a, int grid) {
   return CRGPU_OK;
 }
 
-static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, int64_t n, crgpu_dev_result *res) {
+static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, int64_t n, const uint8_t *keep,
+                                 crgpu_dev_result *res) {
   const int jt = j->join_type;
   const bool outer_nulls = left_or_full_outer(jt);
   hipStream_t st = stream();
@@ -1233,6 +1238,7 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
   a.mask = j->cap - 1;
   a.special = j->special.as<Special>();
   a.matched = j->track_build_matches ? j->matched.as<uint8_t>() : nullptr;
+  a.keep = keep;
   CRGPU_TRY(j->counter.ensure(8));
   CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
   a.out_count = j->counter.as<unsigned long long>();
@@ -1244,7 +1250,7 @@ static crgpu_status probe_packed(crgpu_join *j, const std::vector<DCol> &left, i
     CRGPU_TRY(j->cand.ensure(static_cast<size_t>(n) * 4));
     {
       ProfScope prof("join_probe");
-      hipLaunchKernelGGL(bloom_filter_kernel, dim3(grid_for(n, 1024 * 8)), dim3(1024), 0, st, a.kp, n, j->bloom.as<uint32_t>(),
+      hipLaunchKernelGGL(bloom_filter_kernel, dim3(grid_for(n, 1024 * 8)), dim3(1024), 0, st, a.kp, n, keep, j->bloom.as<uint32_t>(),
                          j->bloom_mask, j->cand.as<int32_t>(), j->counter.as<unsigned long long>());
       CRGPU_HIP(hipGetLastError());
     }
@@ -1556,8 +1562,8 @@ static crgpu_status probe_chained(crgpu_join *j, const std::vector<DCol> &left, 
   return finish_result(j, static_cast<int64_t>(total), res);
 }
 
-extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
-                                             crgpu_dev_result *res) {
+static crgpu_status join_probe_impl(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n, const uint8_t *keep,
+                                    crgpu_dev_result *res) {
   if (j == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_probe: null argument");
   CRGPU_ENTER(j);
   CRGPU_CHECK_CANCEL(j);
@@ -1579,11 +1585,39 @@ extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *le
     left.push_back(d);
   }
   join_setup_outputs(j);
+  if (n == 0) keep = nullptr;
   // Empty build side short-circuits (hashjoiner.go:300-306, join_type.go:79-88): the
   // kernels below already produce the right answer on an empty table, so no special case.
+  if (j->packed && !j->use_radix) return probe_packed(j, left, n, keep, res);
+  if (keep != nullptr) {
+    // the partitioned and the chained tables take dense probe rows: the selected rows are copied out first (what
+    // crgpu_dev_deselect would do), then probed
+    int64_t m = 0;
+    CRGPU_TRY(j->sel_idx.ensure(static_cast<size_t>(n) * 4));
+    CRGPU_TRY(select_flagged(keep, n, j->sel_idx.as<int32_t>(), j->scratch, &m));
+    if (j->sel_cols.size() != static_cast<size_t>(nl)) j->sel_cols = std::vector<OutCol>(nl);
+    for (int c = 0; c < nl; c++) {
+      if (m == 0) {
+        left[c] = DCol{j->left_types[c], 0, nullptr, nullptr, nullptr};
+        continue;
+      }
+      CRGPU_TRY(materialize(left[c], j->sel_idx.as<int32_t>(), m, false, j->sel_cols[c], j->scratch));
+      left[c] = to_dcol(j->sel_cols[c].view());
+    }
+    n = m;
+  }
   if ((j->packed && j->use_radix) || j->use_radix_dup) return probe_radix(j, left, n, res);
-  if (j->packed) return probe_packed(j, left, n, res);
   return probe_chained(j, left, n, res);
+}
+
+extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
+                                             crgpu_dev_result *res) {
+  return join_probe_impl(j, left_cols, n, nullptr, res);
+}
+
+extern "C" crgpu_status crgpu_dev_join_probe_selected(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
+                                                      const uint8_t *keep_bool, crgpu_dev_result *res) {
+  return join_probe_impl(j, left_cols, n, keep_bool, res);
 }
 
 extern "C" crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_result *res) {

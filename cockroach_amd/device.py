@@ -153,6 +153,14 @@ class Join:
         _lib.check(_lib.load().crgpu_dev_join_probe(self.h, dcol_array(cols), n, C.byref(res)))
         return res
 
+    def probe_selected(self, cols, keep, n=None) -> _lib.DevResult:
+        """Probe the rows of `cols` whose byte in `keep` (a BOOL DeviceColumn from select_*) is non-zero."""
+        n = (cols[0].n if cols else 0) if n is None else n
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_join_probe_selected(self.h, dcol_array(cols), n, keep.data_ptr if keep is not None else None,
+                                                             C.byref(res)))
+        return res
+
     def emit_right(self) -> _lib.DevResult:
         res = _lib.DevResult()
         _lib.check(_lib.load().crgpu_dev_join_emit_right(self.h, C.byref(res)))

@@ -175,6 +175,14 @@ crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, i
  * columns then right columns, JoinType.MakeOutputTypes join_type.go:101).
  * RIGHT SEMI / RIGHT ANTI produce no probe-time output (n = 0). */
 crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n, crgpu_dev_result *out);
+/* The same probe over a batch that carries a selection: the reference's selection operators only set the batch's
+ * selection vector and the hash joiner reads its probe batches through it (hashJoiner.exec, hashjoiner.go:504-560:
+ * `sel := batch.Selection()`; colexechash.rehash with sel, hash_utils.eg.go:39), nothing is copied in between.  keep_bool
+ * is a BOOL column in device memory as crgpu_dev_select_* write it: rows whose byte is 0 are not part of the probe side
+ * (they produce nothing, whatever the join type).  NULL: every row.  The packed table probes the selected rows in
+ * place; the partitioned and the chained tables copy them out first (as crgpu_dev_deselect would). */
+crgpu_status crgpu_dev_join_probe_selected(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n, const uint8_t *keep_bool,
+                                           crgpu_dev_result *out);
 /* After the last probe chunk: hjEmittingRight (hashjoiner.go:322-328) --
  * unmatched build rows (RIGHT/FULL OUTER, RIGHT ANTI) or matched ones (RIGHT SEMI). */
 crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_result *out);

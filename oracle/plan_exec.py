@@ -35,7 +35,9 @@ class OracleExec:
     def filter(self, cols, sel):
         return O.deselect(cols, sel)
 
-    def join(self, jt, left, right, leq, req, right_key, out):
+    def join(self, jt, left, right, leq, req, right_key, out, left_sel=None):
+        if left_sel is not None:  # a probe batch with a selection vector: the joiner reads the selected rows only
+            left = self.filter(left, left_sel)
         res = O.hash_join(jt, list(left), list(right), leq, req, right_key)
         self.ops.append(("join", len(left[0]), len(res[0]) if res else 0))
         return [res[q] for q in out]

@@ -36,17 +36,16 @@ def q3(ex, t, build_orders_by_custkey=False):
     filtered ORDERS by o_custkey: ~10 rows per build key) -- the duplicate-build-key join path on the same data."""
     c, o, l = t["customer"], t["orders"], t["lineitem"]
     cust = ex.filter([c["c_custkey"]], ex.select_bytes("EQ", c["c_mktsegment"], b"BUILDING"))
-    orders = ex.filter([o["o_orderkey"], o["o_custkey"], o["o_orderdate"], o["o_shippriority"]],
-                       ex.select_i64("LT", o["o_orderdate"], T.DAY_1995_03_15))
+    o_cols = [o["o_orderkey"], o["o_custkey"], o["o_orderdate"], o["o_shippriority"]]
+    o_sel = ex.select_i64("LT", o["o_orderdate"], T.DAY_1995_03_15)
     if not build_orders_by_custkey:
-        # hashJoiner(left = orders, right = customer): tpch_vec:20584-20588
-        j1 = ex.join(INNER, orders, cust, [1], [0], True, out=[0, 2, 3])
+        # hashJoiner(left = orders, right = customer): tpch_vec:20584-20588; the probe batches carry the selection
+        j1 = ex.join(INNER, o_cols, cust, [1], [0], True, out=[0, 2, 3], left_sel=o_sel)
     else:
-        j1 = ex.join(INNER, cust, orders, [0], [1], False, out=[1, 3, 4])
-    line = ex.filter([l["l_orderkey"], l["l_extendedprice"], l["l_discount"]],
-                     ex.select_i64("GT", l["l_shipdate"], T.DAY_1995_03_15))
+        j1 = ex.join(INNER, cust, ex.filter(o_cols, o_sel), [0], [1], False, out=[1, 3, 4])
     # lineitem x (orders x customer) on l_orderkey = o_orderkey; o_orderkey is a key of the build side
-    j2 = ex.join(INNER, line, j1, [0], [0], True, out=[0, 1, 2, 4, 5])
+    j2 = ex.join(INNER, [l["l_orderkey"], l["l_extendedprice"], l["l_discount"]], j1, [0], [0], True, out=[0, 1, 2, 4, 5],
+                 left_sel=ex.select_i64("GT", l["l_shipdate"], T.DAY_1995_03_15))
     revenue = ex.project("*(1-)", j2[1], j2[2])
     return ex.agg([j2[0], j2[3], j2[4], revenue], [0, 1, 2],
                   [(ANY_NOT_NULL, 0), (ANY_NOT_NULL, 1), (ANY_NOT_NULL, 2), (SUM, 3)])
@@ -136,16 +135,18 @@ class GpuExec:
         self._note("filter", list(cols) + [sel], out)
         return out
 
-    def join(self, jt, left, right, leq, req, right_key, out):
+    def join(self, jt, left, right, leq, req, right_key, out, left_sel=None):
+        """left_sel: a BOOL column from select_*: the probe side is the selected rows of `left` (the reference's selection
+        operators only set the batch's selection vector, the joiner reads through it: crgpu_dev_join_probe_selected)."""
         j = self.dev.Join(jt, [c.type for c in left], [c.type for c in right], leq, req, right_key, out_cols=out)
         self.handles.append(j)
         j.build(right)
-        res = self.dev.result_columns(j.probe(left))
+        res = self.dev.result_columns(j.probe(left) if left_sel is None else j.probe_selected(left, left_sel))
         if self.account:  # only the columns the join reads: keys + emitted columns
             nl = len(left)
             used_l = sorted(set(leq) | {q for q in out if q < nl})
             used_r = sorted(set(req) | {q - nl for q in out if q >= nl})
-            self._note("join", [left[q] for q in used_l] + [right[q] for q in used_r], res)
+            self._note("join", [left[q] for q in used_l] + [right[q] for q in used_r] + ([left_sel] if left_sel is not None else []), res)
         return res
 
     def project(self, op, a, b):
