@@ -16,7 +16,11 @@ struct DeviceCtx {
   hipStream_t stream = nullptr;  // default stream: handle-less calls (hash, select, project, raw copies)
   int cus = 256;
   std::atomic<uint64_t> epoch{0};  // bumped by every asynchronous handle-less call
+  // streams and events of closed handles, reused by the next handles: a query plan opens and closes a dozen operators,
+  // and creating a stream per operator costs tens of microseconds each (guarded by g_mu)
+  std::vector<std::pair<hipStream_t, hipEvent_t>> idle;
 };
+static constexpr size_t kMaxIdleStreams = 64;
 
 static thread_local std::string t_err;
 static thread_local int t_device = -1;            // this thread's library device
@@ -96,15 +100,39 @@ crgpu_status ensure_init() {
 crgpu_status Handle::open() {
   CRGPU_TRY(ensure_init());
   device = t_device;
-  CRGPU_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  CRGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &idle = g_dev[device].idle;
+    if (!idle.empty()) {
+      st = idle.back().first;
+      ev = idle.back().second;
+      idle.pop_back();
+    }
+  }
+  if (st == nullptr) {
+    CRGPU_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CRGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  }
   g_handles.fetch_add(1);
   return CRGPU_OK;
 }
 void Handle::close() {
   if (st != nullptr) {
     (void)hipStreamSynchronize(st);
-    (void)hipStreamDestroy(st);
+    bool kept = false;
+    if (ev != nullptr && device >= 0 && device < kMaxDevices) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      auto &idle = g_dev[device].idle;
+      if (g_dev[device].ready.load() && idle.size() < kMaxIdleStreams) {
+        idle.emplace_back(st, ev);  // drained above: the next handle starts on an empty stream
+        kept = true;
+      }
+    }
+    if (kept) {
+      ev = nullptr;
+    } else {
+      (void)hipStreamDestroy(st);
+    }
     st = nullptr;
     g_handles.fetch_sub(1);
   }
@@ -321,6 +349,11 @@ void crgpu_shutdown(void) {
     if (!d.ready.load()) continue;
     pool_trim(i);
     d.ready.store(false);
+    for (auto &se : d.idle) {  // (g_mu is held)
+      (void)hipStreamDestroy(se.first);
+      (void)hipEventDestroy(se.second);
+    }
+    d.idle.clear();
     if (d.stream != nullptr) {
       (void)hipStreamSynchronize(d.stream);
       (void)hipStreamDestroy(d.stream);
