@@ -1661,17 +1661,23 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
   if (n == 0) return;
   const ulonglong2 *rows = a.rows + (a.starts != nullptr ? static_cast<int64_t>(a.starts[q]) : static_cast<int64_t>(q) * kBulkRows);
   const uint32_t smask = a.slots - 1;
-  for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) idx[i] = kNone;
-  for (int f = 0; f < a.naggs; f++) {
-    const OpK &op = a.ops[f];
-    if (op.lw0 >= 0) {
-      const unsigned long long init = acc_init_w0(op.kind);
-      for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * plane + i] = init;
+  // A region of one tile (the sub form: <= kBulkRows rows) whose keys all turn out distinct needs no accumulator planes:
+  // every row IS its group's result.  The planes are therefore set up after the first tile's find-or-insert.
+  const bool single = n <= kBulkRows;
+  auto init_planes = [&]() {
+    for (int f = 0; f < a.naggs; f++) {
+      const OpK &op = a.ops[f];
+      if (op.lw0 >= 0) {
+        const unsigned long long init = acc_init_w0(op.kind);
+        for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw0) * plane + i] = init;
+      }
+      if (op.lw1 >= 0)
+        for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * plane + i] = 0ull;
     }
-    if (op.lw1 >= 0)
-      for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(op.lw1) * plane + i] = 0ull;
-  }
-  for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
+    for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
+  };
+  for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) idx[i] = kNone;
+  if (!single) init_planes();
   if (threadIdx.x == 0) s_claims = 0;
   __syncthreads();
   constexpr int kRows = kBulkRows / 1024;  // rows per thread and tile at 1024 threads
@@ -1716,6 +1722,47 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
     if (s_claims > a.gmax) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
       if (threadIdx.x == 0) atomicOr(a.failed, 1u);
       return;
+    }
+    if (single && s_claims == n) {
+      // every key of the region is distinct: group l = the row that claimed l; its accumulators are its value
+      if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, n);
+      __syncthreads();
+      const uint32_t base = a.g0 + s_base;
+#pragma unroll
+      for (int k = 0; k < kRows; k++) {
+        if (slot_of[k] == kNone) continue;
+        const uint32_t gid = base + lid[slot_of[k]];
+        const unsigned long long key = rows[t0 + k * blockDim.x + threadIdx.x].x, v = val[k];
+        reinterpret_cast<unsigned long long *>(a.key_data)[gid] = key;
+        a.key_present[gid] = 1;
+        const uint64_t h = fmix64(hash_step(0x9E3779B97F4A7C15ull, key));
+        a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
+                       (static_cast<uint32_t>(h) & kIdxHashMask);
+        for (int f = 0; f < a.naggs; f++) {
+          const OpK &op = a.ops[f];
+          unsigned long long w0 = v, w1 = 0;
+          uint8_t seen = 1;
+          switch (op.kind) {  // what apply_rows_lds leaves in a group's words after this one row
+            case ACC_COUNT_ROWS:
+            case ACC_COUNT: w0 = 1; seen = 0; break;
+            case ACC_AVG_F64: w1 = 1; seen = 0; break;
+            case ACC_SUM_I128: w1 = (v >> 63) ? ~0ull : 0ull; break;
+            case ACC_MIN_F64:
+            case ACC_MAX_F64: w0 = f64_to_ordered(__longlong_as_double(static_cast<long long>(v))); break;
+            case ACC_BOOL_AND:
+            case ACC_BOOL_OR: w0 = v ? 1ull : 0ull; break;
+            default: break;  // SUM_F64, MIN / MAX over integers: the value itself
+          }
+          op.w0[gid] = w0;
+          if (op.w1 != nullptr) op.w1[gid] = op.lw1 >= 0 ? w1 : 0ull;
+          if (op.seen != nullptr) op.seen[gid] = op.lseen >= 0 ? seen : 0;
+        }
+      }
+      return;
+    }
+    if (single) {
+      init_planes();
+      __syncthreads();
     }
     // 2. accumulate in LDS (apply_rows_lds: straight-line updates; rows past the end go to the trash group)
     uint32_t gr[kRows];
