@@ -3609,13 +3609,20 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     CRGPU_HIP(hipGetLastError());
     CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, static_cast<size_t>(kSample) * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
-    std::sort(sample.begin(), sample.end());
+    // distinct keys and the largest multiplicity of the sample, by open addressing (sorting 8192 keys took 0.3 ms)
+    const size_t tab = static_cast<size_t>(kSample) * 4;
+    std::vector<int64_t> tkey(tab);
+    std::vector<int32_t> tcnt(tab, 0);
     distinct = 0;
     maxrun = 0;
-    for (int i = 0, run = 0; i < kSample; i++) {
-      run = (i > 0 && sample[i] == sample[i - 1]) ? run + 1 : 1;
-      if (run == 1) distinct++;
-      if (run > maxrun) maxrun = run;
+    for (int i = 0; i < kSample; i++) {
+      size_t at = static_cast<size_t>((static_cast<uint64_t>(sample[i]) * 0x9E3779B97F4A7C15ull) >> 40) & (tab - 1);
+      while (tcnt[at] != 0 && tkey[at] != sample[i]) at = (at + 1) & (tab - 1);
+      if (tcnt[at] == 0) {
+        tkey[at] = sample[i];
+        distinct++;
+      }
+      if (++tcnt[at] > maxrun) maxrun = tcnt[at];
     }
     if (kSample == 512 && distinct < 384) return CRGPU_OK;  // fewer than ~1000 groups: the fused pass is the right tool
   }
