@@ -621,6 +621,7 @@ using namespace crgpu;
 
 struct crgpu_decoder : crgpu::Handle {
   FetchSpec spec;
+  std::vector<KvSeg> segs_host;
   DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
   std::vector<OutCol> out;
   std::vector<DevBuf> valid_bytes, lens, srcpos, offs64c;
@@ -722,7 +723,8 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
   CRGPU_HIP(hipMemsetAsync(d->err.as<uint8_t>() + 8, 0, 8, st));
   if (n_batches > 0) {
     // cut the batches into segments
-    std::vector<KvSeg> segs;
+    std::vector<KvSeg> &segs = d->segs_host;  // stays alive until the copy below has run (no wait for it here)
+    segs.clear();
     for (int64_t b = 0; b < n_batches; b++) {
       const int64_t lo = batch_offsets_host[b], hi = batch_offsets_host[b + 1];
       for (int64_t p = lo; p < hi || p == lo; p += kSegBytes) {
@@ -759,16 +761,33 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
                          static_cast<int64_t *>(nullptr));
       CRGPU_HIP(hipGetLastError());
     }
+    // The boundaries are verified, the segments' errors collected and their record counts scanned in one go; the verdict
+    // (segments whose guess was wrong), the grand total and the error word come back in ONE round trip.  Only if a guess
+    // was wrong (not seen outside crafted inputs) are the affected segments walked again and the round repeated.
+    uint64_t total = 0;
     for (int64_t iter = 0;; iter++) {
       if (iter > nseg) return fail(CRGPU_ERR_HIP, "crgpu_dev_decode_kv: record boundaries did not converge (internal error)");
       CRGPU_HIP(hipMemsetAsync(d->nbad.p, 0, 4, st));
       hipLaunchKernelGGL(kv_seg_verify_kernel, dim3(vgrid), dim3(256), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_start.as<int64_t>(),
                          d->seg_stop.as<int64_t>(), d->seg_err.as<int32_t>(), d->seg_flag.as<uint8_t>(), d->nbad.as<unsigned int>());
       CRGPU_HIP(hipGetLastError());
+      hipLaunchKernelGGL(kv_seg_errors_kernel, dim3(vgrid), dim3(256), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_err.as<int32_t>(),
+                         d->err.as<KvError>());
+      CRGPU_HIP(hipGetLastError());
+      CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, nullptr));
       unsigned int nbad = 0;
+      KvError e;
       CRGPU_HIP(hipMemcpyAsync(&nbad, d->nbad.p, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(&total, d->seg_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(&e, d->err.p, sizeof(e), hipMemcpyDeviceToHost, st));
       CRGPU_HIP(hipStreamSynchronize(st));
-      if (nbad == 0) break;
+      if (nbad == 0) {
+        if (e.first_row != ~0ull) return kv_check_error(d, "batch");  // (formats the message)
+        break;
+      }
+      // errors seen by a walk that started at a wrong boundary mean nothing: clear the word, walk those segments again
+      CRGPU_HIP(hipMemsetAsync(d->err.p, 0xFF, 8, st));
+      CRGPU_HIP(hipMemsetAsync(d->err.as<uint8_t>() + 8, 0, 8, st));
       ProfScope prof("kv_walk");
       hipLaunchKernelGGL(kv_seg_walk_kernel<1>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
                          d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
@@ -776,14 +795,6 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
                          static_cast<int64_t *>(nullptr));
       CRGPU_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(kv_seg_errors_kernel, dim3(vgrid), dim3(256), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_err.as<int32_t>(),
-                       d->err.as<KvError>());
-    CRGPU_HIP(hipGetLastError());
-    // row number of every segment's first record; the grand total comes back with the error word in one round trip
-    uint64_t total = 0;
-    CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, nullptr));
-    CRGPU_HIP(hipMemcpyAsync(&total, d->seg_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, st));
-    CRGPU_TRY(kv_check_error(d, "batch"));
     n = static_cast<int64_t>(total);
     if (n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_decode_kv: more than 2^31 rows in one call");
     if (n > 0) {
@@ -795,7 +806,6 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
                          d->rec_off.as<int64_t>());
       CRGPU_HIP(hipGetLastError());
     }
-    CRGPU_HIP(hipStreamSynchronize(st));  // `segs` is a host temporary
   }
   const int64_t cap = n > 0 ? n : 1;
   FetchOut o;
