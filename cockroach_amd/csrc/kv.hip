@@ -553,9 +553,22 @@ __device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, cons
 static constexpr int kDecodeStage = 60 * 1024;
 template <int PASS>
 __global__ __launch_bounds__(256) void kv_decode_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ rec_off,
-                                                        int64_t n, FetchSpec f, FetchOut o, KvError *__restrict__ err) {
+                                                        int64_t n, FetchSpec f_arg, FetchOut o_arg, KvError *__restrict__ err) {
   __shared__ __align__(16) uint8_t stage[kDecodeStage];
   __shared__ int64_t s_end;
+  // The parser indexes the column tables and the output pointers with per-lane indices (which value column a lane is
+  // at depends on its row's bytes).  As kernel arguments they live in scalar registers, where a per-lane index costs a
+  // loop over the distinct lane values per access (most of the kernel's instructions: 1300 scalar + 1000 vector per 64
+  // rows); from LDS it is one ds_read.
+  __shared__ FetchSpec s_f;
+  __shared__ FetchOut s_o;
+  if (threadIdx.x == 0) {
+    s_f = f_arg;
+    s_o = o_arg;
+  }
+  __syncthreads();
+  const FetchSpec &f = s_f;
+  const FetchOut &o = s_o;
   const int64_t ntiles = (n + 255) / 256;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * 256, row = row0 + threadIdx.x;
