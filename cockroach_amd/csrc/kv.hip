@@ -20,6 +20,7 @@
 // that neighbouring lanes share cache lines of.  BYTES outputs take two passes
 // (lengths -> scan -> copy).  Bound: HBM stream of the input bytes (read three times:
 // two walks + decode) plus the decoded columns.
+#include <cstdlib>
 #include <cstring>
 
 #include "device.h"
@@ -213,6 +214,7 @@ __device__ __forceinline__ int64_t peek_value_len(const uint8_t *b, int64_t len,
 // ------------------------------------------------------------------ record boundaries
 static constexpr int64_t kSegBytes = 32 * 1024;
 static constexpr int kSpecDepth = 6;
+static constexpr int kMaxRel = 2048;  // record positions a segment keeps from its counting walk (more: the writing walk runs)
 struct KvSeg {
   int64_t lo, hi;      // the batch response this segment belongs to
   int64_t begin, end;  // records that START in [begin, end) belong to the segment
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(64) void kv_seg_walk_kernel(const uint8_t *__restri
                                                          int64_t nseg, int plen, int64_t *__restrict__ start,
                                                          int64_t *__restrict__ stop, uint32_t *__restrict__ count,
                                                          int32_t *__restrict__ errc, const uint8_t *__restrict__ flag,
-                                                         const uint64_t *__restrict__ row_base, int64_t *__restrict__ rec_off) {
+                                                         const uint64_t *__restrict__ row_base, int64_t *__restrict__ rec_off,
+                                                         uint16_t *__restrict__ rel, unsigned int *__restrict__ rel_overflow) {
   __shared__ __align__(16) uint8_t win[kWalkWindow + 16];
   __shared__ int64_t s_pos;
   __shared__ int s_stop;
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(64) void kv_seg_walk_kernel(const uint8_t *__restri
             break;
           }
           if (MODE == 2) rec_off[out_base + nrec] = pos;
+          else if (nrec < kMaxRel) rel[s * kMaxRel + nrec] = static_cast<uint16_t>(pos - sg.begin);  // (pos in [begin, end))
           nrec++;
           pos = next;
         }
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(64) void kv_seg_walk_kernel(const uint8_t *__restri
       if (stopc) break;
     }
     if (MODE != 2 && threadIdx.x == 0) {
+      if (nrec > kMaxRel) atomicOr(rel_overflow, 1u);
       count[s] = static_cast<uint32_t>(nrec);
       stop[s] = pos;
       errc[s] = stopc;
@@ -355,6 +360,16 @@ __global__ __launch_bounds__(256) void kv_seg_verify_kernel(const KvSeg *__restr
   }
   flag[s] = f;
   if (f) atomicAdd(nbad, 1u);
+}
+// record offsets from the positions the counting walk kept: every lane writes (the walk itself keeps one lane busy)
+__global__ __launch_bounds__(64) void kv_rec_off_kernel(const KvSeg *__restrict__ segs, int64_t nseg, const uint32_t *__restrict__ count,
+                                                        const uint64_t *__restrict__ row_base, const uint16_t *__restrict__ rel,
+                                                        int64_t *__restrict__ rec_off) {
+  for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const uint32_t c = count[s];
+    const int64_t begin = segs[s].begin, base = static_cast<int64_t>(row_base[s]);
+    for (uint32_t r = threadIdx.x; r < c; r += 64) rec_off[base + r] = begin + rel[s * kMaxRel + r];
+  }
 }
 __global__ __launch_bounds__(256) void kv_seg_errors_kernel(const KvSeg *__restrict__ segs, int64_t nseg,
                                                             const int32_t *__restrict__ errc, KvError *__restrict__ err) {
@@ -635,6 +650,7 @@ using namespace crgpu;
 struct crgpu_decoder : crgpu::Handle {
   FetchSpec spec;
   std::vector<KvSeg> segs_host;
+  DevBuf seg_rel;
   DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
   std::vector<OutCol> out;
   std::vector<DevBuf> valid_bytes, lens, srcpos, offs64c;
@@ -761,7 +777,9 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
     CRGPU_TRY(d->seg_err.ensure(ns * 4));
     CRGPU_TRY(d->seg_flag.ensure(ns));
     CRGPU_TRY(d->seg_base.ensure((ns + 1) * 8));
-    CRGPU_TRY(d->nbad.ensure(4));
+    CRGPU_TRY(d->nbad.ensure(8));  // [0] segments whose guess was wrong (per round), [1] a segment kept more than kMaxRel records
+    CRGPU_TRY(d->seg_rel.ensure(ns * kMaxRel * 2));
+    CRGPU_HIP(hipMemsetAsync(d->nbad.p, 0, 8, st));
     CRGPU_HIP(hipMemcpyAsync(d->segs.p, segs.data(), ns * sizeof(KvSeg), hipMemcpyHostToDevice, st));
     const int plen = f.key_prefix_len < 8 ? f.key_prefix_len : 8;
     const unsigned wgrid = static_cast<unsigned>(nseg < static_cast<int64_t>(num_cus()) * 32 ? nseg : num_cus() * 32);
@@ -771,13 +789,14 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
       hipLaunchKernelGGL(kv_seg_walk_kernel<0>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
                          d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
                          d->seg_err.as<int32_t>(), static_cast<const uint8_t *>(nullptr), static_cast<const uint64_t *>(nullptr),
-                         static_cast<int64_t *>(nullptr));
+                         static_cast<int64_t *>(nullptr), d->seg_rel.as<uint16_t>(), d->nbad.as<unsigned int>() + 1);
       CRGPU_HIP(hipGetLastError());
     }
     // The boundaries are verified, the segments' errors collected and their record counts scanned in one go; the verdict
     // (segments whose guess was wrong), the grand total and the error word come back in ONE round trip.  Only if a guess
     // was wrong (not seen outside crafted inputs) are the affected segments walked again and the round repeated.
     uint64_t total = 0;
+    unsigned int rel_overflow = 0;
     for (int64_t iter = 0;; iter++) {
       if (iter > nseg) return fail(CRGPU_ERR_HIP, "crgpu_dev_decode_kv: record boundaries did not converge (internal error)");
       CRGPU_HIP(hipMemsetAsync(d->nbad.p, 0, 4, st));
@@ -788,12 +807,14 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
                          d->err.as<KvError>());
       CRGPU_HIP(hipGetLastError());
       CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, nullptr));
-      unsigned int nbad = 0;
+      unsigned int nb2[2] = {0, 0};
       KvError e;
-      CRGPU_HIP(hipMemcpyAsync(&nbad, d->nbad.p, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(nb2, d->nbad.p, 8, hipMemcpyDeviceToHost, st));
       CRGPU_HIP(hipMemcpyAsync(&total, d->seg_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, st));
       CRGPU_HIP(hipMemcpyAsync(&e, d->err.p, sizeof(e), hipMemcpyDeviceToHost, st));
       CRGPU_HIP(hipStreamSynchronize(st));
+      const unsigned int nbad = nb2[0];
+      rel_overflow = nb2[1];
       if (nbad == 0) {
         if (e.first_row != ~0ull) return kv_check_error(d, "batch");  // (formats the message)
         break;
@@ -805,7 +826,7 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
       hipLaunchKernelGGL(kv_seg_walk_kernel<1>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
                          d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
                          d->seg_err.as<int32_t>(), d->seg_flag.as<uint8_t>(), static_cast<const uint64_t *>(nullptr),
-                         static_cast<int64_t *>(nullptr));
+                         static_cast<int64_t *>(nullptr), d->seg_rel.as<uint16_t>(), d->nbad.as<unsigned int>() + 1);
       CRGPU_HIP(hipGetLastError());
     }
     n = static_cast<int64_t>(total);
@@ -813,10 +834,15 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
     if (n > 0) {
       CRGPU_TRY(d->rec_off.ensure(static_cast<size_t>(n) * 8));
       ProfScope prof("kv_walk");
-      hipLaunchKernelGGL(kv_seg_walk_kernel<2>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
-                         d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
-                         d->seg_err.as<int32_t>(), static_cast<const uint8_t *>(nullptr), d->seg_base.as<uint64_t>(),
-                         d->rec_off.as<int64_t>());
+      if (std::getenv("CRGPU_KV_WALK_TWICE") != nullptr) rel_overflow = 1;  // (tests: the form below)
+      if (rel_overflow != 0)  // a segment of more than kMaxRel records (records of < 16 bytes): walk again, writing
+        hipLaunchKernelGGL(kv_seg_walk_kernel<2>, dim3(wgrid), dim3(64), 0, st, repr_dev, d->segs.as<KvSeg>(), nseg, plen,
+                           d->seg_start.as<int64_t>(), d->seg_stop.as<int64_t>(), d->seg_count.as<uint32_t>(),
+                           d->seg_err.as<int32_t>(), static_cast<const uint8_t *>(nullptr), d->seg_base.as<uint64_t>(),
+                           d->rec_off.as<int64_t>(), static_cast<uint16_t *>(nullptr), static_cast<unsigned int *>(nullptr));
+      else
+        hipLaunchKernelGGL(kv_rec_off_kernel, dim3(wgrid), dim3(64), 0, st, d->segs.as<KvSeg>(), nseg, d->seg_count.as<uint32_t>(),
+                           d->seg_base.as<uint64_t>(), d->seg_rel.as<uint16_t>(), d->rec_off.as<int64_t>());
       CRGPU_HIP(hipGetLastError());
     }
   }

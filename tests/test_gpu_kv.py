@@ -156,7 +156,10 @@ def test_decode_segmented_walk_misleading_values(oracle):
     assert "truncated" in str(e.value)
 
 
-def test_decode_one_large_batch_many_segments(oracle):
+@pytest.mark.parametrize("walk_twice", [False, True])
+def test_decode_one_large_batch_many_segments(oracle, walk_twice, monkeypatch):
+    if walk_twice:  # the form a segment of more than 2048 records takes: the record offsets are written by a second walk
+        monkeypatch.setenv("CRGPU_KV_WALK_TWICE", "1")
     rng = np.random.default_rng(12)
     n = 150_000
     kt, kd, vt, ids = [cd.INT64, cd.BYTES], [0, 1], [cd.FLOAT64, cd.BYTES, cd.INT32], [4, 8, 9]
