@@ -1629,7 +1629,7 @@ static constexpr uint32_t kBulkRows = 2048;   // rows per tile = rows a sub-part
 static constexpr uint32_t kBulkSubSlots = 2048;   // sub form: LDS index slots / groups a sub-partition may hold
 static constexpr uint32_t kBulkSubGroups = 1536;
 struct BulkArgs {
-  const ulonglong2 *rows;       // {key, value} rows
+  const void *rows;             // {key, value} rows of 16 bytes, or (WIDE) {k0, k1, value, length} rows of 32 bytes
   const uint32_t *starts;       // part form: first row of region q (nullptr: q * kBulkRows)
   const uint32_t *counts;       // rows of region q
   OpK ops[kMaxOpsPerLaunch];    // accumulator pointers and LDS plane numbers; inputs all come from the row's value
@@ -1638,6 +1638,9 @@ struct BulkArgs {
   int32_t key_type;
   uint8_t *key_data;            // key store of the single group column
   uint8_t *key_present;
+  uint64_t *b_off;              // WIDE: the BYTES key store; group g's bytes go to b_buf[16 g, 16 g + 16)
+  uint32_t *b_len;
+  uint8_t *b_buf;
   unsigned long long *gword;
   unsigned int *ngroups;        // running group count (HBM)
   unsigned int *failed;         // a region held more than gmax groups
@@ -1645,7 +1648,49 @@ struct BulkArgs {
   uint32_t gmax;                // groups a region may hold (sized to the LDS the planes need)
   uint32_t slots;               // LDS index size (power of two, > gmax)
 };
+template <bool WIDE>
+struct BulkRow;
+template <>
+struct BulkRow<false> {
+  typedef ulonglong2 T;
+  static __device__ __forceinline__ bool same_key(const T &a, const T &b) { return a.x == b.x; }
+  static __device__ __forceinline__ unsigned long long value(const T &r) { return r.y; }
+  static __device__ __forceinline__ uint32_t slot_hash(const T &r) { return static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20); }
+  // the group's key and the hash word of the index entry it gets if the index is ever rebuilt (agg_hash of one INT64 column)
+  static __device__ __forceinline__ void store_key(const BulkArgs &a, uint32_t gid, const T &r) {
+    reinterpret_cast<unsigned long long *>(a.key_data)[gid] = r.x;
+    a.key_present[gid] = 1;
+    const uint64_t h = fmix64(hash_step(0x9E3779B97F4A7C15ull, r.x));
+    a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
+                   (static_cast<uint32_t>(h) & kIdxHashMask);
+  }
+};
+template <>
+struct BulkRow<true> {
+  typedef ulonglong4 T;
+  static __device__ __forceinline__ bool same_key(const T &a, const T &b) { return a.x == b.x && a.y == b.y && a.w == b.w; }
+  static __device__ __forceinline__ unsigned long long value(const T &r) { return r.z; }
+  static __device__ __forceinline__ uint32_t slot_hash(const T &r) {
+    return static_cast<uint32_t>(fmix64(wide_key_hash(r.x, r.y, r.w) ^ 0x5851F42D4C957F2Dull) >> 20);
+  }
+  // agg_hash of one BYTES column: the full 8-byte words, the zero-padded rest, then the length
+  static __device__ __forceinline__ void store_key(const BulkArgs &a, uint32_t gid, const T &r) {
+    reinterpret_cast<ulonglong2 *>(a.b_buf)[gid] = make_ulonglong2(r.x, r.y);
+    a.b_off[gid] = static_cast<uint64_t>(gid) * 16u;
+    a.b_len[gid] = static_cast<uint32_t>(r.w);
+    a.key_present[gid] = 1;
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    if (r.w > 0) h = hash_step(h, r.x);
+    if (r.w > 8) h = hash_step(h, r.y);
+    h = fmix64(hash_step(h, 0xB17E5ull + r.w));
+    a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
+                   (static_cast<uint32_t>(h) & kIdxHashMask);
+  }
+};
+template <bool WIDE>
 __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
+  typedef BulkRow<WIDE> R;
+  typedef typename R::T Row;
   // dynamic LDS: [nwords][gmax + 1] accumulator words, [slots] slot -> representative row, [slots] slot -> local group
   // id, [gmax] local group id -> representative row, then the seen planes (bytes)
   extern __shared__ unsigned long long lds_words[];
@@ -1659,7 +1704,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
   const int q = blockIdx.x;
   const uint32_t n = a.counts[q];
   if (n == 0) return;
-  const ulonglong2 *rows = a.rows + (a.starts != nullptr ? static_cast<int64_t>(a.starts[q]) : static_cast<int64_t>(q) * kBulkRows);
+  const Row *rows = static_cast<const Row *>(a.rows) + (a.starts != nullptr ? static_cast<int64_t>(a.starts[q]) : static_cast<int64_t>(q) * kBulkRows);
   const uint32_t smask = a.slots - 1;
   // A region of one tile (the sub form: <= kBulkRows rows) whose keys all turn out distinct needs no accumulator planes:
   // every row IS its group's result.  The planes are therefore set up after the first tile's find-or-insert.
@@ -1692,9 +1737,9 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       slot_of[k] = kNone;
       val[k] = 0;
       if (i < n) {
-        const ulonglong2 r = rows[i];
-        val[k] = r.y;
-        uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & smask;
+        const Row r = rows[i];
+        val[k] = R::value(r);
+        uint32_t sl = R::slot_hash(r) & smask;
         uint32_t probes = 0;
         for (;; probes++) {
           if (probes == a.slots) {  // the index is full of other keys: far more groups than the planes hold
@@ -1712,7 +1757,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
               break;
             }
           }
-          if (rows[cur].x == r.x) break;
+          if (R::same_key(rows[cur], r)) break;
           sl = (sl + 1) & smask;
         }
         slot_of[k] = sl;
@@ -1732,12 +1777,8 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       for (int k = 0; k < kRows; k++) {
         if (slot_of[k] == kNone) continue;
         const uint32_t gid = base + lid[slot_of[k]];
-        const unsigned long long key = rows[t0 + k * blockDim.x + threadIdx.x].x, v = val[k];
-        reinterpret_cast<unsigned long long *>(a.key_data)[gid] = key;
-        a.key_present[gid] = 1;
-        const uint64_t h = fmix64(hash_step(0x9E3779B97F4A7C15ull, key));
-        a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
-                       (static_cast<uint32_t>(h) & kIdxHashMask);
+        const unsigned long long v = val[k];
+        R::store_key(a, gid, rows[t0 + k * blockDim.x + threadIdx.x]);
         for (int f = 0; f < a.naggs; f++) {
           const OpK &op = a.ops[f];
           unsigned long long w0 = v, w1 = 0;
@@ -1792,13 +1833,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
   const uint32_t base = a.g0 + s_base;
   for (uint32_t l = threadIdx.x; l < ngrp; l += blockDim.x) {
     const uint32_t gid = base + l;
-    const unsigned long long key = rows[rep[l]].x;
-    reinterpret_cast<unsigned long long *>(a.key_data)[gid] = key;
-    a.key_present[gid] = 1;
-    // hash word of the index entry this group gets if the index is ever rebuilt (agg_hash of one INT64 column)
-    const uint64_t h = fmix64(hash_step(0x9E3779B97F4A7C15ull, key));
-    a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
-                   (static_cast<uint32_t>(h) & kIdxHashMask);
+    R::store_key(a, gid, rows[rep[l]]);
     for (int f = 0; f < a.naggs; f++) {
       const OpK &op = a.ops[f];
       op.w0[gid] = lds_words[static_cast<size_t>(op.lw0) * plane + l];
@@ -2791,7 +2826,9 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
-    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel),
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_part_accum_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
@@ -3572,14 +3609,42 @@ __global__ void agg_sample_keys_kernel(const long long *__restrict__ keys, int64
   if (i < nsample) out[i] = keys[static_cast<int64_t>(i) * stride];
 }
 
+// BYTES keys: the sample holds a 64-bit hash of each sampled key; out[nsample] is set when a sampled key is longer than
+// the 16 bytes a wide row holds
+__global__ void agg_sample_wide_kernel(DCol key, int64_t stride, int nsample, long long *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsample) return;
+  const int64_t r = static_cast<int64_t>(i) * stride;
+  const uint32_t a0 = key.offsets[r], len = key.offsets[r + 1] - a0;
+  if (len > 16u) {
+    out[nsample] = 1;
+    out[i] = 0;
+    return;
+  }
+  const uint8_t *p = static_cast<const uint8_t *>(key.data) + a0;
+  uint64_t k0 = 0, k1 = 0;
+  for (uint32_t j = 0; j < len; j++) {
+    if (j < 8) k0 |= static_cast<uint64_t>(p[j]) << (8u * j);
+    else k1 |= static_cast<uint64_t>(p[j]) << (8u * (j - 8));
+  }
+  out[i] = static_cast<long long>(wide_key_hash(k0, k1, len));
+}
+
 // Bulk path (see agg_bulk_kernel).  *done = true when the whole input was aggregated; otherwise nothing was changed
 // and the caller continues with the incremental path.
 static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
   *done = false;
   if (a->ngroups != 0 || a->seq != 0 || n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
-  if (a->group_cols.size() != 1 || a->types[a->group_cols[0]] != CRGPU_INT64) return CRGPU_OK;
+  if (a->group_cols.size() != 1) return CRGPU_OK;
+  const int key_type = a->types[a->group_cols[0]];
+  // INT64 keys travel as 16-byte {key, value} rows; BYTES keys of at most 16 bytes as 32-byte {k0, k1, value, length}
+  // rows (wide form, the sub form only: it exists for config G's all-distinct string keys)
+  const bool wide = key_type == CRGPU_BYTES;
+  if (key_type != CRGPU_INT64 && !wide) return CRGPU_OK;
+  static const bool wide_on = getenv("CRGPU_BULK_WIDE") == nullptr || getenv("CRGPU_BULK_WIDE")[0] != '0';
+  if (wide && !wide_on) return CRGPU_OK;
   const DCol &key = cols[a->group_cols[0]];
-  if (key.valid != nullptr || (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0) return CRGPU_OK;
+  if (key.valid != nullptr || (!wide && (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0)) return CRGPU_OK;
   int vcol = -1, nops = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
@@ -3592,7 +3657,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     }
   }
   if (nops > kMaxOpsPerLaunch) return CRGPU_OK;
-  if (vcol >= 0 && (cols[vcol].valid != nullptr || (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0)) return CRGPU_OK;
+  if (vcol >= 0 && (cols[vcol].valid != nullptr || (!wide && (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0))) return CRGPU_OK;
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0) return CRGPU_OK;
   hipStream_t st = stream();
@@ -3603,12 +3668,19 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   for (const int kSample : {512, kBigSample}) {
     std::vector<int64_t> sample(kSample);
     const int64_t stride = n / kSample;
-    CRGPU_TRY(a->scratch.ensure(static_cast<size_t>(kSample) * 8));
-    hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), stride,
-                       kSample, a->scratch.as<long long>());
+    CRGPU_TRY(a->scratch.ensure(static_cast<size_t>(kSample + 1) * 8));
+    if (wide) {
+      sample.resize(kSample + 1);
+      CRGPU_HIP(hipMemsetAsync(a->scratch.as<long long>() + kSample, 0, 8, st));
+      hipLaunchKernelGGL(agg_sample_wide_kernel, dim3(kSample / 256), dim3(256), 0, st, key, stride, kSample, a->scratch.as<long long>());
+    } else {
+      hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), stride,
+                         kSample, a->scratch.as<long long>());
+    }
     CRGPU_HIP(hipGetLastError());
-    CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, static_cast<size_t>(kSample) * 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, sample.size() * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
+    if (wide && sample[kSample] != 0) return CRGPU_OK;  // keys longer than 16 bytes
     // distinct keys and the largest multiplicity of the sample, by open addressing (sorting 8192 keys took 0.3 ms)
     const size_t tab = static_cast<size_t>(kSample) * 4;
     std::vector<int64_t> tkey(tab);
@@ -3631,6 +3703,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   if (dmax < 8) dmax = 8;
   if (dmax > kBigSample / 4) dmax = kBigSample / 4;
   const bool sub_form = kBigSample - distinct <= dmax;
+  if (wide && !sub_form) return CRGPU_OK;
   size_t gmax = 0, slots = 0;
   if (sub_form) {
     slots = kBulkSubSlots;
@@ -3673,7 +3746,15 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   src.pay = vcol >= 0 ? static_cast<const uint8_t *>(cols[vcol].data) : nullptr;
   src.pay_width = vcol >= 0 ? 8 : 0;
   src.fast = vcol >= 0 ? 1 : 0;
-  if (sub_form) {
+  if (wide) {
+    WideSrc ws;
+    ws.key = key;
+    ws.val = vcol >= 0 ? static_cast<const unsigned long long *>(cols[vcol].data) : nullptr;
+    bool ok = false;
+    CRGPU_TRY(radix_partition_split_wide(a->radix, ws, n, &ok, kBulkRows, 10, 7));
+    if (!ok) return CRGPU_OK;  // a sub-partition overflowed, or a key is longer than 16 bytes
+    CRGPU_TRY(a->ks[0].b_buf.ensure(static_cast<size_t>(n) * 16 + 16));
+  } else if (sub_form) {
     bool ok = false;
     CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
     if (!ok) return CRGPU_OK;  // a sub-partition overflowed: many rows per key after all
@@ -3686,7 +3767,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 8, st));
   BulkArgs b;
   std::memset(&b, 0, sizeof(b));
-  b.rows = sub_form ? a->radix.rows_b.as<ulonglong2>() : a->radix.rows_a.as<ulonglong2>();
+  b.rows = sub_form ? a->radix.rows_b.p : a->radix.rows_a.p;
   b.starts = sub_form ? nullptr : a->radix.starts.as<uint32_t>();
   b.counts = sub_form ? a->radix.sub_count.as<uint32_t>() : a->radix.totals.as<uint32_t>();
   int f = 0;
@@ -3705,9 +3786,12 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.naggs = f;
   b.nwords = static_cast<uint32_t>(a->lds_words);
   b.nseen = static_cast<uint32_t>(a->lds_seen);
-  b.key_type = CRGPU_INT64;
+  b.key_type = key_type;
   b.key_data = a->ks[0].data.as<uint8_t>();
   b.key_present = a->ks[0].present.as<uint8_t>();
+  b.b_off = a->ks[0].b_off.as<uint64_t>();
+  b.b_len = a->ks[0].b_len.as<uint32_t>();
+  b.b_buf = a->ks[0].b_buf.as<uint8_t>();
   b.gword = a->gword.as<unsigned long long>();
   b.ngroups = a->bulk_count.as<unsigned int>();
   b.failed = a->bulk_count.as<unsigned int>() + 1;
@@ -3717,7 +3801,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) << a->radix.sub_bits : static_cast<unsigned>(kRadixP1);
   {
     ProfScope prof(sub_form ? "agg_bulk" : "agg_bulk_part");
-    hipLaunchKernelGGL(agg_bulk_kernel, dim3(nregions), dim3(1024), lds, st, b);
+    if (wide) hipLaunchKernelGGL(agg_bulk_kernel<true>, dim3(nregions), dim3(1024), lds, st, b);
+    else hipLaunchKernelGGL(agg_bulk_kernel<false>, dim3(nregions), dim3(1024), lds, st, b);
     CRGPU_HIP(hipGetLastError());
   }
   unsigned int tf[2] = {0, 0};
@@ -3725,6 +3810,12 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   CRGPU_HIP(hipStreamSynchronize(st));
   if (tf[1]) return CRGPU_OK;  // nothing was committed: the groups written so far lie beyond ngroups == 0
   const unsigned int total = tf[0];
+  if (wide) {  // the key bytes of group g lie at 16 g: later appends (find-or-insert) continue behind them
+    a->ks[0].tail = static_cast<uint64_t>(total) * 16u;
+    CRGPU_HIP(hipMemcpyAsync(a->tails_dev.p, &a->ks[0].tail, 8, hipMemcpyHostToDevice, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    a->descriptors_dirty = true;
+  }
   a->ngroups = total;
   a->seq = static_cast<unsigned long long>(n);
   a->new_ratio = static_cast<double>(total) / static_cast<double>(n);

@@ -81,6 +81,17 @@ crgpu_status radix_partition_level1(RadixTable &t, const RadixSrc &src, int64_t 
 // About 2^log2_rows_per_sub rows per sub-partition, at most 2^max_sub_bits (<= 7) sub-partitions per partition.
 crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,
                                    int max_sub_bits);
+// Hash aggregation over a BYTES key column whose values are at most 16 bytes long: 32-byte rows {k0, k1, value, length}
+// (the key's bytes little-endian in two zero-padded words) through the same two partition levels.
+struct WideSrc {
+  DCol key;                        // BYTES, no NULLs
+  const unsigned long long *val;   // optional 8-byte value column (no NULLs), else the value is 0
+};
+__device__ __forceinline__ uint64_t wide_key_hash(uint64_t k0, uint64_t k1, uint64_t len) {
+  return fmix64(k0 ^ fmix64(k1 + len * 0x9E3779B97F4A7C15ull));
+}
+crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64_t n, bool *ok, uint32_t subcap,
+                                        int log2_rows_per_sub, int max_sub_bits);
 // Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows
 // kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
 crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok);

@@ -369,6 +369,198 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
   }
 }
 
+// ------------------------------------------------------------------ wide rows: <= 16-byte BYTES keys (hash aggregation)
+// The same two partition levels for 32-byte rows {k0, k1, value, length}: the key's bytes little-endian in two words,
+// zero-padded, so two keys are equal exactly when (k0, k1, length) are.  A 128-byte line holds four rows.  Keys longer
+// than 16 bytes raise bit 1 of the flag (the caller abandons the attempt); they are skipped by both passes alike.
+__device__ __forceinline__ bool wide_load(const WideSrc &s, int64_t r, ulonglong4 *row) {
+  const uint32_t a0 = s.key.offsets[r], len = s.key.offsets[r + 1] - a0;
+  const uint8_t *p = static_cast<const uint8_t *>(s.key.data) + a0;
+  uint64_t k0 = 0, k1 = 0;
+  if (len > 16u) return false;
+  if (len >= 8u) {  // unaligned 8-byte loads inside the value
+    __builtin_memcpy(&k0, p, 8);
+    if (len > 8u) {
+      uint64_t t;
+      __builtin_memcpy(&t, p + len - 8, 8);
+      k1 = t >> (8u * (16u - len));
+    }
+  } else {
+    for (uint32_t j = 0; j < len; j++) k0 |= static_cast<uint64_t>(p[j]) << (8u * j);
+  }
+  *row = make_ulonglong4(k0, k1, s.val != nullptr ? s.val[r] : 0ull, len);
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void wide_hist_kernel(WideSrc src, int64_t n, int64_t chunk_rows,
+                                                         uint32_t *__restrict__ hist, uint32_t *__restrict__ flag) {
+  __shared__ uint32_t h[kRadixP1];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t lo = blockIdx.x * chunk_rows;
+  int64_t hi = lo + chunk_rows;
+  if (hi > n) hi = n;
+  bool bad = false;
+  for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4096) {
+    ulonglong4 row[4];
+    bool ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t r = r0 + j * 1024;
+      ok[j] = false;
+      if (r < hi) {
+        ok[j] = wide_load(src, r, &row[j]);
+        bad |= !ok[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (ok[j]) atomicAdd(&h[rpart(wide_key_hash(row[j].x, row[j].y, row[j].w))], 1u);
+  }
+  if (bad) atomicOr(flag, 2u);
+  __syncthreads();
+  hist[static_cast<int64_t>(blockIdx.x) * kRadixP1 + threadIdx.x] = h[threadIdx.x];
+}
+
+// radix_scatter_kernel for 32-byte rows: four rows per line buffer, otherwise the same four phases.
+__global__ __launch_bounds__(1024) void wide_scatter_kernel(WideSrc src, int64_t n, int64_t chunk_rows,
+                                                            const uint32_t *__restrict__ offs, ulonglong4 *__restrict__ out) {
+  constexpr int P = kRadixP1, THREADS = 1024, ROWS = 4, TILE = THREADS * ROWS, RPL = 4;
+  __shared__ ulonglong4 bins[P * RPL];
+  __shared__ uint32_t cnt[P];
+  __shared__ uint32_t gbase[P];
+  __shared__ uint8_t first[P];
+  {
+    const uint32_t g0 = offs[static_cast<int64_t>(blockIdx.x) * P + threadIdx.x];
+    const uint32_t a = g0 & (RPL - 1u);
+    gbase[threadIdx.x] = g0 - a;
+    cnt[threadIdx.x] = a;
+    first[threadIdx.x] = static_cast<uint8_t>(a);
+  }
+  __syncthreads();
+  const int64_t lo = blockIdx.x * chunk_rows;
+  int64_t hi = lo + chunk_rows;
+  if (hi > n) hi = n;
+  ulonglong4 nrow[ROWS];
+  bool nok[ROWS];
+#pragma unroll
+  for (int j = 0; j < ROWS; j++) {
+    const int64_t r = lo + j * THREADS + threadIdx.x;
+    nok[j] = r < hi && wide_load(src, r, &nrow[j]);
+  }
+  for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
+    ulonglong4 row[ROWS];
+    uint32_t pp[ROWS], rk[ROWS], nfl[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      row[j] = nrow[j];
+      pp[j] = nok[j] ? rpart(wide_key_hash(row[j].x, row[j].y, row[j].w)) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {  // the next tile is requested while this one is ranked and flushed
+      const int64_t r = t0 + TILE + j * THREADS + threadIdx.x;
+      nok[j] = r < hi && wide_load(src, r, &nrow[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      if (pp[j] != 0xFFFFFFFFu) rk[j] = atomicAdd(&cnt[pp[j]], 1u);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      if (pp[j] != 0xFFFFFFFFu) {
+        nfl[j] = cnt[pp[j]] & ~(RPL - 1u);
+        if (rk[j] < RPL) bins[pp[j] * RPL + rk[j]] = row[j];
+        else if (rk[j] < nfl[j]) out[gbase[pp[j]] + rk[j]] = row[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P * RPL; i += THREADS) {
+      const int p = i / RPL, sl = i % RPL;
+      if (cnt[p] >= RPL && sl >= static_cast<int>(first[p])) out[gbase[p] + sl] = bins[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      if (pp[j] != 0xFFFFFFFFu && rk[j] >= RPL && rk[j] >= nfl[j]) bins[pp[j] * RPL + (rk[j] - nfl[j])] = row[j];
+    {
+      const uint32_t t = cnt[threadIdx.x], f = t & ~(RPL - 1u);
+      if (f) {
+        gbase[threadIdx.x] += f;
+        cnt[threadIdx.x] = t - f;
+        first[threadIdx.x] = 0;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < P * RPL; i += THREADS) {
+    const int p = i / RPL, sl = i % RPL;
+    if (sl >= static_cast<int>(first[p]) && sl < static_cast<int>(cnt[p])) out[gbase[p] + sl] = bins[i];
+  }
+}
+
+// radix_split_kernel for 32-byte rows (tiles of 2048 rows: the same 64 KiB of staging)
+__global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__restrict__ in, const uint32_t *__restrict__ starts,
+                                                          const uint32_t *__restrict__ totals, uint32_t smask,
+                                                          ulonglong4 *__restrict__ out, uint32_t *__restrict__ sub_count,
+                                                          uint32_t *__restrict__ overflow, uint32_t subcap) {
+  constexpr int THREADS = 1024, ROWS = 2, TILE = THREADS * ROWS;
+  const int p = blockIdx.x;
+  const uint32_t nsub = smask + 1;
+  __shared__ ulonglong4 stage[TILE];
+  __shared__ uint32_t tcnt[128], tstart[128], cur[128];
+  __shared__ uint32_t s_half;
+  if (threadIdx.x < 128) tcnt[threadIdx.x] = 0, cur[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t s0 = starts[p], n = totals[p];
+  ulonglong4 *obase = out + static_cast<int64_t>(p) * nsub * subcap;
+  for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+    ulonglong4 row[ROWS];
+    uint32_t sp[ROWS], rk[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) {
+      const uint32_t i = t0 + j * THREADS + threadIdx.x;
+      sp[j] = 0xFFFFFFFFu;
+      if (i < n) {
+        row[j] = in[s0 + i];
+        sp[j] = rsub(wide_key_hash(row[j].x, row[j].y, row[j].w), smask);
+        rk[j] = atomicAdd(&tcnt[sp[j]], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const uint32_t c = tcnt[threadIdx.x];
+      const uint32_t incl = wave_incl_scan_u32(c);
+      tstart[threadIdx.x] = incl - c;
+      if (threadIdx.x == 63) s_half = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < 128) tstart[threadIdx.x] += s_half;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+      if (sp[j] != 0xFFFFFFFFu) stage[tstart[sp[j]] + rk[j]] = row[j];
+    __syncthreads();
+    const uint32_t tile_rows = n - t0 < static_cast<uint32_t>(TILE) ? n - t0 : TILE;
+    for (uint32_t i = threadIdx.x; i < tile_rows; i += THREADS) {
+      const ulonglong4 r = stage[i];
+      const uint32_t s = rsub(wide_key_hash(r.x, r.y, r.w), smask);
+      const uint32_t pos = cur[s] + (i - tstart[s]);
+      if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      cur[threadIdx.x] += tcnt[threadIdx.x];
+      tcnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < nsub) {
+    const uint32_t c = cur[threadIdx.x];
+    sub_count[p * nsub + threadIdx.x] = c;
+    if (c > subcap) atomicOr(overflow, 1u);
+  }
+}
+
 // ------------------------------------------------------------------ level 3 (build side): one table per sub-partition
 // A divergent 16-byte load costs ~2 cycles per ACTIVE lane on a CU (measured: 270 G lane-loads/s
 // chip-wide, L1 or L2 hit alike), and a wave keeps looping until its slowest lane is done, so a
@@ -1398,6 +1590,65 @@ crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n
   CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
   *ok = overflow == 0;
+  return CRGPU_OK;
+}
+
+// Levels 1 and 2 for 32-byte rows {k0, k1, value, length} (<= 16-byte BYTES keys): t.rows_b holds the rows of
+// sub-partition q in [q * subcap, q * subcap + sub_count[q]).  *ok = false when a sub-partition overflowed its region or
+// a key is longer than 16 bytes.
+crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64_t n, bool *ok, uint32_t subcap,
+                                        int log2_rows_per_sub, int max_sub_bits) {
+  hipStream_t st = stream();
+  *ok = false;
+  t.ready = false;
+  t.n = n;
+  int lg = 0;
+  while ((int64_t(1) << lg) < n) lg++;
+  int sb = lg - 10 - log2_rows_per_sub;
+  if (sb < 0) sb = 0;
+  if (sb > max_sub_bits) sb = max_sub_bits;
+  t.sub_bits = sb;
+  const uint32_t nsub = 1u << sb;
+  int nchunks;
+  int64_t chunk_rows;
+  chunking(n, &nchunks, &chunk_rows);
+  CRGPU_TRY(t.hist.ensure(static_cast<size_t>(nchunks) * kRadixP1 * 4));
+  CRGPU_TRY(t.totals.ensure(kRadixP1 * 4));
+  CRGPU_TRY(t.starts.ensure(kRadixP1 * 4));
+  CRGPU_TRY(t.rows_a.ensure(static_cast<size_t>(n + 8 * kRadixP1) * 32));
+  CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(kRadixP1) * nsub * subcap * 32));
+  CRGPU_TRY(t.sub_count.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
+  CRGPU_TRY(t.flag.ensure(4));
+  CRGPU_HIP(hipMemsetAsync(t.flag.p, 0, 4, st));
+  {
+    ProfScope prof("radix_build_hist");
+    hipLaunchKernelGGL(wide_hist_kernel, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, t.hist.as<uint32_t>(),
+                       t.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_colsum_kernel, dim3(kRadixP1 / 64), dim3(1024), 0, st, t.hist.as<uint32_t>(), nchunks,
+                       t.totals.as<uint32_t>());
+    hipLaunchKernelGGL(radix_starts_kernel, dim3(1), dim3(1024), 0, st, t.totals.as<uint32_t>(), t.starts.as<uint32_t>());
+    hipLaunchKernelGGL(radix_offs_kernel, dim3(kRadixP1 / 64), dim3(1024), 0, st, t.hist.as<uint32_t>(), nchunks,
+                       t.starts.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  {
+    ProfScope prof("radix_build_scatter");
+    hipLaunchKernelGGL(wide_scatter_kernel, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, t.hist.as<uint32_t>(),
+                       t.rows_a.as<ulonglong4>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  {
+    ProfScope prof("radix_build_split");
+    hipLaunchKernelGGL(wide_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong4>(), t.starts.as<uint32_t>(),
+                       t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong4>(), t.sub_count.as<uint32_t>(),
+                       t.flag.as<uint32_t>(), subcap);
+    CRGPU_HIP(hipGetLastError());
+  }
+  uint32_t flag = 0;
+  CRGPU_HIP(hipMemcpyAsync(&flag, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  *ok = flag == 0;
   return CRGPU_OK;
 }
 

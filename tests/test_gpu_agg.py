@@ -343,6 +343,115 @@ def test_agg_bulk_path_then_more_input_vs_oracle(oracle):
     assert np.array_equal(_canon(got), _canon(want))
 
 
+def _bytes_vec(mat, lens):
+    """uint8[n, w] + per-row lengths -> BYTES Vec holding the first lens[i] bytes of row i."""
+    keep = np.arange(mat.shape[1])[None, :] < lens[:, None]
+    offs = np.concatenate([[0], np.cumsum(lens, dtype=np.int64)]).astype(np.uint32)
+    return cd.Vec(cd.BYTES, mat[keep], None, offs)
+
+
+def _bytes_as_int_cols(v):
+    """A BYTES column of values <= 24 bytes as four INT64 columns (three zero-padded words + the length), so that results
+    with BYTES keys go through the fixed-width canonical form."""
+    offs = v.offsets.astype(np.int64)
+    lens = offs[1:] - offs[:-1]
+    assert lens.max(initial=0) <= 24
+    mat = np.zeros((v.n, 24), dtype=np.uint8)
+    rows = np.repeat(np.arange(v.n), lens)
+    cols = np.arange(int(lens.sum())) - np.repeat(offs[:-1] - offs[0], lens)
+    mat[rows, cols] = v.data[offs[0]:offs[-1]]
+    words = mat.view(np.int64)
+    return [cd.Vec.from_numpy(cd.INT64, words[:, j].copy()) for j in range(3)] + [cd.Vec.from_numpy(cd.INT64, lens)]
+
+
+def _wide_keys(rng, count):
+    """`count` distinct keys of 0 ... 16 bytes: the bytes of i, then filler (often zero bytes), cut to a random length >= 3;
+    for the first thousand i also the same bytes one longer (keys that differ by one trailing byte, zero or not), and the
+    empty and one- and two-byte keys."""
+    i = np.arange(count, dtype=np.int64)
+    mat = np.zeros((count, 16), dtype=np.uint8)
+    mat[:, :8] = i.view(np.uint8).reshape(count, 8)
+    fill = rng.integers(0, 256, size=(count, 13), dtype=np.uint8)
+    fill[rng.random(count) < 0.3] = 0
+    mat[:, 3:] = fill
+    lens = rng.choice([3, 5, 8, 9, 12, 15, 16], size=count, p=[.05, .05, .1, .1, .1, .1, .5]).astype(np.int64)
+    extra = np.arange(1000)
+    extra = extra[lens[extra] < 16]
+    lens2 = lens[extra] + 1
+    lens[count - extra.size:] = lens2          # the last keys are replaced by the one-longer twins of the first
+    mat[count - extra.size:] = mat[extra]
+    special = [b"", b"\x00", b"\x00\x00", b"a", b"ab"]
+    for j, b in enumerate(special):
+        r = 2000 + j
+        mat[r] = 0
+        mat[r, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        lens[r] = len(b)
+    return mat, lens
+
+
+def test_agg_bulk_wide_bytes_keys_vs_oracle(oracle):
+    """BYTES keys of at most 16 bytes take the wide form of the bulk path (32-byte rows {k0, k1, value, length}): keys of
+    every length from 0 to 16, keys that differ only in their length or in a trailing zero byte, every key twice; the
+    second input (old keys, new keys, keys longer than 16 bytes) goes through the index rebuilt from the groups' hash
+    words and the key store the bulk path filled."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(31)
+    n1, n2 = 1 << 23, 120_000
+    mat, lens = _wide_keys(rng, n1 // 2)
+    pick = np.concatenate([np.arange(n1 // 2), np.arange(n1 // 2)])
+    rng.shuffle(pick)
+    k1 = _bytes_vec(mat[pick], lens[pick])
+    old = rng.integers(0, n1 // 2, size=n2 // 2)
+    new = np.zeros((n2 // 2, 24), dtype=np.uint8)
+    new[:, :8] = (np.arange(n2 // 2, dtype=np.int64) + (1 << 40)).view(np.uint8).reshape(-1, 8)
+    new[:, 8:] = 7
+    new_lens = rng.choice([8, 16, 17, 24], size=n2 // 2).astype(np.int64)
+    mat2 = np.zeros((n2, 24), dtype=np.uint8)
+    mat2[:n2 // 2, :16] = mat[old]
+    mat2[n2 // 2:] = new
+    k2 = _bytes_vec(mat2, np.concatenate([lens[old], new_lens]))
+    x = rng.integers(-10**9, 10**9, size=n1 + n2, dtype=np.int64)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["MIN"], 1, -1), (F["MAX"], 1, -1)]
+    a = dev.Agg([cd.BYTES, cd.INT64], [0], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(k1), dev.upload(cd.Vec.from_numpy(cd.INT64, x[:n1]))], n1)
+    assert dev.prof_get("agg_bulk")[1] == 1, "the wide form of the bulk path did not run"
+    a.consume([dev.upload(k2), dev.upload(cd.Vec.from_numpy(cd.INT64, x[n1:]))], n2)
+    dev.prof_enable(False)
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    kall = cd.Vec(cd.BYTES, np.concatenate([k1.data, k2.data]), None,
+                  np.concatenate([k1.offsets, k2.offsets[1:].astype(np.int64) + int(k1.offsets[-1])]).astype(np.uint32))
+    want = oracle.hash_agg([kall, cd.Vec.from_numpy(cd.INT64, x)], [0], aggs)
+    assert got[0].n == want[0].n == n1 // 2 + n2 // 2
+    assert np.array_equal(_canon(_bytes_as_int_cols(got[0]) + got[1:]), _canon(_bytes_as_int_cols(want[0]) + want[1:]))
+
+
+def test_agg_bulk_wide_abandoned_on_a_long_key(oracle):
+    """One 17-byte key that the 8192-row sample does not see: the histogram pass of the wide form reports it, the
+    attempt is abandoned before anything is committed, and the incremental path gives the oracle's result."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(32)
+    n = 1 << 23
+    mat = np.zeros((n, 17), dtype=np.uint8)
+    mat[:, :8] = rng.permutation(n).astype(np.int64).view(np.uint8).reshape(n, 8)
+    mat[:, 8:] = 0x41
+    lens = np.full(n, 16, dtype=np.int64)
+    lens[12345] = 17
+    k = _bytes_vec(mat, lens)
+    x = cd.Vec.from_numpy(cd.INT64, rng.integers(-1000, 1000, size=n, dtype=np.int64))
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    dev.prof_enable(True)
+    dev.prof_reset()
+    got = G.gpu_agg([k, x], [0], aggs)
+    assert dev.prof_get("radix_build_hist")[1] == 1 and dev.prof_get("agg_bulk")[1] == 0, "expected an abandoned wide attempt"
+    dev.prof_enable(False)
+    want = oracle.hash_agg([k, x], [0], aggs)
+    assert got[0].n == n
+    assert np.array_equal(_canon(_bytes_as_int_cols(got[0]) + got[1:]), _canon(_bytes_as_int_cols(want[0]) + want[1:]))
+
+
 @pytest.mark.parametrize("ngroups", [20_000, 150_000])
 def test_agg_bulk_part_form_vs_oracle(oracle, ngroups):
     """Mid cardinality (tens to ~2000 groups per radix partition): the bulk path without the level-2 split; a
