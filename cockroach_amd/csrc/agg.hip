@@ -1644,6 +1644,7 @@ struct BulkArgs {
   unsigned long long *gword;
   unsigned int *ngroups;        // running group count (HBM)
   unsigned int *failed;         // a region held more than gmax groups
+  unsigned int *not16;          // WIDE: some group's key is not exactly 16 bytes long
   uint32_t g0;
   uint32_t gmax;                // groups a region may hold (sized to the LDS the planes need)
   uint32_t slots;               // LDS index size (power of two, > gmax)
@@ -1678,6 +1679,7 @@ struct BulkRow<true> {
     reinterpret_cast<ulonglong2 *>(a.b_buf)[gid] = make_ulonglong2(r.x, r.y);
     a.b_off[gid] = static_cast<uint64_t>(gid) * 16u;
     a.b_len[gid] = static_cast<uint32_t>(r.w);
+    if (r.w != 16) *a.not16 = 1u;
     a.key_present[gid] = 1;
     uint64_t h = 0x9E3779B97F4A7C15ull;
     if (r.w > 0) h = hash_step(h, r.x);
@@ -1731,13 +1733,14 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
     //    numbers the group
     uint32_t slot_of[kRows];
     unsigned long long val[kRows];
+    Row rr[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
       const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
       slot_of[k] = kNone;
       val[k] = 0;
       if (i < n) {
-        const Row r = rows[i];
+        const Row r = rr[k] = rows[i];
         val[k] = R::value(r);
         uint32_t sl = R::slot_hash(r) & smask;
         uint32_t probes = 0;
@@ -1769,16 +1772,17 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       return;
     }
     if (single && s_claims == n) {
-      // every key of the region is distinct: group l = the row that claimed l; its accumulators are its value
+      // every key of the region is distinct: row i of the region is group i (consecutive lanes write consecutive
+      // groups); its accumulators are its value
       if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, n);
       __syncthreads();
       const uint32_t base = a.g0 + s_base;
 #pragma unroll
       for (int k = 0; k < kRows; k++) {
         if (slot_of[k] == kNone) continue;
-        const uint32_t gid = base + lid[slot_of[k]];
+        const uint32_t gid = base + k * blockDim.x + threadIdx.x;
         const unsigned long long v = val[k];
-        R::store_key(a, gid, rows[t0 + k * blockDim.x + threadIdx.x]);
+        R::store_key(a, gid, rr[k]);
         for (int f = 0; f < a.naggs; f++) {
           const OpK &op = a.ops[f];
           unsigned long long w0 = v, w1 = 0;
@@ -2416,6 +2420,10 @@ __global__ __launch_bounds__(256) void bytes_copy_groups_kernel(const uint64_t *
     for (uint32_t t = 0; t < len; t++) dst[o + t] = src[t];
   }
 }
+__global__ __launch_bounds__(256) void iota16_kernel(int64_t n, uint32_t *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256)
+    out[i] = static_cast<uint32_t>(i) * 16u;
+}
 __global__ __launch_bounds__(256) void narrow_u64_u32_kernel(const uint64_t *__restrict__ in, int64_t n, uint32_t *__restrict__ out) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = static_cast<uint32_t>(in[i]);
@@ -2487,6 +2495,7 @@ struct crgpu_agg : crgpu::Handle {
   // bulk aggregation of a high-cardinality first input (radix.hip buffers); the index is rebuilt lazily afterwards
   RadixTable radix;
   bool index_valid = true;
+  bool dense16 = false;  // every group came from the wide bulk path with a 16-byte key: group g's key is b_buf[16 g, 16 g + 16)
   DevBuf bulk_count;
   // gid-partitioned accumulation
   DevBuf p_gid_res, p_hist, p_offsets, p_gid, p_flags, p_wgs, p_starts;
@@ -2852,6 +2861,7 @@ extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   a->seq = 0;
   a->new_ratio = 1.0;
   a->index_valid = true;
+  a->dense16 = false;
   for (auto &k : a->ks) k.tail = 0;
   for (auto &o : a->ops) o.any_tail = 0;
   CRGPU_HIP(hipMemsetAsync(a->tails_dev.p, 0, kMaxKeyCols * 8, stream()));
@@ -3763,8 +3773,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   }
   CRGPU_TRY(ensure_groups(a, static_cast<size_t>(n)));
   CRGPU_TRY(upload_descriptors(a, &cols));
-  CRGPU_TRY(a->bulk_count.ensure(8));
-  CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 8, st));
+  CRGPU_TRY(a->bulk_count.ensure(16));
+  CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 16, st));
   BulkArgs b;
   std::memset(&b, 0, sizeof(b));
   b.rows = sub_form ? a->radix.rows_b.p : a->radix.rows_a.p;
@@ -3795,6 +3805,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.gword = a->gword.as<unsigned long long>();
   b.ngroups = a->bulk_count.as<unsigned int>();
   b.failed = a->bulk_count.as<unsigned int>() + 1;
+  b.not16 = a->bulk_count.as<unsigned int>() + 2;
   b.g0 = 0;
   b.gmax = static_cast<uint32_t>(gmax);
   b.slots = static_cast<uint32_t>(slots);
@@ -3805,8 +3816,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     else hipLaunchKernelGGL(agg_bulk_kernel<false>, dim3(nregions), dim3(1024), lds, st, b);
     CRGPU_HIP(hipGetLastError());
   }
-  unsigned int tf[2] = {0, 0};
-  CRGPU_HIP(hipMemcpyAsync(tf, a->bulk_count.p, 8, hipMemcpyDeviceToHost, st));
+  unsigned int tf[4] = {0, 0, 0, 0};
+  CRGPU_HIP(hipMemcpyAsync(tf, a->bulk_count.p, 16, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
   if (tf[1]) return CRGPU_OK;  // nothing was committed: the groups written so far lie beyond ngroups == 0
   const unsigned int total = tf[0];
@@ -3815,6 +3826,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     CRGPU_HIP(hipMemcpyAsync(a->tails_dev.p, &a->ks[0].tail, 8, hipMemcpyHostToDevice, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     a->descriptors_dirty = true;
+    a->dense16 = tf[2] == 0;
   }
   a->ngroups = total;
   a->seq = static_cast<unsigned long long>(n);
@@ -3844,6 +3856,7 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
     CRGPU_TRY(try_bulk(a, in, n, &done));
     if (done) return CRGPU_OK;
   }
+  a->dense16 = false;
   if (!a->index_valid) {  // groups appended by the bulk path: give them index entries before looking anything up
     const uint64_t want = next_pow2((static_cast<uint64_t>(a->ngroups) + 1) * 2);
     if (want > kMaxCap) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^29 groups per GPU");
@@ -3921,6 +3934,16 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
     o.type = op.out_type;
     o.nullable = true;
     CRGPU_TRY(o.valid.ensure(static_cast<size_t>((ng + 7) / 8 + 1)));
+    if (op.out_type == CRGPU_BYTES && op.kind == ACC_ANY_KEY && a->dense16 && ng >= kAliasMinGroups && ng < (int64_t(1) << 28)) {
+      // the wide bulk path left group g's 16-byte key at 16 g of the key store: the store IS the output's data, the
+      // offsets are multiples of 16 and no key is NULL
+      CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(ng + 1) * 4));
+      hipLaunchKernelGGL(iota16_kernel, dim3(grid_for(ng + 1, 256)), dim3(256), 0, st, ng + 1, o.offsets.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+      CRGPU_HIP(hipMemsetAsync(o.valid.p, 0xFF, static_cast<size_t>((ng + 7) / 8), st));
+      alias[f] = a->ks[op.key_idx].b_buf.p;
+      continue;
+    }
     if (op.out_type == CRGPU_BYTES) {
       // ANY_NOT_NULL over a BYTES group key or BYTES column
       // ... or MIN / MAX over a BYTES column (present = a value was stored)
