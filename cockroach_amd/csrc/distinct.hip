@@ -29,6 +29,7 @@
 #include <memory>
 
 #include "device.h"
+#include "radix.h"
 
 namespace crgpu {
 
@@ -201,6 +202,69 @@ __global__ __launch_bounds__(256) void distinct_rebase_offsets_kernel(const uint
   for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j <= n; j += stride) dst[j] = tail + (src[j] - first);
 }
 
+// ------------------------------------------------------------------ bulk path: a fresh table fed one large, mostly distinct batch
+// Find-or-insert against the HBM index costs one random CAS with its returned value per new key (~10 G/s: 11.6 of the
+// 14.3 ms of 2^27 all-distinct rows).  When the distinct column is one INT64 without NULLs the rows {key, position} are
+// instead radix-partitioned with the join's build-side kernels (radix.hip: 1024 partitions, then sub-partitions of ~1024
+// rows in fixed regions of kDBulkRows) and one workgroup per sub-partition finds, entirely in LDS, the smallest position
+// of every key: rows that are not the first of their key clear their flag (the flags start out set, so an all-distinct
+// region writes nothing).  The batch then joins the key store whole, the hash words are written by a streaming pass, and
+// the index is rebuilt from them only if more input follows.
+static constexpr uint32_t kDBulkRows = 2048, kDBulkSlots = 4096;
+static constexpr int64_t kDBulkMinRows = int64_t(1) << 23, kDBulkMaxRows = int64_t(1) << 27;
+__global__ __launch_bounds__(1024) void distinct_bulk_kernel(const ulonglong2 *__restrict__ rows_all, const uint32_t *__restrict__ counts,
+                                                             uint8_t *__restrict__ flags) {
+  __shared__ uint32_t idx[kDBulkSlots];     // slot -> a row of the region that holds the slot's key
+  __shared__ uint32_t minpos[kDBulkSlots];  // slot -> smallest input position of the key
+  const uint32_t n = counts[blockIdx.x] < kDBulkRows ? counts[blockIdx.x] : kDBulkRows;  // (overflow is reported by the split)
+  if (n == 0) return;
+  const ulonglong2 *rows = rows_all + static_cast<int64_t>(blockIdx.x) * kDBulkRows;
+  for (uint32_t i = threadIdx.x; i < kDBulkSlots; i += blockDim.x) idx[i] = 0xFFFFFFFFu, minpos[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  constexpr int kRows = kDBulkRows / 1024;
+  uint32_t slot[kRows], pos[kRows];
+#pragma unroll
+  for (int k = 0; k < kRows; k++) {
+    const uint32_t i = k * 1024 + threadIdx.x;
+    slot[k] = 0xFFFFFFFFu;
+    if (i < n) {
+      const ulonglong2 r = rows[i];
+      pos[k] = static_cast<uint32_t>(r.y);
+      uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & (kDBulkSlots - 1);
+      for (;;) {  // ends: at most kDBulkRows keys in twice as many slots
+        uint32_t cur = idx[sl];
+        if (cur == 0xFFFFFFFFu) {
+          cur = atomicCAS(&idx[sl], 0xFFFFFFFFu, i);
+          if (cur == 0xFFFFFFFFu) break;
+        }
+        if (rows[cur].x == r.x) break;
+        sl = (sl + 1) & (kDBulkSlots - 1);
+      }
+      atomicMin(&minpos[sl], pos[k]);
+      slot[k] = sl;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kRows; k++)
+    if (slot[k] != 0xFFFFFFFFu && minpos[slot[k]] != pos[k]) flags[pos[k]] = 0;
+}
+
+// hash words of a batch that joins the store whole: emitted rows leave theirs, the others stay out of index rebuilds
+__global__ __launch_bounds__(256) void distinct_bulk_words_kernel(KeyCols keys, int64_t n, const uint8_t *__restrict__ flags,
+                                                                  unsigned long long *__restrict__ gword) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const DHash h = distinct_hash(keys, i);
+    gword[i] = flags[i] ? (static_cast<unsigned long long>(h.upper) << 32) | h.idx : kDEmpty;
+  }
+}
+
+__global__ void distinct_sample_kernel(const long long *__restrict__ keys, int64_t stride, int nsample, long long *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nsample) out[i] = keys[static_cast<int64_t>(i) * stride];
+}
+
 static inline int dgrid(int64_t n) {
   int64_t want = (n + 255) / 256;
   const int64_t cap = static_cast<int64_t>(num_cus()) * 8;
@@ -220,13 +284,15 @@ struct crgpu_distinct : crgpu::Handle {
   uint32_t ngroups = 0;  // rows of the key store (the keys seen so far, plus the duplicates inside batches appended whole)
   size_t gcap = 0;       // key store capacity (keys)
   DevBuf meta, gword, slot_of, flags, idx, scratch;
+  RadixTable radix;          // partition buffers of the bulk path
+  bool index_stale = false;  // the bulk path appended keys whose index entries do not exist yet (rebuilt from gword)
   struct KS { DevBuf data, offsets; uint64_t tail = 0; };
   std::vector<std::unique_ptr<KS>> ks;
   std::vector<OutCol> out;
   std::vector<crgpu_dcol> views;
 };
 
-static crgpu_status distinct_ensure(crgpu_distinct *d, size_t need_groups) {
+static crgpu_status distinct_ensure(crgpu_distinct *d, size_t need_groups, bool with_index = true) {
   hipStream_t st = stream();
   if (need_groups > d->gcap) {
     size_t g = d->gcap ? d->gcap : 1024;
@@ -244,16 +310,19 @@ static crgpu_status distinct_ensure(crgpu_distinct *d, size_t need_groups) {
     CRGPU_TRY(d->gword.ensure(g * 8, true));
     d->gcap = g;
   }
+  if (!with_index) return CRGPU_OK;
   uint64_t want = 1024;
   while (want < 2 * static_cast<uint64_t>(need_groups)) want *= 2;
   // (the bound counts STORED rows: a mostly-new batch joins the key store whole, duplicates included, and the index is
   // sized for the store plus the incoming batch before the batch has been looked at)
   if (want > kDMaxCap)
     return fail(CRGPU_ERR_OOM, "crgpu_dev_distinct_consume: the index bound of 2^29 stored rows + incoming batch is reached on this GPU (spill: ExportBuffered)");
-  if (want > d->cap) {
+  if (want > d->cap || d->index_stale) {
+    if (want < d->cap) want = d->cap;
     CRGPU_TRY(d->meta.ensure(static_cast<size_t>(want) * 8));
     CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(want) * 8, st));
     d->cap = static_cast<uint32_t>(want);
+    d->index_stale = false;
     if (d->ngroups > 0) {
       ProfScope prof("distinct_reindex");
       hipLaunchKernelGGL(distinct_reindex_kernel, dim3(dgrid(d->ngroups)), dim3(256), 0, st, d->gword.as<unsigned long long>(),
@@ -308,8 +377,71 @@ extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
   if (d->cap) CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(d->cap) * 8, st));
   d->ngroups = 0;
   d->expect_new = true;
+  d->index_stale = false;
   for (auto &k : d->ks) k->tail = 0;
   CRGPU_HIP(hipStreamSynchronize(st));
+  return CRGPU_OK;
+}
+
+// Bulk path (see distinct_bulk_kernel).  *done = true: d->flags holds the emit flag of every row and the hash words of
+// the batch are written; the caller compacts, gathers and appends the batch to the store whole.
+static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol> &in, int64_t n, bool *done) {
+  *done = false;
+  static const bool on = getenv("CRGPU_DISTINCT_BULK") == nullptr || getenv("CRGPU_DISTINCT_BULK")[0] != '0';
+  if (!on || d->ngroups != 0 || n < kDBulkMinRows || n > kDBulkMaxRows || d->dcols.size() != 1) return CRGPU_OK;
+  const DCol &key = in[d->dcols[0]];
+  if (key.type != CRGPU_INT64 || key.valid != nullptr) return CRGPU_OK;
+  hipStream_t st = stream();
+  // mostly distinct?  8192 keys at a fixed stride; up to ~32 rows per key the regions hold (as the aggregator's sub form)
+  constexpr int kSample = 8192;
+  std::vector<int64_t> sample(kSample);
+  CRGPU_TRY(d->scratch.ensure(static_cast<size_t>(kSample) * 8));
+  hipLaunchKernelGGL(distinct_sample_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), n / kSample,
+                     kSample, d->scratch.as<long long>());
+  CRGPU_HIP(hipGetLastError());
+  CRGPU_HIP(hipMemcpyAsync(sample.data(), d->scratch.p, static_cast<size_t>(kSample) * 8, hipMemcpyDeviceToHost, st));
+  CRGPU_HIP(hipStreamSynchronize(st));
+  const size_t tab = static_cast<size_t>(kSample) * 4;
+  std::vector<int64_t> tkey(tab);
+  std::vector<uint8_t> tused(tab, 0);
+  int64_t distinct = 0;
+  for (int i = 0; i < kSample; i++) {
+    size_t at = static_cast<size_t>((static_cast<uint64_t>(sample[i]) * 0x9E3779B97F4A7C15ull) >> 40) & (tab - 1);
+    while (tused[at] && tkey[at] != sample[i]) at = (at + 1) & (tab - 1);
+    if (!tused[at]) {
+      tused[at] = 1;
+      tkey[at] = sample[i];
+      distinct++;
+    }
+  }
+  int64_t dmax = 16 * (int64_t(kSample) * kSample) / n;
+  if (dmax < 8) dmax = 8;
+  if (dmax > kSample / 4) dmax = kSample / 4;
+  if (kSample - distinct > dmax) return CRGPU_OK;
+  RadixSrc src;
+  std::memset(&src, 0, sizeof(src));
+  src.kp.n = 1;
+  src.kp.c[0] = key;
+  src.kp.range[0] = ~0ull;
+  src.pay = nullptr;  // the payload is the row's position
+  bool ok = false;
+  CRGPU_TRY(radix_partition_split(d->radix, src, n, &ok, kDBulkRows, 10, 7));
+  if (!ok) return CRGPU_OK;  // a region overflowed: many rows per key after all
+  CRGPU_HIP(hipMemsetAsync(d->flags.p, 1, static_cast<size_t>(n), st));
+  {
+    ProfScope prof("distinct_bulk");
+    hipLaunchKernelGGL(distinct_bulk_kernel, dim3(static_cast<unsigned>(kRadixP1) << d->radix.sub_bits), dim3(1024), 0, st,
+                       d->radix.rows_b.as<ulonglong2>(), d->radix.sub_count.as<uint32_t>(), d->flags.as<uint8_t>());
+    CRGPU_HIP(hipGetLastError());
+    KeyCols keys;
+    std::memset(&keys, 0, sizeof(keys));
+    keys.n = 1;
+    keys.c[0] = key;
+    hipLaunchKernelGGL(distinct_bulk_words_kernel, dim3(dgrid(n)), dim3(256), 0, st, keys, n, d->flags.as<uint8_t>(),
+                       d->gword.as<unsigned long long>());
+    CRGPU_HIP(hipGetLastError());
+  }
+  *done = true;
   return CRGPU_OK;
 }
 
@@ -335,11 +467,23 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
   }
   int64_t m = 0, m_store = 0;
   bool whole = false;
+  bool bulk = false;
   if (n > 0) {
-    CRGPU_TRY(distinct_ensure(d, static_cast<size_t>(d->ngroups) + static_cast<size_t>(n)));
-    CRGPU_TRY(d->slot_of.ensure(static_cast<size_t>(n) * 4));
     CRGPU_TRY(d->flags.ensure(static_cast<size_t>(n)));
     CRGPU_TRY(d->idx.ensure(static_cast<size_t>(n) * 4));
+    if (d->ngroups == 0 && n >= kDBulkMinRows) {
+      CRGPU_TRY(distinct_ensure(d, static_cast<size_t>(n), false));  // key store and hash words only
+      CRGPU_TRY(distinct_try_bulk(d, in, n, &bulk));
+    }
+  }
+  if (bulk) {
+    CRGPU_TRY(select_flagged(d->flags.as<uint8_t>(), n, d->idx.as<int32_t>(), d->scratch, &m));
+    whole = true;  // the hash words of every row are in place
+    d->expect_new = m * 2 > n;
+    d->index_stale = true;
+  } else if (n > 0) {
+    CRGPU_TRY(distinct_ensure(d, static_cast<size_t>(d->ngroups) + static_cast<size_t>(n)));
+    CRGPU_TRY(d->slot_of.ensure(static_cast<size_t>(n) * 4));
     DResolveArgs a;
     std::memset(&a, 0, sizeof(a));
     a.keys.n = a.store.n = static_cast<int>(d->dcols.size());

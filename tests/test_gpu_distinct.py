@@ -108,6 +108,36 @@ def test_distinct_full_size_invariants(nkeys):
     assert torch.equal(ok[order], uk) and torch.equal(ow[order], first)
 
 
+def test_distinct_bulk_path_vs_oracle(oracle):
+    """A fresh table fed >= 2^23 mostly distinct INT64 keys takes the bulk path (radix partition, first occurrence of every
+    key found in LDS, no hash index); the second batch (old and new keys) forces the index to be rebuilt from the hash
+    words.  Ordered comparison with the oracle, payload = row number, so a wrong 'first' row would show."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(41)
+    n1, n2 = 1 << 23, 200_000
+    base = rng.permutation(n1).astype(np.int64)[: n1 * 5 // 8] * 1_000_003 - 11
+    base[:4] = [-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    k1 = np.concatenate([base, rng.choice(base, n1 - base.size)])  # 3/8 of the rows repeat a key, some keys several times
+    rng.shuffle(k1)
+    k2 = np.concatenate([rng.choice(base, n2 // 2), np.arange(n2 // 2, dtype=np.int64) * 1_000_003 + 5])
+    rng.shuffle(k2)
+    keys = np.concatenate([k1, k2])
+    cols = [cd.Vec.from_numpy(cd.INT64, keys), cd.Vec.from_numpy(cd.INT64, np.arange(n1 + n2, dtype=np.int64))]
+    d = dev.Distinct([cd.INT64, cd.INT64], [0])
+    dev.prof_enable(True)
+    dev.prof_reset()
+    out1 = dev.result_to_vecs(d.consume([dev.upload(v.slice(0, n1)) for v in cols], n1))
+    assert dev.prof_get("distinct_bulk")[1] == 1, "the bulk path did not run"
+    out2 = dev.result_to_vecs(d.consume([dev.upload(v.slice(n1, n1 + n2)) for v in cols], n2))
+    assert dev.prof_get("distinct_reindex")[1] == 1
+    dev.prof_enable(False)
+    d.close()
+    want, _ = oracle.unordered_distinct(cols, [0], False)
+    for c in range(2):
+        got = np.concatenate([out1[c].data, out2[c].data])
+        assert np.array_equal(got, want[c].data)
+
+
 def test_distinct_bytes_keys_whole_batch_append_with_offset_base(oracle):
     """Mostly-new batches join the key store whole.  Here the BYTES key column's offsets do not start at 0 (a slice of
     a larger buffer, as a decode or join result can be) and the batches contain duplicates of keys from the same and
