@@ -25,6 +25,7 @@
 //
 // Roofline: HBM-bound; one random index access per row (the 24 G/s atomics wall for new keys, L2-resident lookups
 // for repeated ones) + the output gather.
+#include <cmath>
 #include <cstring>
 #include <memory>
 
@@ -250,13 +251,71 @@ __global__ __launch_bounds__(1024) void distinct_bulk_kernel(const ulonglong2 *_
     if (slot[k] != 0xFFFFFFFFu && minpos[slot[k]] != pos[k]) flags[pos[k]] = 0;
 }
 
+// Part form: tens to a few thousand keys per level-1 partition.  No level-2 split: one workgroup walks its partition in
+// tiles and the partition's keys stay in LDS across the tiles; only at the end does the first row of every key set its
+// flag (the flags start out clear).  More keys than the LDS index takes raise the overflow flag: attempt abandoned.
+static constexpr uint32_t kDPartSlots = 8192, kDPartMaxKeys = 6144;
+__global__ __launch_bounds__(1024) void distinct_bulk_part_kernel(const ulonglong2 *__restrict__ rows_all, const uint32_t *__restrict__ starts,
+                                                                  const uint32_t *__restrict__ totals, uint8_t *__restrict__ flags,
+                                                                  uint32_t *__restrict__ overflow) {
+  __shared__ uint32_t idx[kDPartSlots];
+  __shared__ uint32_t minpos[kDPartSlots];
+  __shared__ uint32_t s_claims;
+  const uint32_t n = totals[blockIdx.x];
+  if (n == 0) return;
+  const ulonglong2 *rows = rows_all + starts[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < kDPartSlots; i += blockDim.x) idx[i] = 0xFFFFFFFFu, minpos[i] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) s_claims = 0;
+  __syncthreads();
+  for (uint32_t t0 = 0; t0 < n; t0 += 2048) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t i = t0 + k * 1024 + threadIdx.x;
+      if (i < n) {
+        const ulonglong2 r = rows[i];
+        uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & (kDPartSlots - 1);
+        for (uint32_t probes = 0;; probes++) {
+          if (probes == kDPartSlots) {  // full of other keys
+            atomicAdd(&s_claims, kDPartMaxKeys + 1);
+            sl = 0xFFFFFFFFu;
+            break;
+          }
+          uint32_t cur = idx[sl];
+          if (cur == 0xFFFFFFFFu) {
+            cur = atomicCAS(&idx[sl], 0xFFFFFFFFu, i);
+            if (cur == 0xFFFFFFFFu) {
+              atomicAdd(&s_claims, 1u);
+              break;
+            }
+          }
+          if (rows[cur].x == r.x) break;
+          sl = (sl + 1) & (kDPartSlots - 1);
+        }
+        if (sl != 0xFFFFFFFFu) atomicMin(&minpos[sl], static_cast<uint32_t>(r.y));
+      }
+    }
+    __syncthreads();
+    if (s_claims > kDPartMaxKeys) {
+      if (threadIdx.x == 0) atomicOr(overflow, 1u);
+      return;
+    }
+  }
+  __syncthreads();
+  if (s_claims > kDPartMaxKeys) {  // a wave that was ahead overflowed after the others had passed the check above
+    if (threadIdx.x == 0) atomicOr(overflow, 1u);
+    return;
+  }
+  for (uint32_t i = threadIdx.x; i < kDPartSlots; i += blockDim.x)
+    if (minpos[i] != 0xFFFFFFFFu) flags[minpos[i]] = 1;
+}
+
 // hash words of a batch that joins the store whole: emitted rows leave theirs, the others stay out of index rebuilds
 __global__ __launch_bounds__(256) void distinct_bulk_words_kernel(KeyCols keys, int64_t n, const uint8_t *__restrict__ flags,
                                                                   unsigned long long *__restrict__ gword) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const DHash h = distinct_hash(keys, i);
-    gword[i] = flags[i] ? (static_cast<unsigned long long>(h.upper) << 32) | h.idx : kDEmpty;
+    gword[i] = (flags == nullptr || flags[i]) ? (static_cast<unsigned long long>(h.upper) << 32) | h.idx : kDEmpty;
   }
 }
 
@@ -403,43 +462,65 @@ static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol>
   CRGPU_HIP(hipStreamSynchronize(st));
   const size_t tab = static_cast<size_t>(kSample) * 4;
   std::vector<int64_t> tkey(tab);
-  std::vector<uint8_t> tused(tab, 0);
-  int64_t distinct = 0;
+  std::vector<int32_t> tused(tab, 0);
+  int64_t distinct = 0, maxrun = 0;
   for (int i = 0; i < kSample; i++) {
     size_t at = static_cast<size_t>((static_cast<uint64_t>(sample[i]) * 0x9E3779B97F4A7C15ull) >> 40) & (tab - 1);
     while (tused[at] && tkey[at] != sample[i]) at = (at + 1) & (tab - 1);
     if (!tused[at]) {
-      tused[at] = 1;
       tkey[at] = sample[i];
       distinct++;
     }
+    if (++tused[at] > maxrun) maxrun = tused[at];
   }
   int64_t dmax = 16 * (int64_t(kSample) * kSample) / n;
   if (dmax < 8) dmax = 8;
   if (dmax > kSample / 4) dmax = kSample / 4;
-  if (kSample - distinct > dmax) return CRGPU_OK;
+  const bool sub_form = kSample - distinct <= dmax;
+  if (!sub_form) {
+    // part form: G from G (1 - exp(-s / G)) = distinct; it takes ~3 ... ~4500 keys per level-1 partition and no key far
+    // more frequent than the others (its rows would serialise on one LDS word)
+    double lo = 1.0, hi = 1e12;
+    for (int it = 0; it < 60; it++) {
+      const double mid = std::sqrt(lo * hi);
+      if (mid * (1.0 - std::exp(-static_cast<double>(kSample) / mid)) < static_cast<double>(distinct)) lo = mid;
+      else hi = mid;
+    }
+    const double per_part = hi / kRadixP1, mu = static_cast<double>(kSample) / hi;
+    if (per_part < 3.0 || per_part * 1.3 + 4.0 * std::sqrt(per_part) + 16.0 > static_cast<double>(kDPartMaxKeys)) return CRGPU_OK;
+    if (static_cast<double>(maxrun) > std::max(8.0, 3.0 * mu + 6.0)) return CRGPU_OK;
+  }
   RadixSrc src;
   std::memset(&src, 0, sizeof(src));
   src.kp.n = 1;
   src.kp.c[0] = key;
   src.kp.range[0] = ~0ull;
   src.pay = nullptr;  // the payload is the row's position
-  bool ok = false;
-  CRGPU_TRY(radix_partition_split(d->radix, src, n, &ok, kDBulkRows, 10, 7));
-  if (!ok) return CRGPU_OK;  // a region overflowed: many rows per key after all
-  CRGPU_HIP(hipMemsetAsync(d->flags.p, 1, static_cast<size_t>(n), st));
-  {
+  if (sub_form) {
+    bool ok = false;
+    CRGPU_TRY(radix_partition_split(d->radix, src, n, &ok, kDBulkRows, 10, 7));
+    if (!ok) return CRGPU_OK;  // a region overflowed: many rows per key after all
+    CRGPU_HIP(hipMemsetAsync(d->flags.p, 1, static_cast<size_t>(n), st));
     ProfScope prof("distinct_bulk");
     hipLaunchKernelGGL(distinct_bulk_kernel, dim3(static_cast<unsigned>(kRadixP1) << d->radix.sub_bits), dim3(1024), 0, st,
                        d->radix.rows_b.as<ulonglong2>(), d->radix.sub_count.as<uint32_t>(), d->flags.as<uint8_t>());
     CRGPU_HIP(hipGetLastError());
-    KeyCols keys;
-    std::memset(&keys, 0, sizeof(keys));
-    keys.n = 1;
-    keys.c[0] = key;
-    hipLaunchKernelGGL(distinct_bulk_words_kernel, dim3(dgrid(n)), dim3(256), 0, st, keys, n, d->flags.as<uint8_t>(),
-                       d->gword.as<unsigned long long>());
-    CRGPU_HIP(hipGetLastError());
+  } else {
+    CRGPU_TRY(radix_partition_level1(d->radix, src, n));
+    CRGPU_TRY(d->radix.flag.ensure(4));
+    CRGPU_HIP(hipMemsetAsync(d->radix.flag.p, 0, 4, st));
+    CRGPU_HIP(hipMemsetAsync(d->flags.p, 0, static_cast<size_t>(n), st));
+    {
+      ProfScope prof("distinct_bulk_part");
+      hipLaunchKernelGGL(distinct_bulk_part_kernel, dim3(kRadixP1), dim3(1024), 0, st, d->radix.rows_a.as<ulonglong2>(),
+                         d->radix.starts.as<uint32_t>(), d->radix.totals.as<uint32_t>(), d->flags.as<uint8_t>(),
+                         d->radix.flag.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    uint32_t overflow = 0;
+    CRGPU_HIP(hipMemcpyAsync(&overflow, d->radix.flag.p, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (overflow) return CRGPU_OK;  // more keys per partition than the sample suggested
   }
   *done = true;
   return CRGPU_OK;
@@ -478,8 +559,8 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
   }
   if (bulk) {
     CRGPU_TRY(select_flagged(d->flags.as<uint8_t>(), n, d->idx.as<int32_t>(), d->scratch, &m));
-    whole = true;  // the hash words of every row are in place
-    d->expect_new = m * 2 > n;
+    whole = m * 2 > n;
+    d->expect_new = whole;
     d->index_stale = true;
   } else if (n > 0) {
     CRGPU_TRY(distinct_ensure(d, static_cast<size_t>(d->ngroups) + static_cast<size_t>(n)));
@@ -539,6 +620,16 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
         CRGPU_TRY(materialize(in[c], d->idx.as<int32_t>(), m, false, d->out[c], d->scratch));
       }
     }
+  }
+  if (bulk) {  // hash words of the rows that join the store: the batch's (emitted rows only) or the output's
+    KeyCols keys;
+    std::memset(&keys, 0, sizeof(keys));
+    keys.n = 1;
+    keys.c[0] = whole ? in[d->dcols[0]] : DCol{CRGPU_INT64, 0, d->out[d->dcols[0]].data.p, nullptr, nullptr};
+    const int64_t rows = whole ? n : m;
+    hipLaunchKernelGGL(distinct_bulk_words_kernel, dim3(dgrid(rows)), dim3(256), 0, st, keys, rows,
+                       whole ? d->flags.as<uint8_t>() : nullptr, d->gword.as<unsigned long long>());
+    CRGPU_HIP(hipGetLastError());
   }
   // the key store grows by the distinct columns of the output -- or of the whole batch
   for (size_t k = 0; m > 0 && k < d->dcols.size(); k++) {

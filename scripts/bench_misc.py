@@ -328,7 +328,7 @@ def bench_distinct(lg, reps, dv, g, nkeys):
         d.reset()
         m[0] = int(d.consume(cols, n).n)
     dt = _timed(go, reps)
-    kern = _kernels(["distinct_resolve", "distinct_publish", "distinct_gather", "distinct_reindex", "distinct_bulk", "radix_build_hist", "radix_build_scatter", "radix_build_split"], reps)
+    kern = _kernels(["distinct_resolve", "distinct_publish", "distinct_gather", "distinct_reindex", "distinct_bulk", "distinct_bulk_part", "radix_build_hist", "radix_build_scatter", "radix_build_split"], reps)
     cpu = None
     if CPU_SAMPLE:
         from oracle import oracle as O

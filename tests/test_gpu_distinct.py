@@ -138,6 +138,35 @@ def test_distinct_bulk_path_vs_oracle(oracle):
         assert np.array_equal(got, want[c].data)
 
 
+@pytest.mark.parametrize("nkeys", [30_000, 150_000])
+def test_distinct_bulk_part_form_vs_oracle(oracle, nkeys):
+    """Mid cardinality (tens to thousands of keys per radix partition): the bulk path without the level-2 split; only the
+    emitted rows join the key store, the second batch goes through the rebuilt index.  A third case: so many keys per
+    partition that the LDS index overflows although the sample is read as mid cardinality -- cannot happen with uniform
+    keys, so it is forced with keys that all fall into few partitions... not constructible from outside; the overflow
+    branch is covered by the aggregator's twin (test_agg_bulk_part_form_skew_and_overflow)."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(nkeys)
+    n1, n2 = 1 << 23, 100_000
+    base = rng.permutation(nkeys * 4)[:nkeys].astype(np.int64) * 7_919 - 3
+    base[:4] = [-1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max]
+    k1 = base[rng.integers(0, nkeys, size=n1)]
+    k2 = np.concatenate([rng.choice(base, n2 // 2), np.arange(n2 // 2, dtype=np.int64) * 7_919 + 1])
+    rng.shuffle(k2)
+    cols = [cd.Vec.from_numpy(cd.INT64, np.concatenate([k1, k2])), cd.Vec.from_numpy(cd.INT64, np.arange(n1 + n2, dtype=np.int64))]
+    d = dev.Distinct([cd.INT64, cd.INT64], [0])
+    dev.prof_enable(True)
+    dev.prof_reset()
+    out1 = dev.result_to_vecs(d.consume([dev.upload(v.slice(0, n1)) for v in cols], n1))
+    assert dev.prof_get("distinct_bulk_part")[1] == 1, "the part form of the bulk path did not run"
+    out2 = dev.result_to_vecs(d.consume([dev.upload(v.slice(n1, n1 + n2)) for v in cols], n2))
+    dev.prof_enable(False)
+    d.close()
+    want, _ = oracle.unordered_distinct(cols, [0], False)
+    for c in range(2):
+        assert np.array_equal(np.concatenate([out1[c].data, out2[c].data]), want[c].data)
+
+
 def test_distinct_bytes_keys_whole_batch_append_with_offset_base(oracle):
     """Mostly-new batches join the key store whole.  Here the BYTES key column's offsets do not start at 0 (a slice of
     a larger buffer, as a decode or join result can be) and the batches contain duplicates of keys from the same and
