@@ -1739,6 +1739,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
       slot_of[k] = kNone;
       val[k] = 0;
+      bool claimed = false;
       if (i < n) {
         const Row r = rr[k] = rows[i];
         val[k] = R::value(r);
@@ -1754,9 +1755,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
           if (cur == kNone) {
             cur = atomicCAS(&idx[sl], kNone, i);
             if (cur == kNone) {
-              const uint32_t l = atomicAdd(&s_claims, 1u);
-              lid[sl] = l;  // read after the barrier below
-              if (l < a.gmax) rep[l] = i;
+              claimed = true;
               break;
             }
           }
@@ -1764,6 +1763,20 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
           sl = (sl + 1) & smask;
         }
         slot_of[k] = sl;
+      }
+      // the claimants number their groups: one LDS atomic per wave (a same-address atomic per claimant serialised the
+      // ~1024 claims of an all-distinct region)
+      const uint64_t cm = __ballot(claimed);
+      if (cm) {
+        const int lead = __ffsll(static_cast<long long>(cm)) - 1;
+        uint32_t wb = 0;
+        if (lane_id() == static_cast<uint32_t>(lead)) wb = atomicAdd(&s_claims, static_cast<uint32_t>(popc64(cm)));
+        wb = __shfl(wb, lead, 64);
+        if (claimed) {
+          const uint32_t l = wb + rank_in_mask(cm);
+          lid[slot_of[k]] = l;  // read after the barrier below
+          if (l < a.gmax) rep[l] = i;
+        }
       }
     }
     __syncthreads();
