@@ -1638,6 +1638,9 @@ struct BulkArgs {
   int32_t key_type;
   uint8_t *key_data;            // key store of the single group column
   uint8_t *key_present;
+  int32_t key_type2, _pad2;     // WIDE over two integer key columns: the second column's key store
+  uint8_t *key_data2;
+  uint8_t *key_present2;
   uint64_t *b_off;              // WIDE: the BYTES key store; group g's bytes go to b_buf[16 g, 16 g + 16)
   uint32_t *b_len;
   uint8_t *b_buf;
@@ -1674,8 +1677,26 @@ struct BulkRow<true> {
   static __device__ __forceinline__ uint32_t slot_hash(const T &r) {
     return static_cast<uint32_t>(fmix64(wide_key_hash(r.x, r.y, r.w) ^ 0x5851F42D4C957F2Dull) >> 20);
   }
-  // agg_hash of one BYTES column: the full 8-byte words, the zero-padded rest, then the length
+  static __device__ __forceinline__ void store_int(uint8_t *data, int type, uint32_t gid, unsigned long long v) {
+    switch (type) {
+      case CRGPU_INT16: reinterpret_cast<int16_t *>(data)[gid] = static_cast<int16_t>(v); break;
+      case CRGPU_INT32: reinterpret_cast<int32_t *>(data)[gid] = static_cast<int32_t>(v); break;
+      default: reinterpret_cast<unsigned long long *>(data)[gid] = v; break;
+    }
+  }
+  // agg_hash of one BYTES column: the full 8-byte words, the zero-padded rest, then the length; of two integer columns:
+  // their sign-extended values one after the other
   static __device__ __forceinline__ void store_key(const BulkArgs &a, uint32_t gid, const T &r) {
+    if (a.key_type != CRGPU_BYTES) {
+      store_int(a.key_data, a.key_type, gid, r.x);
+      store_int(a.key_data2, a.key_type2, gid, r.y);
+      a.key_present[gid] = 1;
+      a.key_present2[gid] = 1;
+      const uint64_t h = fmix64(hash_step(hash_step(0x9E3779B97F4A7C15ull, r.x), r.y));
+      a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
+                     (static_cast<uint32_t>(h) & kIdxHashMask);
+      return;
+    }
     reinterpret_cast<ulonglong2 *>(a.b_buf)[gid] = make_ulonglong2(r.x, r.y);
     a.b_off[gid] = static_cast<uint64_t>(gid) * 16u;
     a.b_len[gid] = static_cast<uint32_t>(r.w);
@@ -3634,10 +3655,14 @@ __global__ void agg_sample_keys_kernel(const long long *__restrict__ keys, int64
 
 // BYTES keys: the sample holds a 64-bit hash of each sampled key; out[nsample] is set when a sampled key is longer than
 // the 16 bytes a wide row holds
-__global__ void agg_sample_wide_kernel(DCol key, int64_t stride, int nsample, long long *__restrict__ out) {
+__global__ void agg_sample_wide_kernel(DCol key, DCol key2, int64_t stride, int nsample, long long *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nsample) return;
   const int64_t r = static_cast<int64_t>(i) * stride;
+  if (key.type != CRGPU_BYTES) {
+    out[i] = static_cast<long long>(wide_key_hash(static_cast<uint64_t>(col_get_int(key, r)), static_cast<uint64_t>(col_get_int(key2, r)), 16));
+    return;
+  }
   const uint32_t a0 = key.offsets[r], len = key.offsets[r + 1] - a0;
   if (len > 16u) {
     out[nsample] = 1;
@@ -3658,16 +3683,21 @@ __global__ void agg_sample_wide_kernel(DCol key, int64_t stride, int nsample, lo
 static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
   *done = false;
   if (a->ngroups != 0 || a->seq != 0 || n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
-  if (a->group_cols.size() != 1) return CRGPU_OK;
+  if (a->group_cols.size() != 1 && a->group_cols.size() != 2) return CRGPU_OK;
   const int key_type = a->types[a->group_cols[0]];
-  // INT64 keys travel as 16-byte {key, value} rows; BYTES keys of at most 16 bytes as 32-byte {k0, k1, value, length}
-  // rows (wide form, the sub form only: it exists for config G's all-distinct string keys)
-  const bool wide = key_type == CRGPU_BYTES;
+  // One INT64 key travels as 16-byte {key, value} rows; one BYTES key of at most 16 bytes, or two integer keys, as
+  // 32-byte {k0, k1, value, length} rows (wide form, the sub form only: it exists for config G's all-distinct keys)
+  const bool two_ints = a->group_cols.size() == 2;
+  if (two_ints && (!is_int_type(key_type) || !is_int_type(a->types[a->group_cols[1]]))) return CRGPU_OK;
+  const bool wide = two_ints || key_type == CRGPU_BYTES;
   if (key_type != CRGPU_INT64 && !wide) return CRGPU_OK;
   static const bool wide_on = getenv("CRGPU_BULK_WIDE") == nullptr || getenv("CRGPU_BULK_WIDE")[0] != '0';
   if (wide && !wide_on) return CRGPU_OK;
   const DCol &key = cols[a->group_cols[0]];
-  if (key.valid != nullptr || (!wide && (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0)) return CRGPU_OK;
+  DCol key2;
+  std::memset(&key2, 0, sizeof(key2));
+  if (two_ints) key2 = cols[a->group_cols[1]];
+  if (key.valid != nullptr || key2.valid != nullptr || (!wide && (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0)) return CRGPU_OK;
   int vcol = -1, nops = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
@@ -3695,7 +3725,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     if (wide) {
       sample.resize(kSample + 1);
       CRGPU_HIP(hipMemsetAsync(a->scratch.as<long long>() + kSample, 0, 8, st));
-      hipLaunchKernelGGL(agg_sample_wide_kernel, dim3(kSample / 256), dim3(256), 0, st, key, stride, kSample, a->scratch.as<long long>());
+      hipLaunchKernelGGL(agg_sample_wide_kernel, dim3(kSample / 256), dim3(256), 0, st, key, key2, stride, kSample, a->scratch.as<long long>());
     } else {
       hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), stride,
                          kSample, a->scratch.as<long long>());
@@ -3772,11 +3802,12 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   if (wide) {
     WideSrc ws;
     ws.key = key;
+    ws.key2 = key2;
     ws.val = vcol >= 0 ? static_cast<const unsigned long long *>(cols[vcol].data) : nullptr;
     bool ok = false;
     CRGPU_TRY(radix_partition_split_wide(a->radix, ws, n, &ok, kBulkRows, 10, 7));
     if (!ok) return CRGPU_OK;  // a sub-partition overflowed, or a key is longer than 16 bytes
-    CRGPU_TRY(a->ks[0].b_buf.ensure(static_cast<size_t>(n) * 16 + 16));
+    if (!two_ints) CRGPU_TRY(a->ks[0].b_buf.ensure(static_cast<size_t>(n) * 16 + 16));
   } else if (sub_form) {
     bool ok = false;
     CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
@@ -3812,6 +3843,11 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.key_type = key_type;
   b.key_data = a->ks[0].data.as<uint8_t>();
   b.key_present = a->ks[0].present.as<uint8_t>();
+  if (two_ints) {
+    b.key_type2 = a->types[a->group_cols[1]];
+    b.key_data2 = a->ks[1].data.as<uint8_t>();
+    b.key_present2 = a->ks[1].present.as<uint8_t>();
+  }
   b.b_off = a->ks[0].b_off.as<uint64_t>();
   b.b_len = a->ks[0].b_len.as<uint32_t>();
   b.b_buf = a->ks[0].b_buf.as<uint8_t>();
@@ -3834,7 +3870,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   CRGPU_HIP(hipStreamSynchronize(st));
   if (tf[1]) return CRGPU_OK;  // nothing was committed: the groups written so far lie beyond ngroups == 0
   const unsigned int total = tf[0];
-  if (wide) {  // the key bytes of group g lie at 16 g: later appends (find-or-insert) continue behind them
+  if (wide && !two_ints) {  // the key bytes of group g lie at 16 g: later appends (find-or-insert) continue behind them
     a->ks[0].tail = static_cast<uint64_t>(total) * 16u;
     CRGPU_HIP(hipMemcpyAsync(a->tails_dev.p, &a->ks[0].tail, 8, hipMemcpyHostToDevice, st));
     CRGPU_HIP(hipStreamSynchronize(st));

@@ -81,10 +81,12 @@ crgpu_status radix_partition_level1(RadixTable &t, const RadixSrc &src, int64_t 
 // About 2^log2_rows_per_sub rows per sub-partition, at most 2^max_sub_bits (<= 7) sub-partitions per partition.
 crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,
                                    int max_sub_bits);
-// Hash aggregation over a BYTES key column whose values are at most 16 bytes long: 32-byte rows {k0, k1, value, length}
-// (the key's bytes little-endian in two zero-padded words) through the same two partition levels.
+// Hash aggregation over a BYTES key column whose values are at most 16 bytes long -- or over two integer key columns --:
+// 32-byte rows {k0, k1, value, length} (the key's bytes little-endian in two zero-padded words) through the same two
+// partition levels.
 struct WideSrc {
-  DCol key;                        // BYTES, no NULLs
+  DCol key;                        // BYTES, no NULLs -- or the first of two integer key columns: {k0, k1} = the two
+  DCol key2;                       // sign-extended values, length 16 (type 0: absent)
   const unsigned long long *val;   // optional 8-byte value column (no NULLs), else the value is 0
 };
 __device__ __forceinline__ uint64_t wide_key_hash(uint64_t k0, uint64_t k1, uint64_t len) {

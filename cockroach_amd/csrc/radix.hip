@@ -374,6 +374,11 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
 // zero-padded, so two keys are equal exactly when (k0, k1, length) are.  A 128-byte line holds four rows.  Keys longer
 // than 16 bytes raise bit 1 of the flag (the caller abandons the attempt); they are skipped by both passes alike.
 __device__ __forceinline__ bool wide_load(const WideSrc &s, int64_t r, ulonglong4 *row) {
+  if (s.key.type != CRGPU_BYTES) {  // two integer key columns
+    *row = make_ulonglong4(static_cast<uint64_t>(col_get_int(s.key, r)), static_cast<uint64_t>(col_get_int(s.key2, r)),
+                           s.val != nullptr ? s.val[r] : 0ull, 16ull);
+    return true;
+  }
   const uint32_t a0 = s.key.offsets[r], len = s.key.offsets[r + 1] - a0;
   const uint8_t *p = static_cast<const uint8_t *>(s.key.data) + a0;
   uint64_t k0 = 0, k1 = 0;

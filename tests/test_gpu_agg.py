@@ -428,6 +428,46 @@ def test_agg_bulk_wide_bytes_keys_vs_oracle(oracle):
     assert np.array_equal(_canon(_bytes_as_int_cols(got[0]) + got[1:]), _canon(_bytes_as_int_cols(want[0]) + want[1:]))
 
 
+@pytest.mark.parametrize("t2", ["INT64", "INT32", "INT16"])
+def test_agg_bulk_wide_two_integer_keys_vs_oracle(oracle, t2):
+    """Two integer group columns take the wide form too ({k0, k1} = the sign-extended values): negative values, the
+    extremes of both types, key pairs that agree in one column only, every pair twice; then more input through the
+    rebuilt index."""
+    from cockroach_amd import device as dev
+    typ = getattr(cd, t2)
+    npt = {"INT64": np.int64, "INT32": np.int32, "INT16": np.int16}[t2]
+    info = np.iinfo(npt)
+    rng = np.random.default_rng(33)
+    n1, n2 = 1 << 23, 100_000
+    m = n1 // 2
+    a = (rng.permutation(m).astype(np.int64) - m // 2) * 977           # distinct first components ...
+    a[:m // 4] = a[m // 4:m // 2]                                        # ... a quarter of them used twice, with
+    b = rng.integers(int(info.min), int(info.max), size=m, dtype=np.int64, endpoint=True)
+    b[:m // 4] = b[m // 4:m // 2] + np.where(b[m // 4:m // 2] < info.max, 1, -1)  # a different second component
+    a[:4] = [np.iinfo(np.int64).min, np.iinfo(np.int64).max, -1, 0]
+    b[:4] = [info.min, info.max, -1, 0]
+    pick = np.concatenate([np.arange(m), np.arange(m)])
+    rng.shuffle(pick)
+    old = rng.integers(0, m, size=n2 // 2)
+    ka = np.concatenate([a[pick], a[old], np.arange(n2 // 2, dtype=np.int64) + (1 << 50)])
+    kb = np.concatenate([b[pick], b[old], np.zeros(n2 // 2, dtype=np.int64)]).astype(npt)
+    x = rng.integers(-10**9, 10**9, size=n1 + n2, dtype=np.int64)
+    cols = [cd.Vec.from_numpy(cd.INT64, ka), cd.Vec.from_numpy(typ, kb), cd.Vec.from_numpy(cd.INT64, x)]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 1, -1), (F["SUM_INT"], 2, -1), (F["COUNT_ROWS"], -1, -1), (F["MAX"], 2, -1)]
+    ag = dev.Agg([cd.INT64, typ, cd.INT64], [0, 1], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    ag.consume([dev.upload(v.slice(0, n1)) for v in cols], n1)
+    assert dev.prof_get("agg_bulk")[1] == 1, "the wide form of the bulk path did not run"
+    ag.consume([dev.upload(v.slice(n1, n1 + n2)) for v in cols], n2)
+    dev.prof_enable(False)
+    got = dev.result_to_vecs(ag.finish())
+    ag.close()
+    want = oracle.hash_agg(cols, [0, 1], aggs)
+    assert got[0].n == want[0].n
+    assert np.array_equal(_canon(got), _canon(want))
+
+
 def test_agg_bulk_wide_abandoned_on_a_long_key(oracle):
     """One 17-byte key that the 8192-row sample does not see: the histogram pass of the wide form reports it, the
     attempt is abandoned before anything is committed, and the incremental path gives the oracle's result."""
