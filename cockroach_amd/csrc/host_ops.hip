@@ -6,10 +6,14 @@
 // in large pieces, drives the bulk device API and hands results back in caller-owned
 // output batches -- the colexecop.Operator Next() contract
 // (pkg/sql/colexecop/operator.go:22-58).  Nothing borrowed is retained across calls.
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <unordered_set>
+#include <vector>
 
 #include "common.h"
 
@@ -22,13 +26,86 @@ static constexpr int kMaxInline = 30;                    // coldata.BytesMaxInli
 // ------------------------------------------------------------------ host-side staging
 // std::vector<uint8_t>::resize zero-fills, which doubles the memory traffic of a buffer that is overwritten at once
 // (a D2H copy, a memcpy): this allocator default-initialises instead, i.e. leaves the bytes alone.
+// Large staging and result buffers are PINNED (hipHostMalloc) and pooled: a transfer from or to pageable memory is
+// staged through the runtime's own bounce buffers (D2H measured 29 GB/s against ~55 from pinned memory), and a fresh
+// pageable buffer pays a page fault per 4 KiB on first touch.  Blocks are powers of two from 64 KiB, returned to a
+// process-wide free list (kept until the process ends; beyond CRGPU_PINNED_MAX_BYTES, 8 GiB, blocks are pageable).
+class PinnedPool {
+ public:
+  static PinnedPool &get() {
+    static PinnedPool *p = new PinnedPool();  // never destroyed: hipHostFree after the runtime has shut down is not safe
+    return *p;
+  }
+  void *alloc(size_t bytes) {
+    if (bytes < kMin) return std::malloc(bytes ? bytes : 1);
+    const int b = bucket(bytes);
+    const size_t size = size_t(1) << b;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (!free_[b].empty()) {
+        void *p = free_[b].back();
+        free_[b].pop_back();
+        return p;
+      }
+      if (pinned_bytes_ + size > max_bytes_) return std::malloc(bytes);
+      pinned_bytes_ += size;
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, size, hipHostMallocPortable) != hipSuccess || p == nullptr) {
+      (void)hipGetLastError();
+      std::lock_guard<std::mutex> g(mu_);
+      pinned_bytes_ -= size;
+      return std::malloc(bytes);
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    pinned_.insert(p);
+    return p;
+  }
+  void release(void *p, size_t bytes) {
+    if (p == nullptr) return;
+    if (bytes >= kMin) {
+      std::lock_guard<std::mutex> g(mu_);
+      if (pinned_.count(p)) {
+        free_[bucket(bytes)].push_back(p);
+        return;
+      }
+    }
+    std::free(p);
+  }
+
+ private:
+  static constexpr size_t kMin = size_t(64) << 10;
+  static int bucket(size_t bytes) {
+    int b = 16;
+    while ((size_t(1) << b) < bytes) b++;
+    return b;
+  }
+  PinnedPool() {
+    const char *e = std::getenv("CRGPU_PINNED_MAX_BYTES");
+    max_bytes_ = e != nullptr ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : size_t(8) << 30;
+  }
+  std::mutex mu_;
+  std::vector<void *> free_[64];
+  std::unordered_set<void *> pinned_;
+  size_t pinned_bytes_ = 0, max_bytes_ = 0;
+};
+
 template <class T>
-struct NoInitAlloc : std::allocator<T> {
+struct NoInitAlloc {
+  using value_type = T;
   template <class U> struct rebind { using other = NoInitAlloc<U>; };
   NoInitAlloc() = default;
   template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+  T *allocate(size_t n) {
+    void *p = PinnedPool::get().alloc(n * sizeof(T));
+    if (p == nullptr) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t n) noexcept { PinnedPool::get().release(p, n * sizeof(T)); }
   template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
   template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+  template <class U> bool operator==(const NoInitAlloc<U> &) const { return true; }
+  template <class U> bool operator!=(const NoInitAlloc<U> &) const { return false; }
 };
 using ByteVec = std::vector<uint8_t, NoInitAlloc<uint8_t>>;
 
