@@ -255,11 +255,59 @@ static crgpu_status upload_table(const std::vector<HostCol> &h, DevTable &t) {
   return CRGPU_OK;
 }
 
+// Tables of fixed-width columns without NULLs can be uploaded asynchronously (their sizes are known up front); the
+// staged host columns must then stay untouched until the copies have run.
+static bool plain_fixed(const std::vector<HostCol> &h) {
+  for (const HostCol &c : h)
+    if (c.type == CRGPU_BYTES || c.any_null) return false;
+  return !h.empty();
+}
+static crgpu_status upload_table_async(const std::vector<HostCol> &h, DevTable &t) {
+  const size_t nc = h.size();
+  if (t.data.size() != nc) {
+    t.data = std::vector<DevBuf>(nc);
+    t.valid = std::vector<DevBuf>(nc);
+    t.offsets = std::vector<DevBuf>(nc);
+    t.cols.resize(nc);
+  }
+  t.n = h[0].n;
+  for (size_t c = 0; c < nc; c++) {
+    crgpu_dcol &d = t.cols[c];
+    d.type = h[c].type;
+    d._pad = 0;
+    CRGPU_TRY(t.data[c].ensure(h[c].data.size() ? h[c].data.size() : 16));
+    if (!h[c].data.empty()) CRGPU_HIP(hipMemcpyAsync(t.data[c].p, h[c].data.data(), h[c].data.size(), hipMemcpyHostToDevice, stream()));
+    d.data = t.data[c].p;
+    d.offsets = nullptr;
+    d.valid = nullptr;
+  }
+  return CRGPU_OK;
+}
+
 // result of a bulk call copied back to the host, served in output batches
 struct HostResult {
   std::vector<HostCol> cols;
   int64_t n = 0, cursor = 0;
+  hipEvent_t ready = nullptr;  // set while the device-to-host copies of the columns are still in flight
+  HostResult() = default;
+  HostResult(const HostResult &) = delete;
+  HostResult &operator=(const HostResult &) = delete;
+  ~HostResult() {
+    if (ready != nullptr) {
+      (void)hipEventSynchronize(ready);  // the copies write into `cols`
+      (void)hipEventDestroy(ready);
+    }
+  }
+  crgpu_status wait() {
+    if (ready == nullptr) return CRGPU_OK;
+    const hipError_t e = hipEventSynchronize(ready);
+    (void)hipEventDestroy(ready);
+    ready = nullptr;
+    CRGPU_HIP(e);
+    return CRGPU_OK;
+  }
 };
+
 
 static crgpu_status download_result(const crgpu_dev_result &r, HostResult &out) {
   out.n = r.n;
@@ -291,6 +339,27 @@ static crgpu_status download_result(const crgpu_dev_result &r, HostResult &out) 
       if (!h.data.empty()) CRGPU_HIP(hipMemcpy(h.data.data(), d.data, h.data.size(), hipMemcpyDeviceToHost));
     }
   }
+  return CRGPU_OK;
+}
+
+// The same without waiting, for results made of fixed-width columns that cannot be NULL: the copies are enqueued behind
+// the kernels that produce the columns and `out.ready` tells when they have landed.  The device columns stay valid
+// until the handle's next call, whose kernels run behind these copies on the same stream.
+static crgpu_status download_result_async(const crgpu_dev_result &r, HostResult &out) {
+  for (int c = 0; c < r.ncols; c++)
+    if (r.cols[c].type == CRGPU_BYTES || r.cols[c].valid != nullptr) return download_result(r, out);
+  out.n = r.n;
+  out.cursor = 0;
+  out.cols.resize(r.ncols);
+  for (int c = 0; c < r.ncols; c++) {
+    HostCol &h = out.cols[c];
+    h.init(r.cols[c].type);
+    h.n = r.n;
+    h.data.resize(static_cast<size_t>(r.n) * type_width(r.cols[c].type));
+    if (!h.data.empty()) CRGPU_HIP(hipMemcpyAsync(h.data.data(), r.cols[c].data, h.data.size(), hipMemcpyDeviceToHost, stream()));
+  }
+  CRGPU_HIP(hipEventCreateWithFlags(&out.ready, hipEventDisableTiming));
+  CRGPU_HIP(hipEventRecord(out.ready, stream()));
   return CRGPU_OK;
 }
 
@@ -368,6 +437,7 @@ static crgpu_status emit_from_queue(std::deque<std::unique_ptr<HostResult>> &q, 
   out->length = 0;
   while (!q.empty() && q.front()->cursor >= q.front()->n) q.pop_front();
   if (q.empty()) return CRGPU_OK;
+  CRGPU_TRY(q.front()->wait());
   bool emitted;
   return emit_rows(*q.front(), out, &emitted);
 }
@@ -436,6 +506,13 @@ struct crgpu_hj : crgpu::Shell {
   std::vector<int> left_types, right_types;
   std::vector<HostCol> build_stage, probe_stage;
   DevTable build_dev, probe_dev;
+  // Probe chunks of fixed-width columns are pipelined: a chunk is uploaded asynchronously when it is full and probed
+  // only when the NEXT chunk is full (or output is asked for), so the transfer runs while the shell stages more batches;
+  // its result comes back asynchronously too.  probe_inflight holds the host rows of the chunk whose upload is pending.
+  std::vector<HostCol> probe_inflight;
+  DevTable probe_dev2;
+  int probe_cur = 0;       // which device table the uploaded chunk sits in
+  bool deferred = false;   // an uploaded chunk has not been probed yet
   enum State { BUILDING, PROBING, DRAINING } state = BUILDING;
   std::deque<std::unique_ptr<HostResult>> outq;
   int64_t export_cursor = 0;
@@ -454,6 +531,7 @@ extern "C" crgpu_status crgpu_hj_new(const crgpu_join_spec *spec, crgpu_hj **out
   for (int i = 0; i < spec->n_right_cols; i++) h->right_types.push_back(spec->right_types[i]);
   init_cols(h->build_stage, h->right_types);
   init_cols(h->probe_stage, h->left_types);
+  init_cols(h->probe_inflight, h->left_types);
   *out = h;
   return CRGPU_OK;
 }
@@ -467,9 +545,12 @@ extern "C" void crgpu_hj_free(crgpu_hj *h) {
 extern "C" crgpu_status crgpu_hj_reset(crgpu_hj *h) {
   if (h == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_hj_reset: null handle");
   CRGPU_ENTER(h->inner);
+  if (h->deferred) CRGPU_HIP(hipStreamSynchronize(stream()));  // an upload may still read probe_inflight
+  h->deferred = false;
   CRGPU_TRY(crgpu_dev_join_reset(h->dev));
   clear_cols(h->build_stage);
   clear_cols(h->probe_stage);
+  clear_cols(h->probe_inflight);
   h->outq.clear();
   h->state = crgpu_hj::BUILDING;
   h->export_cursor = 0;
@@ -496,21 +577,45 @@ extern "C" crgpu_status crgpu_hj_build_finish(crgpu_hj *h) {
   return CRGPU_OK;
 }
 
-static crgpu_status hj_flush_probe(crgpu_hj *h) {
+static crgpu_status hj_probe_table(crgpu_hj *h, DevTable &t) {
+  crgpu_dev_result r;
+  CRGPU_TRY(crgpu_dev_join_probe(h->dev, t.cols.data(), t.n, &r));
+  if (r.n > 0) {
+    std::unique_ptr<HostResult> hr(new HostResult());
+    CRGPU_TRY(download_result_async(r, *hr));
+    h->outq.push_back(std::move(hr));
+  }
+  return CRGPU_OK;
+}
+
+// drain: everything staged or uploaded is probed before the call returns (output was asked for, or the input ended)
+static crgpu_status hj_flush_probe(crgpu_hj *h, bool drain) {
+  if (h->deferred) {  // the chunk uploaded by the previous flush: its transfer ran while the next chunk was staged
+    h->deferred = false;
+    CRGPU_TRY(hj_probe_table(h, h->probe_cur ? h->probe_dev2 : h->probe_dev));
+  }
   if (h->probe_stage.empty() || h->probe_stage[0].n == 0) return CRGPU_OK;
   if (h->build_on_host) {  // the host copy of the build side is only needed for ExportBuffered before probing starts
     clear_cols(h->build_stage);
     for (auto &c : h->build_stage) { c.data.shrink_to_fit(); c.present.shrink_to_fit(); c.offsets.shrink_to_fit(); }
     h->build_on_host = false;
   }
-  CRGPU_TRY(upload_table(h->probe_stage, h->probe_dev));
-  crgpu_dev_result r;
-  CRGPU_TRY(crgpu_dev_join_probe(h->dev, h->probe_dev.cols.data(), h->probe_dev.n, &r));
+  if (!plain_fixed(h->probe_stage)) {
+    CRGPU_TRY(upload_table(h->probe_stage, h->probe_dev));
+    clear_cols(h->probe_stage);
+    return hj_probe_table(h, h->probe_dev);
+  }
+  // (the other device table and probe_inflight are free: the chunk that used them has been probed, which waited for
+  // its upload)
+  h->probe_cur ^= 1;
+  DevTable &t = h->probe_cur ? h->probe_dev2 : h->probe_dev;
+  CRGPU_TRY(upload_table_async(h->probe_stage, t));
+  std::swap(h->probe_stage, h->probe_inflight);
   clear_cols(h->probe_stage);
-  if (r.n > 0) {
-    std::unique_ptr<HostResult> hr(new HostResult());
-    CRGPU_TRY(download_result(r, *hr));
-    h->outq.push_back(std::move(hr));
+  h->deferred = true;
+  if (drain) {
+    h->deferred = false;
+    CRGPU_TRY(hj_probe_table(h, t));
   }
   return CRGPU_OK;
 }
@@ -521,7 +626,7 @@ extern "C" crgpu_status crgpu_hj_probe_append(crgpu_hj *h, const crgpu_batch *le
   CRGPU_CHECK_CANCEL(h->inner);
   if (h->state != crgpu_hj::PROBING) return fail(CRGPU_ERR_STATE, "crgpu_hj_probe_append: build side not finished or probe side already finished");
   CRGPU_TRY(stage_batch(h->probe_stage, left));
-  if (!h->probe_stage.empty() && h->probe_stage[0].n >= kFlushRows) CRGPU_TRY(hj_flush_probe(h));
+  if (!h->probe_stage.empty() && h->probe_stage[0].n >= kFlushRows) CRGPU_TRY(hj_flush_probe(h, false));
   return CRGPU_OK;
 }
 
@@ -530,7 +635,7 @@ extern "C" crgpu_status crgpu_hj_probe_finish(crgpu_hj *h) {
   CRGPU_ENTER(h->inner);
   CRGPU_CHECK_CANCEL(h->inner);
   if (h->state != crgpu_hj::PROBING) return fail(CRGPU_ERR_STATE, "crgpu_hj_probe_finish: not probing");
-  CRGPU_TRY(hj_flush_probe(h));
+  CRGPU_TRY(hj_flush_probe(h, true));
   crgpu_dev_result r;
   CRGPU_TRY(crgpu_dev_join_emit_right(h->dev, &r));  // hjEmittingRight (hashjoiner.go:322-328)
   if (r.n > 0) {
@@ -548,7 +653,7 @@ extern "C" crgpu_status crgpu_hj_next_output(crgpu_hj *h, crgpu_out_batch *out) 
   CRGPU_CHECK_CANCEL(h->inner);
   out->length = 0;
   while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
-  if (h->outq.empty() && h->state == crgpu_hj::PROBING) CRGPU_TRY(hj_flush_probe(h));
+  if (h->outq.empty() && h->state == crgpu_hj::PROBING) CRGPU_TRY(hj_flush_probe(h, true));
   return emit_from_queue(h->outq, out);
 }
 
