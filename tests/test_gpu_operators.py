@@ -433,3 +433,56 @@ def test_operators_nulls_appear_after_null_free_batches(oracle):
             want.append(row)
     assert got == want
     ud.close()
+
+
+@pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER"])
+def test_hash_joiner_pipelined_probe_chunks(jt):
+    """Five probe chunks of 2^20 rows read ahead before the output is drained: the shell uploads a chunk asynchronously,
+    probes it one chunk later and copies plain results back behind an event (INNER), or takes the synchronous copies
+    (LEFT OUTER: nullable build columns).  Every probe row must come out exactly once, with its own build row; a
+    Reset in the middle of a pipelined probe starts over cleanly."""
+    rng = np.random.default_rng(77)
+    nb, npr, bs = 1 << 16, 5 * (1 << 20) + 777, 1 << 16
+    bk = rng.permutation(nb * 2)[:nb].astype(np.int64)
+    pk = rng.integers(0, nb * 2, size=npr, dtype=np.int64)
+    pw = np.arange(npr, dtype=np.int64)
+    types = [cd.INT64, cd.INT64]
+    left = [cd.Vec.from_numpy(cd.INT64, pk), cd.Vec.from_numpy(cd.INT64, pw)]
+    right = [cd.Vec.from_numpy(cd.INT64, bk), cd.Vec.from_numpy(cd.INT64, bk * 3 + 1)]
+    lsrc = ops.BatchSource(make_batches(left, bs, False, rng), types)
+    rsrc = ops.BatchSource(make_batches(right, bs, False, rng), types)
+    hj = ops.HashJoiner(H.JOIN_TYPE[jt], types, types, [0], [0], True, lsrc, rsrc, capacity=bs, lookahead=64)
+    hj.init()
+    present = np.zeros(nb * 2, dtype=bool)
+    present[bk] = True
+    hit = present[pk]
+
+    def collect(stop_after=None):
+        cols = [[], [], [], []]
+        valid3 = []
+        rows = 0
+        while True:
+            b = hj.next()
+            if b.length == 0:
+                break
+            for c in range(4):
+                cols[c].append(np.array(b.cols[c].data[:b.length]))
+            valid3.append(b.cols[3].present()[:b.length])
+            rows += b.length
+            if stop_after is not None and rows >= stop_after:
+                return None
+        return [np.concatenate(c) for c in cols], np.concatenate(valid3)
+
+    assert collect(stop_after=1 << 20) is None  # leave the joiner in the middle of its pipelined probe
+    hj.reset()
+    (k, w, rk, rv), v3 = collect()
+    hj.close()
+    order = np.argsort(w, kind="stable")
+    k, w, rk, rv, v3 = k[order], w[order], rk[order], rv[order], v3[order]
+    if jt == "INNER":
+        assert np.array_equal(w, pw[hit]) and np.array_equal(k, pk[hit])
+        assert np.array_equal(rk, k) and np.array_equal(rv, k * 3 + 1) and v3.all()
+    else:
+        assert np.array_equal(w, pw) and np.array_equal(k, pk)
+        assert np.array_equal(v3, hit)
+        assert np.array_equal(rk[hit], pk[hit]) and np.array_equal(rv[hit], pk[hit] * 3 + 1)
