@@ -1638,7 +1638,7 @@ struct BulkArgs {
   int32_t key_type;
   uint8_t *key_data;            // key store of the single group column
   uint8_t *key_present;
-  int32_t key_type2, _pad2;     // WIDE over two integer key columns: the second column's key store
+  int32_t key_type2, _pad2;     // WIDE over two INT64 key columns: the second column's key store
   uint8_t *key_data2;
   uint8_t *key_present2;
   uint64_t *b_off;              // WIDE: the BYTES key store; group g's bytes go to b_buf[16 g, 16 g + 16)
@@ -1648,6 +1648,9 @@ struct BulkArgs {
   unsigned int *ngroups;        // running group count (HBM)
   unsigned int *failed;         // a region held more than gmax groups
   unsigned int *not16;          // WIDE: some group's key is not exactly 16 bytes long
+  unsigned long long wmask;     // WIDE: all ones when the row's fourth word belongs to the key (its length), zero when it
+                                // is a second value (one integer key, two value columns)
+  uint8_t op_val[kMaxOpsPerLaunch];  // which of the row's values an aggregation reads (0: the first, 1: the second)
   uint32_t g0;
   uint32_t gmax;                // groups a region may hold (sized to the LDS the planes need)
   uint32_t slots;               // LDS index size (power of two, > gmax)
@@ -1657,9 +1660,10 @@ struct BulkRow;
 template <>
 struct BulkRow<false> {
   typedef ulonglong2 T;
-  static __device__ __forceinline__ bool same_key(const T &a, const T &b) { return a.x == b.x; }
+  static __device__ __forceinline__ bool same_key(const BulkArgs &, const T &a, const T &b) { return a.x == b.x; }
   static __device__ __forceinline__ unsigned long long value(const T &r) { return r.y; }
-  static __device__ __forceinline__ uint32_t slot_hash(const T &r) { return static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20); }
+  static __device__ __forceinline__ unsigned long long value2(const T &) { return 0ull; }
+  static __device__ __forceinline__ uint32_t slot_hash(const BulkArgs &, const T &r) { return static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20); }
   // the group's key and the hash word of the index entry it gets if the index is ever rebuilt (agg_hash of one INT64 column)
   static __device__ __forceinline__ void store_key(const BulkArgs &a, uint32_t gid, const T &r) {
     reinterpret_cast<unsigned long long *>(a.key_data)[gid] = r.x;
@@ -1672,27 +1676,31 @@ struct BulkRow<false> {
 template <>
 struct BulkRow<true> {
   typedef ulonglong4 T;
-  static __device__ __forceinline__ bool same_key(const T &a, const T &b) { return a.x == b.x && a.y == b.y && a.w == b.w; }
-  static __device__ __forceinline__ unsigned long long value(const T &r) { return r.z; }
-  static __device__ __forceinline__ uint32_t slot_hash(const T &r) {
-    return static_cast<uint32_t>(fmix64(wide_key_hash(r.x, r.y, r.w) ^ 0x5851F42D4C957F2Dull) >> 20);
+  static __device__ __forceinline__ bool same_key(const BulkArgs &g, const T &a, const T &b) {
+    return a.x == b.x && a.y == b.y && ((a.w ^ b.w) & g.wmask) == 0;
   }
-  static __device__ __forceinline__ void store_int(uint8_t *data, int type, uint32_t gid, unsigned long long v) {
-    switch (type) {
-      case CRGPU_INT16: reinterpret_cast<int16_t *>(data)[gid] = static_cast<int16_t>(v); break;
-      case CRGPU_INT32: reinterpret_cast<int32_t *>(data)[gid] = static_cast<int32_t>(v); break;
-      default: reinterpret_cast<unsigned long long *>(data)[gid] = v; break;
-    }
+  static __device__ __forceinline__ unsigned long long value(const T &r) { return r.z; }
+  static __device__ __forceinline__ unsigned long long value2(const T &r) { return r.w; }
+  static __device__ __forceinline__ uint32_t slot_hash(const BulkArgs &g, const T &r) {
+    return static_cast<uint32_t>(fmix64(wide_key_hash(r.x, r.y, r.w & g.wmask) ^ 0x5851F42D4C957F2Dull) >> 20);
   }
   // agg_hash of one BYTES column: the full 8-byte words, the zero-padded rest, then the length; of two integer columns:
   // their sign-extended values one after the other
   static __device__ __forceinline__ void store_key(const BulkArgs &a, uint32_t gid, const T &r) {
     if (a.key_type != CRGPU_BYTES) {
-      store_int(a.key_data, a.key_type, gid, r.x);
-      store_int(a.key_data2, a.key_type2, gid, r.y);
+      // INT64 keys only: a per-type switch on the store width here was MISCOMPILED by hipcc 7.2 for gfx950 (the group
+      // number of the present-byte store after it was an undefined register on the 8-byte path of the all-distinct
+      // branch, so one byte per region was written; found with a first-run-in-a-fresh-process check, since pooled
+      // memory holds the 1s of earlier runs).  tests/test_gpu_agg.py::test_agg_bulk_paths_in_a_fresh_process pins it.
+      reinterpret_cast<unsigned long long *>(a.key_data)[gid] = r.x;
       a.key_present[gid] = 1;
-      a.key_present2[gid] = 1;
-      const uint64_t h = fmix64(hash_step(hash_step(0x9E3779B97F4A7C15ull, r.x), r.y));
+      uint64_t h = hash_step(0x9E3779B97F4A7C15ull, r.x);
+      if (a.key_data2 != nullptr) {  // two integer keys (else: one key, the row carries two values)
+        reinterpret_cast<unsigned long long *>(a.key_data2)[gid] = r.y;
+        a.key_present2[gid] = 1;
+        h = hash_step(h, r.y);
+      }
+      h = fmix64(h);
       a.gword[gid] = (static_cast<unsigned long long>((static_cast<uint32_t>(h >> 30) & 0x7FFFFFu) << 8) << 32) |
                      (static_cast<uint32_t>(h) & kIdxHashMask);
       return;
@@ -1753,18 +1761,20 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
     // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key); the claimant
     //    numbers the group
     uint32_t slot_of[kRows];
-    unsigned long long val[kRows];
+    unsigned long long val[kRows], val2[kRows];
     Row rr[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
       const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
       slot_of[k] = kNone;
       val[k] = 0;
+      val2[k] = 0;
       bool claimed = false;
       if (i < n) {
         const Row r = rr[k] = rows[i];
         val[k] = R::value(r);
-        uint32_t sl = R::slot_hash(r) & smask;
+        val2[k] = R::value2(r);
+        uint32_t sl = R::slot_hash(a, r) & smask;
         uint32_t probes = 0;
         for (;; probes++) {
           if (probes == a.slots) {  // the index is full of other keys: far more groups than the planes hold
@@ -1780,7 +1790,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
               break;
             }
           }
-          if (R::same_key(rows[cur], r)) break;
+          if (R::same_key(a, rows[cur], r)) break;
           sl = (sl + 1) & smask;
         }
         slot_of[k] = sl;
@@ -1815,10 +1825,10 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       for (int k = 0; k < kRows; k++) {
         if (slot_of[k] == kNone) continue;
         const uint32_t gid = base + k * blockDim.x + threadIdx.x;
-        const unsigned long long v = val[k];
         R::store_key(a, gid, rr[k]);
         for (int f = 0; f < a.naggs; f++) {
           const OpK &op = a.ops[f];
+          const unsigned long long v = (WIDE && a.op_val[f]) ? val2[k] : val[k];
           unsigned long long w0 = v, w1 = 0;
           uint8_t seen = 1;
           switch (op.kind) {  // what apply_rows_lds leaves in a group's words after this one row
@@ -1855,7 +1865,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       takem |= (slot_of[k] != kNone ? 1u : 0u) << k;
     }
     for (int f = 0; f < a.naggs; f++)
-      apply_rows_lds<kRows>(a.ops[f], val, takem, gr, a.gmax, plane, lds_words, lds_seen, rowi, 0ull);
+      apply_rows_lds<kRows>(a.ops[f], (WIDE && a.op_val[f]) ? val2 : val, takem, gr, a.gmax, plane, lds_words, lds_seen, rowi, 0ull);
     // no barrier needed before the next tile's inserts: they touch idx / lid / rep / s_claims, the updates above touch
     // the planes; lid entries read above were written before the barrier and are never rewritten
   }
@@ -3660,7 +3670,8 @@ __global__ void agg_sample_wide_kernel(DCol key, DCol key2, int64_t stride, int 
   if (i >= nsample) return;
   const int64_t r = static_cast<int64_t>(i) * stride;
   if (key.type != CRGPU_BYTES) {
-    out[i] = static_cast<long long>(wide_key_hash(static_cast<uint64_t>(col_get_int(key, r)), static_cast<uint64_t>(col_get_int(key2, r)), 16));
+    const uint64_t k1 = key2.data != nullptr ? static_cast<uint64_t>(col_get_int(key2, r)) : 0ull;  // (one key, two values: no key2)
+    out[i] = static_cast<long long>(wide_key_hash(static_cast<uint64_t>(col_get_int(key, r)), k1, 16));
     return;
   }
   const uint32_t a0 = key.offsets[r], len = key.offsets[r + 1] - a0;
@@ -3678,6 +3689,17 @@ __global__ void agg_sample_wide_kernel(DCol key, DCol key2, int64_t stride, int 
   out[i] = static_cast<long long>(wide_key_hash(k0, k1, len));
 }
 
+// sets *flag when one of the first n bits of a validity bitmap is clear
+__global__ __launch_bounds__(256) void agg_bitmap_has_null_kernel(const uint8_t *__restrict__ valid, int64_t n, unsigned int *__restrict__ flag) {
+  const int64_t nbytes = (n + 7) / 8;
+  bool bad = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < nbytes; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const uint32_t want = (i == nbytes - 1 && (n & 7)) ? ((1u << (n & 7)) - 1u) : 0xFFu;
+    bad |= (valid[i] & want) != want;
+  }
+  if (bad) *flag = 1u;
+}
+
 // Bulk path (see agg_bulk_kernel).  *done = true when the whole input was aggregated; otherwise nothing was changed
 // and the caller continues with the incremental path.
 static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
@@ -3688,32 +3710,57 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   // One INT64 key travels as 16-byte {key, value} rows; one BYTES key of at most 16 bytes, or two integer keys, as
   // 32-byte {k0, k1, value, length} rows (wide form, the sub form only: it exists for config G's all-distinct keys)
   const bool two_ints = a->group_cols.size() == 2;
-  if (two_ints && (!is_int_type(key_type) || !is_int_type(a->types[a->group_cols[1]]))) return CRGPU_OK;
-  const bool wide = two_ints || key_type == CRGPU_BYTES;
-  if (key_type != CRGPU_INT64 && !wide) return CRGPU_OK;
-  static const bool wide_on = getenv("CRGPU_BULK_WIDE") == nullptr || getenv("CRGPU_BULK_WIDE")[0] != '0';
-  if (wide && !wide_on) return CRGPU_OK;
-  const DCol &key = cols[a->group_cols[0]];
-  DCol key2;
-  std::memset(&key2, 0, sizeof(key2));
-  if (two_ints) key2 = cols[a->group_cols[1]];
-  if (key.valid != nullptr || key2.valid != nullptr || (!wide && (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0)) return CRGPU_OK;
-  int vcol = -1, nops = 0;
+  if (two_ints && (key_type != CRGPU_INT64 || a->types[a->group_cols[1]] != CRGPU_INT64)) return CRGPU_OK;
+  int vcol = -1, vcol2 = -1, nops = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
     nops++;
     if (h.filter_col >= 0) return CRGPU_OK;
     if (h.kind != ACC_COUNT_ROWS) {
       if (h.in_type != CRGPU_INT64 && h.in_type != CRGPU_FLOAT64) return CRGPU_OK;
-      if (vcol >= 0 && vcol != h.col) return CRGPU_OK;
-      vcol = h.col;
+      if (vcol < 0 || vcol == h.col) vcol = h.col;
+      else if (vcol2 < 0 || vcol2 == h.col) vcol2 = h.col;
+      else return CRGPU_OK;
     }
   }
   if (nops > kMaxOpsPerLaunch) return CRGPU_OK;
-  if (vcol >= 0 && (cols[vcol].valid != nullptr || (!wide && (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0))) return CRGPU_OK;
+  // a second value column rides in the wide row's fourth word, which is free only when the key is one integer column
+  // (the final stage of a distributed GROUP BY: key, partial sum, partial count)
+  const bool two_vals = vcol2 >= 0;
+  if (two_vals && (two_ints || key_type != CRGPU_INT64)) return CRGPU_OK;
+  const bool wide = two_ints || two_vals || key_type == CRGPU_BYTES;
+  if (key_type != CRGPU_INT64 && !wide) return CRGPU_OK;
+  static const bool wide_on = getenv("CRGPU_BULK_WIDE") == nullptr || getenv("CRGPU_BULK_WIDE")[0] != '0';
+  if (wide && !wide_on) return CRGPU_OK;
+  DCol key = cols[a->group_cols[0]];
+  DCol key2;
+  std::memset(&key2, 0, sizeof(key2));
+  if (two_ints) key2 = cols[a->group_cols[1]];
+  if (!wide && (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0) return CRGPU_OK;
+  if (vcol >= 0 && !wide && (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0) return CRGPU_OK;
+  hipStream_t st = stream();
+  {
+    // Columns that carry a validity bitmap without a NULL in it (the partial rows of a distributed GROUP BY arrive like
+    // that: the outputs of the local stage are nullable) are as good as columns without one: a pass over n / 8 bytes
+    const uint8_t *maps[4] = {key.valid, key2.valid, vcol >= 0 ? cols[vcol].valid : nullptr, two_vals ? cols[vcol2].valid : nullptr};
+    bool any = false;
+    for (const uint8_t *m : maps) any = any || m != nullptr;
+    if (any) {
+      CRGPU_TRY(a->bulk_count.ensure(16));
+      CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 4, st));
+      for (const uint8_t *m : maps)
+        if (m != nullptr) hipLaunchKernelGGL(agg_bitmap_has_null_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0, st, m, n, a->bulk_count.as<unsigned int>());
+      CRGPU_HIP(hipGetLastError());
+      unsigned int has_null = 0;
+      CRGPU_HIP(hipMemcpyAsync(&has_null, a->bulk_count.p, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipStreamSynchronize(st));
+      if (has_null) return CRGPU_OK;
+      key.valid = nullptr;
+      key2.valid = nullptr;
+    }
+  }
   const size_t bpg = static_cast<size_t>(a->lds_words) * 8 + static_cast<size_t>(a->lds_seen);
   if (bpg == 0) return CRGPU_OK;
-  hipStream_t st = stream();
   // Which form?  s keys sampled at a fixed stride: for G equally likely groups the sample holds G (1 - exp(-s / G))
   // distinct keys.  The small sample rejects low-cardinality inputs for ~30 us.
   int64_t distinct = 0, maxrun = 0;
@@ -3804,10 +3851,11 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     ws.key = key;
     ws.key2 = key2;
     ws.val = vcol >= 0 ? static_cast<const unsigned long long *>(cols[vcol].data) : nullptr;
+    ws.val2 = two_vals ? static_cast<const unsigned long long *>(cols[vcol2].data) : nullptr;
     bool ok = false;
     CRGPU_TRY(radix_partition_split_wide(a->radix, ws, n, &ok, kBulkRows, 10, 7));
     if (!ok) return CRGPU_OK;  // a sub-partition overflowed, or a key is longer than 16 bytes
-    if (!two_ints) CRGPU_TRY(a->ks[0].b_buf.ensure(static_cast<size_t>(n) * 16 + 16));
+    if (key_type == CRGPU_BYTES) CRGPU_TRY(a->ks[0].b_buf.ensure(static_cast<size_t>(n) * 16 + 16));
   } else if (sub_form) {
     bool ok = false;
     CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
@@ -3827,6 +3875,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   int f = 0;
   for (const AggOpHost &h : a->ops) {
     if (h.kind == ACC_ANY_KEY) continue;
+    b.op_val[f] = (two_vals && h.kind != ACC_COUNT_ROWS && h.col == vcol2) ? 1 : 0;
     OpK &k = b.ops[f++];
     k.kind = static_cast<int8_t>(h.kind);
     k.in_type = static_cast<int8_t>(h.in_type);
@@ -3855,6 +3904,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.ngroups = a->bulk_count.as<unsigned int>();
   b.failed = a->bulk_count.as<unsigned int>() + 1;
   b.not16 = a->bulk_count.as<unsigned int>() + 2;
+  b.wmask = two_vals ? 0ull : ~0ull;
   b.g0 = 0;
   b.gmax = static_cast<uint32_t>(gmax);
   b.slots = static_cast<uint32_t>(slots);
@@ -3870,7 +3920,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   CRGPU_HIP(hipStreamSynchronize(st));
   if (tf[1]) return CRGPU_OK;  // nothing was committed: the groups written so far lie beyond ngroups == 0
   const unsigned int total = tf[0];
-  if (wide && !two_ints) {  // the key bytes of group g lie at 16 g: later appends (find-or-insert) continue behind them
+  if (key_type == CRGPU_BYTES) {  // the key bytes of group g lie at 16 g: later appends (find-or-insert) continue behind them
     a->ks[0].tail = static_cast<uint64_t>(total) * 16u;
     CRGPU_HIP(hipMemcpyAsync(a->tails_dev.p, &a->ks[0].tail, 8, hipMemcpyHostToDevice, st));
     CRGPU_HIP(hipStreamSynchronize(st));

@@ -88,10 +88,13 @@ struct WideSrc {
   DCol key;                        // BYTES, no NULLs -- or the first of two integer key columns: {k0, k1} = the two
   DCol key2;                       // sign-extended values, length 16 (type 0: absent)
   const unsigned long long *val;   // optional 8-byte value column (no NULLs), else the value is 0
+  const unsigned long long *val2;  // non-null: ONE integer key column in `key` and two value columns -- the row is
+                                   // {key, 0, val, val2} and its fourth word is no part of the key (wmask = 0 below)
 };
 __device__ __forceinline__ uint64_t wide_key_hash(uint64_t k0, uint64_t k1, uint64_t len) {
   return fmix64(k0 ^ fmix64(k1 + len * 0x9E3779B97F4A7C15ull));
 }
+// (wmask: all ones when the fourth word belongs to the key -- the length --, zero when it carries a second value)
 crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64_t n, bool *ok, uint32_t subcap,
                                         int log2_rows_per_sub, int max_sub_bits);
 // Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows

@@ -374,6 +374,10 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
 // zero-padded, so two keys are equal exactly when (k0, k1, length) are.  A 128-byte line holds four rows.  Keys longer
 // than 16 bytes raise bit 1 of the flag (the caller abandons the attempt); they are skipped by both passes alike.
 __device__ __forceinline__ bool wide_load(const WideSrc &s, int64_t r, ulonglong4 *row) {
+  if (s.val2 != nullptr) {  // one integer key column, two value columns
+    *row = make_ulonglong4(static_cast<uint64_t>(col_get_int(s.key, r)), 0ull, s.val != nullptr ? s.val[r] : 0ull, s.val2[r]);
+    return true;
+  }
   if (s.key.type != CRGPU_BYTES) {  // two integer key columns
     *row = make_ulonglong4(static_cast<uint64_t>(col_get_int(s.key, r)), static_cast<uint64_t>(col_get_int(s.key2, r)),
                            s.val != nullptr ? s.val[r] : 0ull, 16ull);
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(1024) void wide_hist_kernel(WideSrc src, int64_t n,
   int64_t hi = lo + chunk_rows;
   if (hi > n) hi = n;
   bool bad = false;
+  const uint64_t wmask = src.val2 != nullptr ? 0ull : ~0ull;
   for (int64_t r0 = lo + threadIdx.x; r0 < hi; r0 += 4096) {
     ulonglong4 row[4];
     bool ok[4];
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(1024) void wide_hist_kernel(WideSrc src, int64_t n,
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (ok[j]) atomicAdd(&h[rpart(wide_key_hash(row[j].x, row[j].y, row[j].w))], 1u);
+      if (ok[j]) atomicAdd(&h[rpart(wide_key_hash(row[j].x, row[j].y, row[j].w & wmask))], 1u);
   }
   if (bad) atomicOr(flag, 2u);
   __syncthreads();
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(1024) void wide_scatter_kernel(WideSrc src, int64_t
   if (hi > n) hi = n;
   ulonglong4 nrow[ROWS];
   bool nok[ROWS];
+  const uint64_t wmask = src.val2 != nullptr ? 0ull : ~0ull;
 #pragma unroll
   for (int j = 0; j < ROWS; j++) {
     const int64_t r = lo + j * THREADS + threadIdx.x;
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(1024) void wide_scatter_kernel(WideSrc src, int64_t
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {
       row[j] = nrow[j];
-      pp[j] = nok[j] ? rpart(wide_key_hash(row[j].x, row[j].y, row[j].w)) : 0xFFFFFFFFu;
+      pp[j] = nok[j] ? rpart(wide_key_hash(row[j].x, row[j].y, row[j].w & wmask)) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {  // the next tile is requested while this one is ranked and flushed
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(1024) void wide_scatter_kernel(WideSrc src, int64_t
 __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__restrict__ in, const uint32_t *__restrict__ starts,
                                                           const uint32_t *__restrict__ totals, uint32_t smask,
                                                           ulonglong4 *__restrict__ out, uint32_t *__restrict__ sub_count,
-                                                          uint32_t *__restrict__ overflow, uint32_t subcap) {
+                                                          uint32_t *__restrict__ overflow, uint32_t subcap, uint64_t wmask) {
   constexpr int THREADS = 1024, ROWS = 2, TILE = THREADS * ROWS;
   const int p = blockIdx.x;
   const uint32_t nsub = smask + 1;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__re
       sp[j] = 0xFFFFFFFFu;
       if (i < n) {
         row[j] = in[s0 + i];
-        sp[j] = rsub(wide_key_hash(row[j].x, row[j].y, row[j].w), smask);
+        sp[j] = rsub(wide_key_hash(row[j].x, row[j].y, row[j].w & wmask), smask);
         rk[j] = atomicAdd(&tcnt[sp[j]], 1u);
       }
     }
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__re
     const uint32_t tile_rows = n - t0 < static_cast<uint32_t>(TILE) ? n - t0 : TILE;
     for (uint32_t i = threadIdx.x; i < tile_rows; i += THREADS) {
       const ulonglong4 r = stage[i];
-      const uint32_t s = rsub(wide_key_hash(r.x, r.y, r.w), smask);
+      const uint32_t s = rsub(wide_key_hash(r.x, r.y, r.w & wmask), smask);
       const uint32_t pos = cur[s] + (i - tstart[s]);
       if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
     }
@@ -1647,7 +1653,7 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
     ProfScope prof("radix_build_split");
     hipLaunchKernelGGL(wide_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong4>(), t.starts.as<uint32_t>(),
                        t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong4>(), t.sub_count.as<uint32_t>(),
-                       t.flag.as<uint32_t>(), subcap);
+                       t.flag.as<uint32_t>(), subcap, src.val2 != nullptr ? 0ull : ~0ull);
     CRGPU_HIP(hipGetLastError());
   }
   uint32_t flag = 0;

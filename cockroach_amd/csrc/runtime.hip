@@ -256,6 +256,20 @@ crgpu_status DevBuf::ensure(size_t bytes, bool keep) {
     }
     if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
   }
+  {
+    // Test aid (CRGPU_POOL_POISON=<byte>): every block a buffer receives is filled with that byte first.  Pooled blocks
+    // keep the contents of their previous owner and fresh ones are zero, so a kernel that forgets to write part of its
+    // output can pass by luck; the GPU suite runs clean with 0 and with 165 (see tests/conftest.py).
+    static const int poison = getenv("CRGPU_POOL_POISON") != nullptr ? atoi(getenv("CRGPU_POOL_POISON")) : -1;
+    if (poison >= 0) {
+      hipError_t c = hipMemsetAsync(np, poison & 0xFF, ncap, stream());
+      if (c == hipSuccess) c = hipStreamSynchronize(stream());
+      if (c != hipSuccess) {
+        (void)hipFree(np);
+        return hip_fail(c, "hipMemsetAsync(poison)", __FILE__, __LINE__);
+      }
+    }
+  }
   if (keep && p != nullptr && cap > 0) {
     hipError_t c = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, stream());
     if (c == hipSuccess) c = hipStreamSynchronize(stream());

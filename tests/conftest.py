@@ -4,6 +4,11 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Test aid of libcrgpu.so's buffer pool (csrc/runtime.hip, DevBuf::ensure): every block a buffer receives is filled with
+# this byte first.  Without it a pooled block keeps what its previous owner wrote, and a kernel that forgets part of its
+# output (e.g. the "present" bytes of new groups -- it happened) can pass by luck.  0 exposes missing non-zero writes;
+# run the suite with CRGPU_POOL_POISON=165 as well to expose outputs that rely on fresh memory being zero.
+os.environ.setdefault("CRGPU_POOL_POISON", "0")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
