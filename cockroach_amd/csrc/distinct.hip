@@ -319,6 +319,17 @@ __global__ __launch_bounds__(256) void distinct_bulk_words_kernel(KeyCols keys, 
   }
 }
 
+// sets *flag when one of the first n bits of a validity bitmap is clear
+__global__ __launch_bounds__(256) void distinct_bitmap_has_null_kernel(const uint8_t *__restrict__ valid, int64_t n, uint32_t *__restrict__ flag) {
+  const int64_t nbytes = (n + 7) / 8;
+  bool bad = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < nbytes; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const uint32_t want = (i == nbytes - 1 && (n & 7)) ? ((1u << (n & 7)) - 1u) : 0xFFu;
+    bad |= (valid[i] & want) != want;
+  }
+  if (bad) *flag = 1u;
+}
+
 __global__ void distinct_sample_kernel(const long long *__restrict__ keys, int64_t stride, int nsample, long long *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nsample) out[i] = keys[static_cast<int64_t>(i) * stride];
@@ -448,9 +459,20 @@ static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol>
   *done = false;
   static const bool on = getenv("CRGPU_DISTINCT_BULK") == nullptr || getenv("CRGPU_DISTINCT_BULK")[0] != '0';
   if (!on || d->ngroups != 0 || n < kDBulkMinRows || n > kDBulkMaxRows || d->dcols.size() != 1) return CRGPU_OK;
-  const DCol &key = in[d->dcols[0]];
-  if (key.type != CRGPU_INT64 || key.valid != nullptr) return CRGPU_OK;
+  DCol key = in[d->dcols[0]];
+  if (key.type != CRGPU_INT64) return CRGPU_OK;
   hipStream_t st = stream();
+  if (key.valid != nullptr) {  // a bitmap without a NULL in it (the output of a join or of a local aggregation) is as good as none
+    CRGPU_TRY(d->radix.flag.ensure(4));
+    CRGPU_HIP(hipMemsetAsync(d->radix.flag.p, 0, 4, st));
+    hipLaunchKernelGGL(distinct_bitmap_has_null_kernel, dim3(dgrid((n + 7) / 8)), dim3(256), 0, st, key.valid, n, d->radix.flag.as<uint32_t>());
+    CRGPU_HIP(hipGetLastError());
+    uint32_t has_null = 0;
+    CRGPU_HIP(hipMemcpyAsync(&has_null, d->radix.flag.p, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (has_null) return CRGPU_OK;
+    key.valid = nullptr;
+  }
   // mostly distinct?  8192 keys at a fixed stride; up to ~32 rows per key the regions hold (as the aggregator's sub form)
   constexpr int kSample = 8192;
   std::vector<int64_t> sample(kSample);

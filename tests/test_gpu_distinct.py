@@ -167,6 +167,50 @@ def test_distinct_bulk_part_form_vs_oracle(oracle, nkeys):
         assert np.array_equal(np.concatenate([out1[c].data, out2[c].data]), want[c].data)
 
 
+def test_distinct_bulk_path_key_with_all_set_validity_bitmap():
+    """A distinct column that carries a validity bitmap without a NULL (a join's or an aggregation's output) takes the
+    bulk path like one without; a single NULL keeps the batch on the index path.  All three give the same rows for the
+    non-NULL keys, in input order."""
+    import torch
+    from cockroach_amd import device as dev
+    from tests.gpu_util import wrap_torch
+    n = (1 << 23) + 3
+    dv = torch.device("cuda", 0)
+    g = torch.Generator(device=dv)
+    g.manual_seed(5)
+    k = torch.randint(0, n // 2, (n,), generator=g, device=dv, dtype=torch.int64) * 13 - 9
+    w = torch.arange(n, device=dv, dtype=torch.int64)
+    pres = np.ones(n, dtype=bool)
+    all_set = torch.from_numpy(np.packbits(pres, bitorder="little")).to(dv)
+    pres[n - 2] = False
+    one_null = torch.from_numpy(np.packbits(pres, bitorder="little")).to(dv)
+    torch.cuda.synchronize()
+    outs = []
+    dev.prof_enable(True)
+    for valid, want_bulk in ((None, 1), (all_set, 1), (one_null, 0)):
+        d = dev.Distinct([cd.INT64, cd.INT64], [0])
+        dev.prof_reset()
+        res = d.consume([dev.from_torch(cd.INT64, k, valid=valid), dev.from_torch(cd.INT64, w)], n)
+        assert dev.prof_get("distinct_bulk")[1] == want_bulk
+        m = int(res.n)
+        rc = dev.result_columns(res)
+        outs.append((wrap_torch(rc[0], m, torch.int64, dv).clone(), wrap_torch(rc[1], m, torch.int64, dv).clone()))
+        d.close()
+    dev.prof_enable(False)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    uk, inv = torch.unique(k, return_inverse=True)
+    first = torch.full((uk.numel(),), n, device=dv, dtype=torch.int64).scatter_reduce(0, inv, w, reduce="amin")
+    assert torch.equal(torch.sort(outs[0][1]).values, torch.sort(first).values) and bool((outs[0][1][1:] > outs[0][1][:-1]).all())
+    # the NULL row (position n - 2) is a key of its own on the index path: one more row unless its key was seen before
+    keep = outs[2][1] != n - 2
+    assert int((~keep).sum()) == 1
+    seen_before = bool((k[: n - 2] == k[n - 2]).any())
+    later = (k[n - 1] == k[n - 2]) and not seen_before  # the row after it would then be its key's first occurrence
+    if not later:
+        want_w = outs[0][1] if seen_before else outs[0][1][outs[0][1] != n - 2]
+        assert torch.equal(outs[2][1][keep], want_w)
+
+
 def test_distinct_bytes_keys_whole_batch_append_with_offset_base(oracle):
     """Mostly-new batches join the key store whole.  Here the BYTES key column's offsets do not start at 0 (a slice of
     a larger buffer, as a decode or join result can be) and the batches contain duplicates of keys from the same and
