@@ -1864,8 +1864,14 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       rowi[k] = 0;
       takem |= (slot_of[k] != kNone ? 1u : 0u) << k;
     }
-    for (int f = 0; f < a.naggs; f++)
-      apply_rows_lds<kRows>(a.ops[f], (WIDE && a.op_val[f]) ? val2 : val, takem, gr, a.gmax, plane, lds_words, lds_seen, rowi, 0ull);
+    for (int f = 0; f < a.naggs; f++) {
+      // (a select per row: choosing between the two arrays by pointer would move both into scratch memory)
+      unsigned long long vsel[kRows];
+      const bool second = WIDE && a.op_val[f] != 0;
+#pragma unroll
+      for (int k = 0; k < kRows; k++) vsel[k] = second ? val2[k] : val[k];
+      apply_rows_lds<kRows>(a.ops[f], vsel, takem, gr, a.gmax, plane, lds_words, lds_seen, rowi, 0ull);
+    }
     // no barrier needed before the next tile's inserts: they touch idx / lid / rep / s_claims, the updates above touch
     // the planes; lid entries read above were written before the barrier and are never rewritten
   }
