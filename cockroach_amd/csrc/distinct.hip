@@ -518,6 +518,7 @@ static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol>
   src.kp.c[0] = key;
   src.kp.range[0] = ~0ull;
   src.pay = nullptr;  // the payload is the row's position
+  src.fast = (reinterpret_cast<uintptr_t>(key.data) & 15u) == 0 ? 1 : 0;
   if (sub_form) {
     bool ok = false;
     CRGPU_TRY(radix_partition_split(d->radix, src, n, &ok, kDBulkRows, 10, 7));

@@ -950,8 +950,8 @@ static RadixSrc radix_src(const KeyPack &kp, const DCol *pay) {
   s.pay = pay ? static_cast<const uint8_t *>(pay->data) : nullptr;
   s.pay_width = pay ? type_width(pay->type) : 0;
   const DCol &key = kp.c[0];
-  s.fast = kp.n == 1 && key.type == CRGPU_INT64 && key.valid == nullptr && pay != nullptr && s.pay_width == 8 &&
-           aligned16(key.data) && aligned16(pay->data);
+  s.fast = kp.n == 1 && key.type == CRGPU_INT64 && key.valid == nullptr && aligned16(key.data) &&
+           (pay == nullptr || (s.pay_width == 8 && aligned16(pay->data)));
   return s;
 }
 

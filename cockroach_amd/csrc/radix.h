@@ -45,7 +45,7 @@ struct RadixSrc {
   KeyPack kp;          // the key word of a row (device.h)
   const uint8_t *pay;  // payload column, or null => the payload is the row id
   int32_t pay_width;
-  int32_t fast;  // int64 key without NULLs + 8-byte payload, both 16-byte aligned: vector loads
+  int32_t fast;  // int64 key without NULLs + 8-byte payload (or none: the row id), 16-byte aligned: vector loads
 };
 
 struct RadixSpecial {  // the one build key whose packed value equals kRadixEmpty

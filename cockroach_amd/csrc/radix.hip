@@ -61,8 +61,13 @@ __device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64
                                             bool *ok) {
   if (FAST && r0 + 1 < hi) {
     const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(s.kp.c[0].data)[r0 >> 1];
-    const ulonglong2 b = reinterpret_cast<const ulonglong2 *>(s.pay)[r0 >> 1];
-    k[0] = a.x, k[1] = a.y, v[0] = b.x, v[1] = b.y;
+    k[0] = a.x, k[1] = a.y;
+    if (s.pay != nullptr) {
+      const ulonglong2 b = reinterpret_cast<const ulonglong2 *>(s.pay)[r0 >> 1];
+      v[0] = b.x, v[1] = b.y;
+    } else {  // the payload is the row id
+      v[0] = static_cast<uint64_t>(r0), v[1] = static_cast<uint64_t>(r0 + 1);
+    }
     ok[0] = ok[1] = true;
     return;
   }
