@@ -657,6 +657,38 @@ struct crgpu_decoder : crgpu::Handle {
   std::vector<crgpu_dcol> views;
 };
 
+// bitmap[c] bit i = bytes[c][i] != 0 for every output column c (blockIdx.y); rows past n read as present, like pack_bitmap
+struct KvPackArgs {
+  const uint8_t *bytes[kMaxOutFetch];
+  uint8_t *bitmap[kMaxOutFetch];
+  int64_t n;
+  int32_t ncols, _pad;
+};
+__global__ __launch_bounds__(256) void kv_pack_valid_kernel(KvPackArgs a) {
+  // (selected with a uniform loop: indexing the kernel arguments with blockIdx.y directly costs a scalar loop per access)
+  const uint8_t *bytes = nullptr;
+  uint8_t *bitmap = nullptr;
+  for (int c = 0; c < a.ncols; c++)
+    if (c == static_cast<int>(blockIdx.y)) bytes = a.bytes[c], bitmap = a.bitmap[c];
+  const int64_t nbytes = (a.n + 7) >> 3;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; b < nbytes; b += stride) {
+    uint32_t bits = 0;
+    if (b * 8 + 8 <= a.n) {
+      const unsigned long long w = *reinterpret_cast<const unsigned long long *>(bytes + b * 8);  // eight rows at once
+#pragma unroll
+      for (int k = 0; k < 8; k++) bits |= (((w >> (8 * k)) & 0xFFull) != 0 ? 1u : 0u) << k;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int64_t i = b * 8 + k;
+        bits |= (i < a.n ? (bytes[i] != 0 ? 1u : 0u) : 1u) << k;
+      }
+    }
+    bitmap[b] = static_cast<uint8_t>(bits);
+  }
+}
+
 extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgpu_decoder **out) {
   CRGPU_TRY(ensure_init());
   if (s == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decoder_create: null argument");
@@ -909,7 +941,19 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
         hipLaunchKernelGGL(kv_copy_bytes_kernel, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o);
       CRGPU_HIP(hipGetLastError());
     }
-    for (int c = 0; c < f.n_out; c++) CRGPU_TRY(pack_bitmap(o.valid[c], n, d->out[c].valid.as<uint8_t>()));
+    {  // validity bytes -> bitmaps, all output columns in ONE launch (a launch per column was ~16 per call)
+      KvPackArgs pa;
+      std::memset(&pa, 0, sizeof(pa));
+      pa.ncols = f.n_out;
+      pa.n = n;
+      for (int c = 0; c < f.n_out; c++) {
+        pa.bytes[c] = o.valid[c];
+        pa.bitmap[c] = d->out[c].valid.as<uint8_t>();
+      }
+      const int64_t nbytes = (n + 7) >> 3;
+      hipLaunchKernelGGL(kv_pack_valid_kernel, dim3(kv_grid(nbytes, 256), static_cast<unsigned>(f.n_out)), dim3(256), 0, st, pa);
+      CRGPU_HIP(hipGetLastError());
+    }
   }
   CRGPU_HIP(hipStreamSynchronize(st));
   for (int c = 0; c < f.n_out; c++) d->views[c] = d->out[c].view();
