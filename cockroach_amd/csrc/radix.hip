@@ -56,16 +56,18 @@ __device__ __forceinline__ void rstore(uint8_t *dst, int64_t pos, int width, uin
 }
 
 // rows r0, r0+1 (r0 even) of one join side as {packed key, payload}
-template <bool FAST>
+// FAST: 0 generic loader; 1 vector loads of key and payload; 2 vector load of the key, the payload is the row id (a
+// compile-time form of its own: a run-time test of s.pay inside form 1 cost config J's probe-side scatter 0.2 ms)
+template <int FAST>
 __device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64_t hi, uint64_t *k, uint64_t *v,
                                             bool *ok) {
-  if (FAST && r0 + 1 < hi) {
+  if (FAST != 0 && r0 + 1 < hi) {
     const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(s.kp.c[0].data)[r0 >> 1];
     k[0] = a.x, k[1] = a.y;
-    if (s.pay != nullptr) {
+    if (FAST == 1) {
       const ulonglong2 b = reinterpret_cast<const ulonglong2 *>(s.pay)[r0 >> 1];
       v[0] = b.x, v[1] = b.y;
-    } else {  // the payload is the row id
+    } else {
       v[0] = static_cast<uint64_t>(r0), v[1] = static_cast<uint64_t>(r0 + 1);
     }
     ok[0] = ok[1] = true;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(1024) void radix_offs_kernel(uint32_t *__restrict__
 // beyond the capacity are dropped and the flag is raised (skewed keys: the caller repeats the pass with offsets from a
 // histogram).  For hashed keys a cell holds chunk_rows / 1024 rows on average with a standard deviation of its square
 // root, so a capacity eight deviations above the mean practically never overflows.
-template <bool FAST, bool CELLS>
+template <int FAST, bool CELLS>
 __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64_t n, int64_t chunk_rows,
                                                              const uint32_t *__restrict__ offs,
                                                              ulonglong2 *__restrict__ out, uint32_t cell_cap,
@@ -1501,11 +1503,14 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
   }
   {
     ProfScope prof(prof_scatter);
-    if (src.fast)
-      hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+    if (src.fast && src.pay != nullptr)
+      hipLaunchKernelGGL((radix_scatter_kernel<1, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+                         hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
+    else if (src.fast)
+      hipLaunchKernelGGL((radix_scatter_kernel<2, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
                          hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
     else
-      hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
+      hipLaunchKernelGGL((radix_scatter_kernel<0, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
                          hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
     CRGPU_HIP(hipGetLastError());
   }
@@ -1548,11 +1553,14 @@ static crgpu_status radix_partition_cells(RadixTable &t, const RadixSrc &src, in
   }
   {
     ProfScope prof("radix_probe_scatter");
-    if (src.fast)
-      hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
+    if (src.fast && src.pay != nullptr)
+      hipLaunchKernelGGL((radix_scatter_kernel<1, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
+                         t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
+    else if (src.fast)
+      hipLaunchKernelGGL((radix_scatter_kernel<2, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
                          t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
     else
-      hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
+      hipLaunchKernelGGL((radix_scatter_kernel<0, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
                          t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
     hipLaunchKernelGGL(radix_cell_prefix_kernel, dim3(kRadixP1), dim3(512), 0, st, t.p_cell_cnt.as<uint32_t>(),
