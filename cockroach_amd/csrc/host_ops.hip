@@ -577,12 +577,15 @@ extern "C" crgpu_status crgpu_hj_build_finish(crgpu_hj *h) {
   return CRGPU_OK;
 }
 
-static crgpu_status hj_probe_table(crgpu_hj *h, DevTable &t) {
+// async_result: the caller goes on staging, so the result may come back behind an event; a caller that is about to
+// read the result takes the plain copies (an event per result costs ~50 us, which shows with small read-ahead)
+static crgpu_status hj_probe_table(crgpu_hj *h, DevTable &t, bool async_result) {
   crgpu_dev_result r;
   CRGPU_TRY(crgpu_dev_join_probe(h->dev, t.cols.data(), t.n, &r));
   if (r.n > 0) {
     std::unique_ptr<HostResult> hr(new HostResult());
-    CRGPU_TRY(download_result_async(r, *hr));
+    if (async_result) CRGPU_TRY(download_result_async(r, *hr));
+    else CRGPU_TRY(download_result(r, *hr));
     h->outq.push_back(std::move(hr));
   }
   return CRGPU_OK;
@@ -592,7 +595,7 @@ static crgpu_status hj_probe_table(crgpu_hj *h, DevTable &t) {
 static crgpu_status hj_flush_probe(crgpu_hj *h, bool drain) {
   if (h->deferred) {  // the chunk uploaded by the previous flush: its transfer ran while the next chunk was staged
     h->deferred = false;
-    CRGPU_TRY(hj_probe_table(h, h->probe_cur ? h->probe_dev2 : h->probe_dev));
+    CRGPU_TRY(hj_probe_table(h, h->probe_cur ? h->probe_dev2 : h->probe_dev, !drain));
   }
   if (h->probe_stage.empty() || h->probe_stage[0].n == 0) return CRGPU_OK;
   if (h->build_on_host) {  // the host copy of the build side is only needed for ExportBuffered before probing starts
@@ -603,7 +606,7 @@ static crgpu_status hj_flush_probe(crgpu_hj *h, bool drain) {
   if (!plain_fixed(h->probe_stage)) {
     CRGPU_TRY(upload_table(h->probe_stage, h->probe_dev));
     clear_cols(h->probe_stage);
-    return hj_probe_table(h, h->probe_dev);
+    return hj_probe_table(h, h->probe_dev, false);
   }
   // (the other device table and probe_inflight are free: the chunk that used them has been probed, which waited for
   // its upload)
@@ -615,7 +618,7 @@ static crgpu_status hj_flush_probe(crgpu_hj *h, bool drain) {
   h->deferred = true;
   if (drain) {
     h->deferred = false;
-    CRGPU_TRY(hj_probe_table(h, t));
+    CRGPU_TRY(hj_probe_table(h, t, false));
   }
   return CRGPU_OK;
 }
