@@ -2871,8 +2871,8 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
   CRGPU_HIP(hipMemsetAsync(a->any_tails_dev.p, 0, static_cast<size_t>(spec->n_aggs) * 8, stream()));
   CRGPU_TRY(ensure_groups(a.get(), 1024));
   CRGPU_TRY(reindex(a.get(), 256));  // hashAggregator starts with 256 buckets too (hash_aggregator.go:217)
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
+  static DeviceOnce lds_attr_set;
+  if (lds_attr_set.need()) {
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<true, true, false>),
@@ -2891,7 +2891,7 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_part_accum_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
-    lds_attr_set = true;
+    lds_attr_set.mark();
   }
   *out = a.release();
   return CRGPU_OK;
@@ -3305,11 +3305,11 @@ static crgpu_status launch_partitioned(crgpu_agg *a, const PassInput &in, const 
 // The deduplicated sum-family pass (agg_sumfam_kernel): *done = false when the handle / chunk is outside its form.
 template <int NIN>
 static void launch_sumfam_n(const SfArgs &args, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
+  static DeviceOnce attr_set;  // per instantiation
+  if (attr_set.need()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_sumfam_kernel<NIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(kLdsMax));
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(agg_sumfam_kernel<NIN>, grid, block, lds, st, args);
 }

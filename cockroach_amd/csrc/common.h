@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,20 @@ int current_device();        // the calling thread's library device (-1 before a
 void mark_default_work();    // a handle-less call queued asynchronous work on the default stream: handle calls order themselves after it
 crgpu_status noalloc_setup_device(int device);  // partition.hip: resolves this device's copy of the static scratch array (called by crgpu_init with the device current)
 
+// "Once per device" latch for per-device HIP state set lazily (hipFuncSetAttribute applies to the current device only;
+// one process may drive several GPUs).  Two threads racing through need()/mark() both do the idempotent work.
+struct DeviceOnce {
+  std::atomic<uint32_t> mask{0};
+  bool need() const {
+    const int d = current_device();
+    return d < 0 || d >= 32 || !((mask.load(std::memory_order_acquire) >> d) & 1u);
+  }
+  void mark() {
+    const int d = current_device();
+    if (d >= 0 && d < 32) mask.fetch_or(1u << d, std::memory_order_release);
+  }
+};
+
 static constexpr uint32_t kHandleMagic = 0x43524748u;  // "CRGH"
 // First base of every handle struct (crgpu_join, crgpu_agg, ...): crgpu_cancel() accepts any of them.
 struct Handle {
@@ -49,7 +64,7 @@ struct Handle {
   hipStream_t st = nullptr;
   hipEvent_t ev = nullptr;      // orders st after the work queued so far on the device's default stream
   uint64_t seen_epoch = 0;
-  volatile int32_t cancelled = 0;  // set by crgpu_cancel from any thread; sticky until reset
+  std::atomic<int32_t> cancelled{0};  // set by crgpu_cancel from any thread; sticky until reset
   Handle() = default;
   Handle(const Handle &) = delete;
   Handle &operator=(const Handle &) = delete;
@@ -80,7 +95,7 @@ struct CallScope {
   if (_scope.st != CRGPU_OK) return _scope.st
 #define CRGPU_CHECK_CANCEL(h)                                                                         \
   do {                                                                                                \
-    if ((h)->cancelled) return ::crgpu::fail(CRGPU_ERR_CANCELLED, "operation cancelled (crgpu_cancel)"); \
+    if ((h)->cancelled.load(std::memory_order_relaxed)) return ::crgpu::fail(CRGPU_ERR_CANCELLED, "operation cancelled (crgpu_cancel)"); \
   } while (0)
 
 // Grow-only device buffer; every byte is accounted in crgpu_mem_usage().

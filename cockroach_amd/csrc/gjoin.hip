@@ -297,11 +297,11 @@ extern "C" crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crg
   g->views.resize(spec->n_aggs);
   CRGPU_TRY(g->counter.ensure(8));
   CRGPU_TRY(g->err.ensure(4));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gjoin_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kRadixSlots * 16 + kGjMaxPlanes * kGjSlots * 8));
-    attr_set = true;
+    attr_set.mark();
   }
   *out = g.release();
   return CRGPU_OK;
@@ -339,8 +339,10 @@ extern "C" crgpu_status crgpu_dev_gjoin_build(crgpu_gjoin *g, const crgpu_dcol *
   CRGPU_TRY(gj_src(key, payload, g->build_type, n, &src));
   bool ok = false;
   g->built = false;
-  CRGPU_TRY(radix_build(g->tb, src, n, &ok));
+  CRGPU_TRY(radix_build(g->tb, src, n, &ok, /*check_dup=*/true));
   if (!ok) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_build: build keys are not unique enough for the partitioned tables (compose join -> aggregate)");
+  // every group IS a build row: a key held by two build rows would be counted once where the join emits it twice
+  if (g->tb.has_dup_keys) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_build: duplicate build keys (compose join -> aggregate)");
   g->n_build = n;
   g->built = true;
   return CRGPU_OK;

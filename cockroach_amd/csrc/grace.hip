@@ -164,7 +164,19 @@ static crgpu_status chunk_fetch(crgpu_grace *g, SpillChunk &c) {
 static crgpu_status partition_and_spill(crgpu_grace *g, int input, const crgpu_dcol *cols, int64_t n, int64_t parent_mem) {
   if (n == 0) return CRGPU_OK;
   const int nc = static_cast<int>(g->types[input].size());
-  crgpu_partitioner *&p = g->partitioners[input][g->seed];
+  // one partitioner per input: a repartition bumps the seed, and the handle of the previous seed (chunk-sized
+  // destination / histogram / output buffers) would otherwise stay until the operator is destroyed -- up to 2 x
+  // max_repartitions of them inside the operator whose job is to stay within mem_limit
+  auto &held = g->partitioners[input];
+  for (auto it = held.begin(); it != held.end();) {
+    if (it->first != g->seed) {
+      crgpu_dev_partitioner_destroy(it->second);
+      it = held.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  crgpu_partitioner *&p = held[g->seed];
   if (p == nullptr) {
     CRGPU_TRY(crgpu_dev_partitioner_create(g->types[input].data(), nc, g->hash_cols[input].data(),
                                            static_cast<int32_t>(g->hash_cols[input].size()), g->seed, g->num_buckets, &p));

@@ -740,8 +740,15 @@ static crgpu_status ha_flush(crgpu_ha *h) {
     clear_cols(h->stage);
     return fail(CRGPU_ERR_STATE, "crgpu_agg: the device state was released for export");
   }
-  CRGPU_TRY(upload_table(h->stage, h->staged_dev));
-  const crgpu_status st = crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n);
+  crgpu_status st = upload_table(h->stage, h->staged_dev);
+  if (getenv("CRGPU_TEST_FAIL_AGG_UPLOAD") != nullptr && st == CRGPU_OK) st = fail(CRGPU_ERR_OOM, "crgpu_agg: injected upload failure (CRGPU_TEST_FAIL_AGG_UPLOAD)");
+  if (st != CRGPU_OK) {
+    // With tracking on the rows are in `tracked` already: the stage is cleared, or crgpu_agg_export_buffered would
+    // append them to `tracked` a second time and hand them out twice.  Without tracking the stage keeps them.
+    if (h->track) clear_cols(h->stage);
+    return st;
+  }
+  st = crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n);
   clear_cols(h->stage);  // (tracked rows keep the batch when tracking is on)
   return st;
 }

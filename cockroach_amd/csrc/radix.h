@@ -71,6 +71,7 @@ struct RadixTable {
   DevBuf p_cell_cnt, p_cell_pref;
   uint32_t p_nchunks = 0, p_cell_cap = 0;
   bool cells_failed = false;  // a cell overflowed once (skewed keys): this table's probes use the histogram form
+  bool has_dup_keys = false;  // radix_build(check_dup): two build rows share a key (the table keeps one of them)
 };
 
 // Level 1 only: t.rows_a holds partition p's rows in [starts[p], starts[p] + totals[p]) (uint32 arrays of kRadixP1).
@@ -99,7 +100,9 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
                                         int log2_rows_per_sub, int max_sub_bits);
 // Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows
 // kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
-crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok);
+// check_dup: the table kernels also verify that the build keys are unique and report it in t.has_dup_keys (the join
+// paths do not need it: first writer wins and they want one match; the fused group-join does).
+crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, bool check_dup = false);
 // Probes n rows.  partitioned: radix-partition the probe rows first (large probes);
 // otherwise look every row up directly (three dependent random reads per row).
 // nulls_pass: additionally emit the probe rows whose key is NULL as unmatched

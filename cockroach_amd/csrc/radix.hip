@@ -588,6 +588,10 @@ __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__re
 // sub-partition (<= 2560 rows into 3072 slots; load threshold of 3-way cuckoo is 0.91).
 // A lookup reads at most three slots (1.6 on average for a hit; an EMPTY slot ends a miss early
 // because occupied slots never become empty again).  The 48 KiB image is written out coalesced.
+// CHECK_DUP: after the build every row looks its own key up; a row that finds ANOTHER row of its key first (a dropped
+// or a second entry of a duplicate key) raises bit 8 of `failed` -- the fused group-join needs unique build keys and
+// must not count a probe row once where the join emits it twice.
+template <bool CHECK_DUP>
 __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__restrict__ rows,
                                                           const uint32_t *__restrict__ sub_count,
                                                           ulonglong2 *__restrict__ table,
@@ -606,7 +610,11 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
     if (srow[i].x == kRadixEmpty) {  // the one key equal to the empty marker lives beside the table
       special->val = srow[i].y;
-      special->present = 1;
+      if (CHECK_DUP) {
+        if (atomicExch(&special->present, 1u) != 0u) atomicOr(failed, 8u);
+      } else {
+        special->present = 1;
+      }
       continue;
     }
     uint32_t cur = i, from = kNone, rnd = (i + 1u) * 2654435761u + static_cast<uint32_t>(q);
@@ -636,6 +644,25 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
     if (iter == 4096) atomicOr(failed, 2u);
   }
   __syncthreads();
+  if (CHECK_DUP) {
+    bool dup = false;
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+      const unsigned long long k = srow[i].x;
+      if (k == kRadixEmpty) continue;
+      uint32_t s[3];
+      rslots(fmix64(k), s);
+      bool found = false;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const uint32_t id = tab[s[c]];
+        if (!found && id != kNone && srow[id].x == k) {
+          found = true;
+          dup = dup || id != i;
+        }
+      }
+    }
+    if (dup) atomicOr(failed, 8u);
+  }
   ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
   for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) {
     const uint32_t id = tab[i];
@@ -734,6 +761,7 @@ __device__ __forceinline__ uint32_t chd_place(uint32_t *tab, const unsigned long
 }
 
 static constexpr int kChdMaxBucket = 31;  // keys one bucket may hold (Poisson(2.5) over 2^26 buckets stays far below)
+template <bool CHECK_DUP>
 __global__ __launch_bounds__(512) void radix_chd_table_kernel(const ulonglong2 *__restrict__ rows,
                                                               const uint32_t *__restrict__ sub_count,
                                                               ulonglong2 *__restrict__ table, uint8_t *__restrict__ disp,
@@ -763,7 +791,11 @@ __global__ __launch_bounds__(512) void radix_chd_table_kernel(const ulonglong2 *
     const unsigned long long k = skey[i];
     if (k == kRadixEmpty) {  // the one key equal to the empty marker lives beside the table
       special->val = rows[base + i].y;
-      special->present = 1;
+      if (CHECK_DUP) {
+        if (atomicExch(&special->present, 1u) != 0u) atomicOr(failed, 8u);
+      } else {
+        special->present = 1;
+      }
       rnk[i] = 0xFFFF;
       continue;
     }
@@ -872,6 +904,16 @@ __global__ __launch_bounds__(512) void radix_chd_table_kernel(const ulonglong2 *
       }
     }
     __syncthreads();
+  }
+  if (CHECK_DUP) {  // every row must own the slot its key leads to
+    bool dup = false;
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+      if (rnk[i] == 0xFFFF) continue;
+      uint32_t bk, a, b;
+      chd_words(fmix64(skey[i]), bk, a, b);
+      dup = dup || tab[chd_slot(a, b, sdisp[bk])] != i;
+    }
+    if (dup) atomicOr(failed, 8u);
   }
   ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
   for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) {
@@ -1676,9 +1718,10 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
   return CRGPU_OK;
 }
 
-crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok) {
+crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, bool check_dup) {
   hipStream_t st = stream();
   *ok = false;
+  t.has_dup_keys = false;
   bool split_ok = false;
   CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap, 11, kRadixMaxSubBits));
   if (!split_ok) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
@@ -1698,13 +1741,20 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
     CRGPU_TRY(t.disp.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixBuckets));
     {
       ProfScope prof("radix_build_table");
-      hipLaunchKernelGGL(radix_chd_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
-                         t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.disp.as<uint8_t>(),
-                         t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+      if (check_dup)
+        hipLaunchKernelGGL(radix_chd_table_kernel<true>, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                           t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.disp.as<uint8_t>(),
+                           t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+      else
+        hipLaunchKernelGGL(radix_chd_table_kernel<false>, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                           t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.disp.as<uint8_t>(),
+                           t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
       CRGPU_HIP(hipGetLastError());
     }
     CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
+    if ((overflow & 8u) && !(overflow & ~8u)) t.has_dup_keys = true;
+    overflow &= ~8u;
     if (!overflow) {
       t.chd = true;
       t.ready = true;
@@ -1718,13 +1768,20 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   }
   {
     ProfScope prof("radix_build_table");
-    hipLaunchKernelGGL(radix_table_kernel, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
-                       t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(),
-                       t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+    if (check_dup)
+      hipLaunchKernelGGL(radix_table_kernel<true>, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                         t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(),
+                         t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
+    else
+      hipLaunchKernelGGL(radix_table_kernel<false>, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                         t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(),
+                         t.special.as<RadixSpecial>(), t.flag.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
   }
   CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
+  t.has_dup_keys = (overflow & 8u) != 0;
+  overflow &= ~8u;
   if (overflow) return CRGPU_OK;  // a cuckoo insertion did not terminate (an unlucky hash): classic table
   t.ready = true;
   *ok = true;
@@ -1742,11 +1799,11 @@ static crgpu_status launch_probe_jt(const RadixProbeArgs &a, int grid) {
   if (a.disp != nullptr) {  // perfect-hash tables; MODE 0 stages the partition's displacement bytes in dynamic LDS
     const size_t lds = MODE == 0 ? static_cast<size_t>(a.smask + 1) * kRadixBuckets : 0;
     if (lds > 48 * 1024) {
-      static bool attr_set = false;  // per instantiation
-      if (!attr_set) {
+      static DeviceOnce attr_set;  // per instantiation
+      if (attr_set.need()) {
         CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_probe_kernel<JT, MODE, TB, RPT, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kRadixBuckets));
-        attr_set = true;
+        attr_set.mark();
       }
     }
     hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, true>), dim3(grid), dim3(TB), lds, st, a);
@@ -1841,11 +1898,11 @@ crgpu_status radix_build_dup(RadixTable &t, const RadixSrc &src, int64_t n, bool
   CRGPU_TRY(t.pay_sorted.ensure(static_cast<size_t>(kRadixP1) * nsub * kRadixSubCap * 8));
   CRGPU_TRY(t.special.ensure(sizeof(RadixSpecial)));
   CRGPU_HIP(hipMemsetAsync(t.special.p, 0, sizeof(RadixSpecial), st));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(kGroupLds)));
-    attr_set = true;
+    attr_set.mark();
   }
   uint32_t overflow = 0;
   {

@@ -338,6 +338,35 @@ def test_hash_aggregator_export_buffered(oracle):
     ha.close()
 
 
+def test_hash_aggregator_export_after_failed_upload(monkeypatch):
+    """The OOM protocol when the UPLOAD of a staged chunk fails (the case input tracking exists for): the flush has
+    moved the staged rows to the tracked input before the device call, so ExportBuffered must hand out every input row
+    exactly once (round-2 advisor finding: the stage stayed filled and was appended a second time)."""
+    import ctypes as C
+    from cockroach_amd import _lib
+    rng = np.random.default_rng(23)
+    n = 5_000
+    g = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 50, n, dtype=np.int64))
+    x = cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(n))
+    cols, types = [g, x], [cd.INT64, cd.FLOAT64]
+    aggs = [(0, 0, -1), (10, 1, -1)]
+    batches = make_batches(cols, 512, False, rng)
+    ha = ops.HashAggregator(types, [0], aggs, ops.BatchSource(batches, types), capacity=512, track_input=True)
+    ha.init()
+    for b in batches:
+        mb, _keep = ops._marshal_batch(b)
+        _lib.check(ha.lib.crgpu_agg_append(ha.h, C.byref(mb)))
+    monkeypatch.setenv("CRGPU_TEST_FAIL_AGG_UPLOAD", "1")
+    with pytest.raises(_lib.CrgpuError) as e:
+        _lib.check(ha.lib.crgpu_agg_finish(ha.h))
+    assert e.value.code == _lib.ERR_OOM
+    monkeypatch.delenv("CRGPU_TEST_FAIL_AGG_UPLOAD")
+    ha.release_before_export()
+    assert _export_all(ha) == H.vecs_to_tuples(cols)
+    ha.release_after_export()
+    ha.close()
+
+
 def test_unordered_distinct_export_buffered(oracle):
     """unordered_distinct.go:123-134: ExportBuffered hands out the new tuples of the input read so far that Next has
     not returned yet; the table of seen tuples stays, so a later batch is still filtered against them."""

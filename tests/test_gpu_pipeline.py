@@ -110,3 +110,28 @@ def test_fused_group_join_int_payload_overflow_and_unsupported(oracle):
         gj.build(dev.upload(cd.Vec.from_numpy(cd.INT64, np.zeros(100_000, dtype=np.int64))))
     assert e.value.code == _lib.ERR_UNSUPPORTED
     gj.close()
+
+
+@pytest.mark.parametrize("table", ["cuckoo", "chd"])
+def test_fused_group_join_rejects_a_few_duplicate_build_keys(monkeypatch, table):
+    """The fused form needs UNIQUE build keys (every group is a build row).  A handful of duplicated keys -- far from
+    overflowing a sub-partition -- used to build silently (first writer wins in the tables) and count each probe row
+    once where the join emits it twice; now the table kernels verify uniqueness and the build says UNSUPPORTED so the
+    caller composes join -> aggregate.  Also the key equal to the tables' empty marker, held twice."""
+    from cockroach_amd import _lib
+    from cockroach_amd import device as dev
+    if table == "chd":
+        monkeypatch.setenv("CRGPU_RADIX_TABLE", "chd")
+    rng = np.random.default_rng(11)
+    nb = 200_000
+    keys = rng.permutation(nb * 2)[:nb].astype(np.int64)
+    for dup_keys in (keys[[5, 77, 1234]], np.array([-1, -1], dtype=np.int64), keys[:nb // 2]):
+        k = np.concatenate([keys, dup_keys])
+        gj = dev.GroupJoin([(F["COUNT_ROWS"], 0)])
+        with pytest.raises(_lib.CrgpuError) as e:
+            gj.build(dev.upload(cd.Vec.from_numpy(cd.INT64, k[rng.permutation(len(k))])))
+        assert e.value.code == _lib.ERR_UNSUPPORTED and "duplicate" in str(e.value)
+        gj.close()
+    gj = dev.GroupJoin([(F["COUNT_ROWS"], 0)])  # the same keys once: builds
+    gj.build(dev.upload(cd.Vec.from_numpy(cd.INT64, np.concatenate([keys, np.array([-1], dtype=np.int64)]))))
+    gj.close()
