@@ -51,6 +51,10 @@ def parse(argv=None):
                     help="run the N > 1 code path (hash repartition -> crgpu_exchange over RCCL -> local join, then the "
                          "two-stage GROUP BY) even with one rank: a self-exchange through RCCL")
     ap.add_argument("--log2-groupby", type=int, default=26, help="rows per GPU of the distributed GROUP BY leg (N > 1)")
+    ap.add_argument("--no-q9", action="store_true", help="skip the distributed TPC-H Q9 leg of an N > 1 run")
+    ap.add_argument("--q9-sf", type=float, default=0.0,
+                    help="scale factor of the distributed TPC-H Q9 leg (BASELINE.json configs[3]); 0: SF100 on N > 1 GPUs, "
+                         "SF10 for --force-distributed with one rank")
     ap.add_argument("--variant", default="hit100", choices=["hit100", "hit50", "zipf", "null1"],
                     help="probe-key variants of config J (SURVEY.md 8(d)): 100%% hit (the headline), 50%% hit, "
                          "Zipf-like skew (theta=1), 1%% NULL probe keys")
@@ -246,7 +250,7 @@ def main(argv=None):
         part_b = dev.Partitioner([I64, I64], [0], world)
         part_p = dev.Partitioner([I64, I64], [0], world)
         # one exchange handle per join input: a result is owned by its handle until that handle's next call
-        xch_b, xch_p = xch, dev.Exchange(_second_id(torch, dist, dev, world, rank, device), world, rank)
+        xch_b, xch_p = xch, xch.clone()  # the same communicator, own stream and result buffers (crgpu_exchange_clone)
 
     def exchange(part, x, cols_t, n):
         """hash-repartition (crgpu_dev_partition) + RCCL all-to-all (crgpu_exchange_all_to_all); device columns."""
@@ -291,22 +295,32 @@ def main(argv=None):
     # result check outside the timed region (size-independent property: sum(v) == sum(3k+1) over probe keys)
     w_out = _wrap(torch, res.cols[0].data, out_rows, device)
     v_out = _wrap(torch, res.cols[1].data, out_rows, device)
-    ok = True
-    if world == 1:
-        hit = pk < nb  # build keys are a permutation of [0, nb) (a self-exchange only reorders the rows)
-        if args.variant == "null1":
-            hit = hit & ~isnull
-        ok = out_rows == int(hit.sum().item()) and int(v_out.sum().item()) == int(((pk * 3 + 1) * hit).sum().item()) \
-            and int(w_out.sum().item()) == int((pw * hit).sum().item())
+    # The union of all ranks' build keys is a permutation of [0, nb * world) (rank r holds k * world + r), so a probe row
+    # hits iff its key is below nb * world (and not NULL): what THIS rank's probe rows must contribute to the output of
+    # the whole job -- rows, sum(v) = sum(3k + 1), sum(w) -- is known from its inputs, wherever the exchange sent them.
+    hit = pk < nb * world
+    if args.variant == "null1":
+        hit = hit & ~isnull
+    want = torch.stack([hit.sum(), ((pk * 3 + 1) * hit).sum(), (pw * hit).sum()]).to(torch.int64)
+    got = torch.stack([torch.tensor(out_rows, device=device), v_out.sum(), w_out.sum()]).to(torch.int64)  # (int64 sums wrap alike)
+    # every output row must sit on the rank its key routes to: k = (v - 1) / 3, dest = rehash64(1, k) % world
+    misrouted = torch.zeros(1, dtype=torch.int64, device=device)
+    if distributed and out_rows:
+        ns = min(out_rows, 1 << 24)
+        k_out = ((v_out[:ns] - 1) // 3).contiguous()
+        dest = torch.empty(ns, dtype=torch.int64, device=device)
+        torch.cuda.synchronize()
+        _lib.check(_lib.load().crgpu_dev_hash_cols(dev.dcol_array([dev.from_torch(I64, k_out)]), 1, ns, 1, 64, world, dest.data_ptr()))
+        _lib.check(_lib.load().crgpu_dev_synchronize())
+        misrouted = (dest != rank).sum().reshape(1)
     if world > 1:
-        t = torch.tensor([dt, float(out_rows), float(ok)], device=device, dtype=torch.float64)
-        tmax = t.clone()
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0].item())
-        total_out = int(tsum[1].item())
-        ok = total_out == npr * world
+        both = torch.cat([want, got, misrouted])
+        dist.all_reduce(both, op=dist.ReduceOp.SUM)
+        want, got, misrouted = both[:3], both[3:6], both[6:]
+    ok = bool((want == got).all().item()) and int(misrouted.item()) == 0
     # per-kernel HIP-event times recorded on the library stream (crgpu_prof_*); algorithmic bytes per row
     # of each kernel's own input/output
     kern_rows = {"join_build": (nb, 16.0), "join_probe": (npr, 32.0),
@@ -359,14 +373,26 @@ def main(argv=None):
     join.close()
     if distributed:
         gb = distributed_group_by(args, torch, dist, dev, cd, _lib, xch_b, world, rank, device)
+        for h in (part_b, part_p, xch_p):
+            h.close()
+        part_b = part_p = xch_p = None
+        del bk, bv, pk, pw, res, _b, _p, w_out, v_out, hit
+        torch.cuda.empty_cache()
+        _lib.load().crgpu_mem_trim()
+        q9 = None
+        if not args.no_q9:
+            q9 = distributed_q9(args, torch, dist, dev, _lib, xch_b, world, rank, device)
         if rank == 0:
             line["group_by"] = gb
+            if q9 is not None:
+                line["tpch_q9"] = q9
+                ok = ok and q9["result_check"] == "ok"
     if rank == 0:
         if world == 1 and not args.no_other_paths and not args.force_distributed:
             # the other rows of the hot path, measured in the same run (not part of `value`): DESIGN.md 4.3 / 4.4
             line["other_paths"] = other_paths(local_rank)
         print(json.dumps(line), flush=True)
-    for h in (part_b, part_p, xch_b, xch_p):
+    for h in (part_b, part_p, xch_p, xch_b):
         if h is not None:
             h.close()
     if world > 1:
@@ -375,15 +401,6 @@ def main(argv=None):
     if not ok:
         sys.exit(3)
     return line if rank == 0 else None
-
-
-def _second_id(torch, dist, dev, world, rank, device):
-    uid = torch.zeros(dev.Exchange.ID_BYTES, dtype=torch.uint8, device=device)
-    if rank == 0:
-        uid = torch.tensor(list(dev.Exchange.unique_id()), dtype=torch.uint8, device=device)
-    if world > 1:
-        dist.broadcast(uid, 0)
-    return bytes(uid.cpu().tolist())
 
 
 def distributed_group_by(args, torch, dist, dev, cd, _lib, xch, world, rank, device):
@@ -447,6 +464,78 @@ def distributed_group_by(args, torch, dist, dev, cd, _lib, xch, world, rank, dev
     part.close()
     return {"case": f"two-stage GROUP BY: 2^{args.log2_groupby} rows (k int64, x int64) per GPU, each key 4x, SUM_INT + COUNT_ROWS",
             "rows_per_s": n * world / dt, "ms": dt * 1e3, "groups": int(tot[0].item()), "result_check": "ok" if ok else "MISMATCH"}
+
+
+def distributed_q9(args, torch, dist, dev, _lib, xch, world, rank, device):
+    """BASELINE.json configs[3]: TPC-H Q9 at SF100 over N GPUs (workloads/tpch_dist.py): every rank holds a contiguous
+    shard of every table; the filtered part, supplier and nation are mirrored (crgpu_exchange_broadcast), partsupp x
+    green, lineitem (semi-reduced by the green parts), the join result and orders are routed BY_HASH
+    (crgpu_dev_partition + crgpu_exchange_all_to_all), the GROUP BY runs in two stages.  Every rank generates the same
+    synthetic tables from one seed and keeps its shard.  The union of the ranks' groups is checked against the
+    independent dense evaluation of tests/tpch_check.py (175 groups, tpch.go:318-336)."""
+    import time
+    from tests import tpch_check as K
+    from workloads import tpch_dist as Q, tpch_plans as P, tpch_synth as T
+    sf = args.q9_sf or (100.0 if world > 1 else 10.0)
+    t, rows = T.generate(sf, device, 42)
+    torch.cuda.synchronize()
+    nat, year, profit = K.q9_expected(t, rows["_aux"])
+    want = sorted(zip([T.NATIONS[i] for i in nat.tolist()], [float(y) for y in year.tolist()], profit.tolist()))
+    shard = Q.shard_tables(t, rank, world)
+    if world > 1:  # keep the shard only
+        shard = {name: {k: (T.BytesCol(v.data.clone(), v.offsets.clone()) if isinstance(v, T.BytesCol) else v.clone())
+                        for k, v in cols.items()} for name, cols in shard.items()}
+    del t, nat, year, profit
+    rows.pop("_aux")
+    torch.cuda.empty_cache()
+    fabric = Q.RcclFabric(xch)
+
+    def once():
+        ex = P.GpuExec()
+        res = Q.run(Q.q9_dist(ex, {k: ex.table(v) for k, v in shard.items()}), fabric)
+        out = list(zip(*[v.to_values() for v in ex.to_host(res)])) if res[0].n else []
+        ex.close()
+        fabric.close()
+        return out
+
+    mine = once()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    reps = 3
+    dev.prof_reset()
+    dev.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / reps
+    dev.prof_enable(False)
+    kern = {}
+    for f in ("exchange", "partition", "join_probe", "join_build", "agg", "expr_select", "expr_project", "deselect",
+              "radix_build_scatter", "radix_build_split", "radix_build_table", "radix_probe_scatter"):
+        ms, cnt = dev.prof_get(f)
+        if cnt:
+            kern[f] = round(ms / reps, 3)
+    everyone = [mine]
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[0].item())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    keys = [set(r[:2] for r in part) for part in everyone]
+    disjoint = sum(len(k) for k in keys) == len(set().union(*keys))
+    got = sorted(sum(everyone, []))
+    ok = disjoint and len(got) == len(want) and all(
+        g[:2] == w[:2] and abs(g[2] - w[2]) <= 1e-9 * abs(w[2]) + 1e-6 for g, w in zip(got, want))
+    in_rows = sum(rows[k] for k in Q.q9_scanned_tables())
+    return {"case": f"TPC-H Q9 at SF{sf:g}, synthetic tables sharded over {world} GPU(s): mirrored part(green)/supplier/nation, "
+                    "BY_HASH exchange of partsupp x green, lineitem (semi-reduced), the join result and orders, two-stage GROUP BY",
+            "rows": in_rows, "ms": dt * 1e3, "rows_per_s": in_rows / dt, "groups": len(got), "groups_per_rank": [len(p) for p in everyone],
+            "kernels_ms_rank0": kern, "result_check": "ok" if ok else "MISMATCH"}
 
 
 def other_paths(device_index):

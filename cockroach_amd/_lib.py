@@ -137,6 +137,8 @@ SYMBOLS = [
     ("crgpu_exchange_unique_id", _I32, [_VP]),
     ("crgpu_exchange_create", _I32, [_VP, _I32, _I32, C.POINTER(_VP)]),
     ("crgpu_exchange_all_to_all", _I32, [_VP, C.POINTER(DCol), _I32, C.POINTER(_I64), C.POINTER(DevResult), C.POINTER(_I64)]),
+    ("crgpu_exchange_clone", _I32, [_VP, C.POINTER(_VP)]),
+    ("crgpu_exchange_broadcast", _I32, [_VP, C.POINTER(DCol), _I32, _I64, C.POINTER(DevResult), C.POINTER(_I64)]),
     ("crgpu_exchange_destroy", None, [_VP]),
     ("crgpu_dev_partition_noalloc", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(DCol), _I64,
                                            C.POINTER(_VP), _VP]),

@@ -12,8 +12,11 @@
 // already holds, e.g. PyTorch's, else ROCm's).
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <string>
 
 #include <rccl/rccl.h>
 
@@ -93,12 +96,20 @@ static inline int xgrid(int64_t n) {
 
 using namespace crgpu;
 
-struct crgpu_exchange : crgpu::Handle {
+// The communicator of a group of exchange handles (crgpu_exchange_create + its crgpu_exchange_clone s): destroyed with
+// the last of them.
+struct CommBox {
   ncclComm_t comm = nullptr;
+  ~CommBox();
+};
+
+struct crgpu_exchange : crgpu::Handle {
+  std::shared_ptr<CommBox> box;
+  ncclComm_t comm = nullptr;  // == box->comm
   int world = 1, rank = 0;
-  DevBuf counts_dev, all_counts_dev, tmp_a, tmp_b, offs64, scratch;
+  DevBuf counts_dev, all_counts_dev, offs64, scratch;
   std::vector<OutCol> out;
-  std::vector<DevBuf> valid_bytes;
+  std::vector<DevBuf> valid_bytes, valid_send, lens_send, lens_recv;  // per column: all columns of a call are in flight together
   std::vector<crgpu_dcol> views;
 };
 
@@ -128,23 +139,54 @@ extern "C" crgpu_status crgpu_exchange_create(const uint8_t *id, int32_t world, 
   x->rank = rank;
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof(uid));
-  ncclResult_t r = g_rccl.CommInitRank(&x->comm, world, uid, rank);  // collective: every rank of the node calls it
+  x->box = std::make_shared<CommBox>();
+  ncclResult_t r = g_rccl.CommInitRank(&x->box->comm, world, uid, rank);  // collective: every rank of the node calls it
   if (r != ncclSuccess) {
     delete x;
     return nccl_fail(r, "ncclCommInitRank");
   }
+  x->comm = x->box->comm;
   *out = x;
+  return CRGPU_OK;
+}
+
+CommBox::~CommBox() {
+  if (comm != nullptr && g_rccl.CommDestroy != nullptr) (void)g_rccl.CommDestroy(comm);
+}
+
+extern "C" crgpu_status crgpu_exchange_clone(crgpu_exchange *x, crgpu_exchange **out) {
+  if (x == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_clone: null argument");
+  CRGPU_ENTER(x);
+  auto y = new crgpu_exchange();
+  crgpu_status os = y->open();
+  if (os != CRGPU_OK) {
+    delete y;
+    return os;
+  }
+  y->world = x->world;
+  y->rank = x->rank;
+  y->box = x->box;
+  y->comm = x->comm;
+  *out = y;
   return CRGPU_OK;
 }
 
 extern "C" void crgpu_exchange_destroy(crgpu_exchange *x) {
   if (x == nullptr) return;
   if (x->st != nullptr) (void)hipStreamSynchronize(x->st);
-  if (x->comm != nullptr && g_rccl.CommDestroy != nullptr) (void)g_rccl.CommDestroy(x->comm);
-  delete x;
+  delete x;  // the communicator goes with the last handle that shares it
 }
 
-// one grouped all-to-all-v of `elem` byte wide items: region p of `src` (scnt[p] items at soff[p]) goes to rank p
+// Self-regions (source rank == destination rank) are device-to-device copies on the handle's stream; with
+// CRGPU_EXCHANGE_SELF=rccl they travel through ncclSend / ncclRecv like every other region (what the one-GPU tests use to
+// drive RCCL: with world size 1 every region is a self-region).
+static bool self_through_rccl() {
+  const char *e = std::getenv("CRGPU_EXCHANGE_SELF");
+  return e != nullptr && e[0] == 'r';
+}
+
+// one grouped all-to-all-v of `elem` byte wide items: scnt[p] items at soff[p] of `src` go to rank p, rcnt[p] items from
+// rank p land at roff[p] of `dst`
 static crgpu_status a2a_bytes(crgpu_exchange *x, const uint8_t *src, const std::vector<int64_t> &soff, const std::vector<int64_t> &scnt,
                               uint8_t *dst, const std::vector<int64_t> &roff, const std::vector<int64_t> &rcnt, size_t elem) {
   hipStream_t st = stream();
@@ -154,8 +196,16 @@ static crgpu_status a2a_bytes(crgpu_exchange *x, const uint8_t *src, const std::
   const size_t unit = (elem == 8 || elem == 4) ? elem : 1;
   const int64_t per_item = static_cast<int64_t>(elem / unit);
   constexpr int64_t kPiece = int64_t(1) << 25;
+  const bool self_rccl = self_through_rccl();
+  if (!self_rccl && scnt[x->rank] > 0) {
+    if (scnt[x->rank] != rcnt[x->rank]) return fail(CRGPU_ERR_STATE, "crgpu_exchange: self-region counts disagree");
+    CRGPU_HIP(hipMemcpyAsync(dst + roff[x->rank] * elem, src + soff[x->rank] * elem, static_cast<size_t>(scnt[x->rank]) * elem,
+                             hipMemcpyDeviceToDevice, st));
+  }
+  if (x->world == 1 && !self_rccl) return CRGPU_OK;
   CRGPU_NCCL(g_rccl.GroupStart());
   for (int p = 0; p < x->world; p++) {
+    if (p == x->rank && !self_rccl) continue;
     const int64_t sn = scnt[p] * per_item, rn = rcnt[p] * per_item;
     for (int64_t o = 0; o < sn; o += kPiece)
       CRGPU_NCCL(g_rccl.Send(src + (soff[p] * per_item + o) * unit, static_cast<size_t>(sn - o < kPiece ? sn - o : kPiece), dt, p, x->comm, st));
@@ -165,19 +215,21 @@ static crgpu_status a2a_bytes(crgpu_exchange *x, const uint8_t *src, const std::
   CRGPU_NCCL(g_rccl.GroupEnd());
   return CRGPU_OK;
 }
-// what every rank sends to every rank: gathers `mine` (world values) of all ranks; theirs[p] = what rank p sends here
-static crgpu_status swap_counts(crgpu_exchange *x, const std::vector<int64_t> &mine, std::vector<int64_t> &theirs) {
+// every rank's `words` uint64 values, gathered: all[p * words + i] = value i of rank p (one all-gather + one wait)
+static crgpu_status gather_words(crgpu_exchange *x, const std::vector<uint64_t> &mine, std::vector<uint64_t> &all) {
   hipStream_t st = stream();
-  const int W = x->world;
-  CRGPU_TRY(x->counts_dev.ensure(static_cast<size_t>(W) * 8));
-  CRGPU_TRY(x->all_counts_dev.ensure(static_cast<size_t>(W) * W * 8));
-  CRGPU_HIP(hipMemcpyAsync(x->counts_dev.p, mine.data(), static_cast<size_t>(W) * 8, hipMemcpyHostToDevice, st));
-  CRGPU_NCCL(g_rccl.AllGather(x->counts_dev.p, x->all_counts_dev.p, static_cast<size_t>(W) * 8, ncclChar, x->comm, st));
-  std::vector<int64_t> all(static_cast<size_t>(W) * W);
+  const size_t W = static_cast<size_t>(x->world), words = mine.size();
+  all.assign(W * words, 0);
+  if (W == 1) {  // nothing to agree on with nobody
+    all = mine;
+    return CRGPU_OK;
+  }
+  CRGPU_TRY(x->counts_dev.ensure(words * 8));
+  CRGPU_TRY(x->all_counts_dev.ensure(W * words * 8));
+  CRGPU_HIP(hipMemcpyAsync(x->counts_dev.p, mine.data(), words * 8, hipMemcpyHostToDevice, st));
+  CRGPU_NCCL(g_rccl.AllGather(x->counts_dev.p, x->all_counts_dev.p, words * 8, ncclChar, x->comm, st));
   CRGPU_HIP(hipMemcpyAsync(all.data(), x->all_counts_dev.p, all.size() * 8, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
-  theirs.resize(W);
-  for (int p = 0; p < W; p++) theirs[p] = all[static_cast<size_t>(p) * W + x->rank];
   return CRGPU_OK;
 }
 static void prefix(const std::vector<int64_t> &cnt, std::vector<int64_t> &off, int64_t *total) {
@@ -190,85 +242,150 @@ static void prefix(const std::vector<int64_t> &cnt, std::vector<int64_t> &off, i
   *total = t;
 }
 
-extern "C" crgpu_status crgpu_exchange_all_to_all(crgpu_exchange *x, const crgpu_dcol *cols, int32_t n_cols,
-                                                  const int64_t *send_counts, crgpu_dev_result *res, int64_t *recv_counts) {
-  if (x == nullptr || res == nullptr || send_counts == nullptr || recv_counts == nullptr)
-    return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: null argument");
-  CRGPU_ENTER(x);
-  CRGPU_CHECK_CANCEL(x);
-  if (n_cols < 0 || n_cols > kMaxCols || (n_cols > 0 && cols == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: bad columns");
+// The exchange proper.  Region p of this rank's columns = rows [soff[p], soff[p] + scnt[p]) goes to rank p (all-to-all:
+// disjoint regions in rank order; broadcast: every region is the whole input).  Three collectives carry control
+// information so that all ranks take every decision together -- a rank that returned early would leave its peers blocked
+// inside a grouped send/recv:
+//   1. one all-gather of {row counts per destination, payload bytes per destination of every BYTES column, a bit per
+//      column "this rank holds a validity bitmap"}: receive counts, the agreed nullability of every column (the OR: a
+//      rank without a bitmap sends all-ones validity) and the size limits (every rank computes EVERY rank's totals from
+//      the gathered matrix and fails identically);
+//   2. after all buffers are allocated, one all-gather of a status word: a rank-local allocation failure aborts the
+//      exchange on every rank;
+//   3. the data: per column one grouped {ncclSend, ncclRecv} x (world - 1) + a device copy of the self-region.
+static crgpu_status exchange_impl(crgpu_exchange *x, const char *who, const crgpu_dcol *cols, int32_t n_cols, int64_t n,
+                                  const std::vector<int64_t> &soff, const std::vector<int64_t> &scnt, crgpu_dev_result *res,
+                                  int64_t *recv_counts) {
   const int W = x->world;
   hipStream_t st = stream();
-  std::vector<int64_t> scnt(send_counts, send_counts + W), rcnt, soff, roff;
-  int64_t n = 0, m = 0;
-  for (int p = 0; p < W; p++)
-    if (scnt[p] < 0) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: negative count");
-  prefix(scnt, soff, &n);
-  if (n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_exchange_all_to_all: at most 2^31 rows per call");
   for (int c = 0; c < n_cols; c++) {
-    if (!valid_type(cols[c].type)) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_exchange_all_to_all: unsupported column type");
-    if (n > 0 && cols[c].type == CRGPU_BYTES && cols[c].offsets == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: BYTES column without offsets");
-    if (n > 0 && cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: null data pointer");
+    if (!valid_type(cols[c].type)) return fail(CRGPU_ERR_UNSUPPORTED, std::string(who) + ": unsupported column type");
+    if (n > 0 && cols[c].type == CRGPU_BYTES && cols[c].offsets == nullptr) return fail(CRGPU_ERR_INVALID, std::string(who) + ": BYTES column without offsets");
+    if (n > 0 && cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, std::string(who) + ": null data pointer");
   }
-  CRGPU_TRY(swap_counts(x, scnt, rcnt));
+  std::vector<int> bcols;  // the BYTES columns
+  for (int c = 0; c < n_cols; c++)
+    if (cols[c].type == CRGPU_BYTES) bcols.push_back(c);
+  const size_t nb = bcols.size();
+  // ---- 1. what this rank sends
+  const size_t words = static_cast<size_t>(W) * (1 + nb) + 1;
+  std::vector<uint64_t> mine(words, 0), all;
+  for (int p = 0; p < W; p++) mine[p] = static_cast<uint64_t>(scnt[p]);
+  std::vector<std::vector<int64_t>> bso(nb, std::vector<int64_t>(W, 0)), bs(nb, std::vector<int64_t>(W, 0));
+  if (n > 0 && nb > 0) {  // payload offsets at the region boundaries
+    std::vector<uint32_t> bounds(nb * 2 * W, 0);
+    for (size_t k = 0; k < nb; k++)
+      for (int p = 0; p < W; p++) {
+        CRGPU_HIP(hipMemcpyAsync(&bounds[(k * W + p) * 2], cols[bcols[k]].offsets + soff[p], 4, hipMemcpyDeviceToHost, st));
+        CRGPU_HIP(hipMemcpyAsync(&bounds[(k * W + p) * 2 + 1], cols[bcols[k]].offsets + soff[p] + scnt[p], 4, hipMemcpyDeviceToHost, st));
+      }
+    CRGPU_HIP(hipStreamSynchronize(st));
+    for (size_t k = 0; k < nb; k++)
+      for (int p = 0; p < W; p++) {
+        bso[k][p] = bounds[(k * W + p) * 2];
+        bs[k][p] = static_cast<int64_t>(bounds[(k * W + p) * 2 + 1]) - bounds[(k * W + p) * 2];
+        mine[static_cast<size_t>(W) * (1 + k) + p] = static_cast<uint64_t>(bs[k][p]);
+      }
+  }
+  uint64_t mask = 0;
+  for (int c = 0; c < n_cols; c++)
+    if (cols[c].valid != nullptr) mask |= 1ull << c;
+  mine[words - 1] = mask;
+  CRGPU_TRY(gather_words(x, mine, all));
+  // ---- what arrives, on this rank and on every other one
+  std::vector<int64_t> rcnt(W), roff;
+  std::vector<std::vector<int64_t>> br(nb, std::vector<int64_t>(W, 0)), bro(nb);
+  uint64_t any_mask = 0;
+  bool rows_over = false, bytes_over = false;
+  for (int p = 0; p < W; p++) any_mask |= all[static_cast<size_t>(p) * words + words - 1];
+  for (int r = 0; r < W; r++) {  // totals arriving at rank r
+    int64_t rows = 0;
+    for (int p = 0; p < W; p++) rows += static_cast<int64_t>(all[static_cast<size_t>(p) * words + r]);
+    rows_over = rows_over || rows > 0x7FFFFFF0ll;
+    for (size_t k = 0; k < nb; k++) {
+      int64_t bytes = 0;
+      for (int p = 0; p < W; p++) bytes += static_cast<int64_t>(all[static_cast<size_t>(p) * words + static_cast<size_t>(W) * (1 + k) + r]);
+      bytes_over = bytes_over || bytes > 0xFFFFFFF0ll;
+    }
+  }
+  if (rows_over) return fail(CRGPU_ERR_UNSUPPORTED, std::string(who) + ": more than 2^31 rows arrive at a rank; exchange in smaller pieces");
+  if (bytes_over) return fail(CRGPU_ERR_UNSUPPORTED, std::string(who) + ": a BYTES column exceeds 4 GiB on a rank after the exchange");
+  for (int p = 0; p < W; p++) {
+    rcnt[p] = static_cast<int64_t>(all[static_cast<size_t>(p) * words + x->rank]);
+    for (size_t k = 0; k < nb; k++) br[k][p] = static_cast<int64_t>(all[static_cast<size_t>(p) * words + static_cast<size_t>(W) * (1 + k) + x->rank]);
+  }
+  int64_t m = 0;
   prefix(rcnt, roff, &m);
-  if (m > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_exchange_all_to_all: more than 2^31 rows arrive; exchange in smaller pieces");
   for (int p = 0; p < W; p++) recv_counts[p] = rcnt[p];
   if (static_cast<int>(x->out.size()) != n_cols) {
     x->out = std::vector<OutCol>(n_cols);
     x->valid_bytes = std::vector<DevBuf>(n_cols);
+    x->valid_send = std::vector<DevBuf>(n_cols);
+    x->lens_send = std::vector<DevBuf>(n_cols);
+    x->lens_recv = std::vector<DevBuf>(n_cols);
     x->views.resize(n_cols);
   }
-  ProfScope prof("exchange");
-  for (int c = 0; c < n_cols; c++) {
-    const crgpu_dcol &col = cols[c];
+  // ---- 2. every buffer of the data phase, then the agreement that all ranks have theirs
+  std::vector<int64_t> btotal(nb, 0);
+  crgpu_status local = CRGPU_OK;
+  auto need = [&](DevBuf &b, size_t bytes) {
+    if (local == CRGPU_OK) local = b.ensure(bytes > 0 ? bytes : 1);
+  };
+  for (int c = 0, k = 0; c < n_cols; c++) {
     OutCol &o = x->out[c];
-    o.type = col.type;
-    // validity: every rank must agree on whether the column carries a bitmap (the plan's nullability), so it is exchanged
-    // whenever THIS rank has one and assumed absent otherwise -- callers pass a bitmap on every rank or on none
-    o.nullable = col.valid != nullptr;
-    if (col.type == CRGPU_BYTES) {
-      // lengths travel as a uint32 column; the payload as bytes with its own per-destination byte counts
-      CRGPU_TRY(x->tmp_a.ensure(static_cast<size_t>(n > 0 ? n : 1) * 4));
-      if (n > 0) hipLaunchKernelGGL(offsets_to_lens_kernel, dim3(xgrid(n)), dim3(256), 0, st, col.offsets, n, x->tmp_a.as<uint32_t>());
-      CRGPU_TRY(x->tmp_b.ensure(static_cast<size_t>(m > 0 ? m : 1) * 4));
-      CRGPU_TRY(a2a_bytes(x, x->tmp_a.as<uint8_t>(), soff, scnt, x->tmp_b.as<uint8_t>(), roff, rcnt, 4));
-      std::vector<uint32_t> bounds(W + 1, 0);  // payload offsets at the region boundaries
-      if (n > 0) {
-        for (int p = 0; p <= W; p++) {
-          const int64_t row = p < W ? soff[p] : n;
-          CRGPU_HIP(hipMemcpyAsync(&bounds[p], col.offsets + row, 4, hipMemcpyDeviceToHost, st));
-        }
-        CRGPU_HIP(hipStreamSynchronize(st));
-      }
-      std::vector<int64_t> bs(W), br, bso(W), bro;
-      for (int p = 0; p < W; p++) {
-        bs[p] = static_cast<int64_t>(bounds[p + 1]) - bounds[p];
-        bso[p] = bounds[p];
-      }
-      CRGPU_TRY(swap_counts(x, bs, br));
-      int64_t btotal = 0;
-      prefix(br, bro, &btotal);
-      if (btotal > 0xFFFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_exchange_all_to_all: a BYTES column exceeds 4 GiB after the exchange");
-      CRGPU_TRY(o.data.ensure(static_cast<size_t>(btotal > 0 ? btotal : 1)));
-      CRGPU_TRY(a2a_bytes(x, static_cast<const uint8_t *>(col.data), bso, bs, o.data.as<uint8_t>(), bro, br, 1));
-      // received lengths -> offsets
-      CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(m + 1) * 4));
-      CRGPU_TRY(x->offs64.ensure(static_cast<size_t>(m + 1) * 8));
-      CRGPU_TRY(exclusive_scan_u32(x->tmp_b.as<uint32_t>(), m, x->offs64.as<uint64_t>(), x->scratch, nullptr));
-      hipLaunchKernelGGL(narrow_u64_kernel, dim3(xgrid(m + 1)), dim3(256), 0, st, x->offs64.as<uint64_t>(), m + 1, o.offsets.as<uint32_t>());
-      CRGPU_HIP(hipGetLastError());
+    o.type = cols[c].type;
+    o.nullable = ((any_mask >> c) & 1ull) != 0;
+    if (o.type == CRGPU_BYTES) {
+      prefix(br[k], bro[k], &btotal[k]);
+      need(x->lens_send[c], static_cast<size_t>(n) * 4);
+      need(x->lens_recv[c], static_cast<size_t>(m) * 4);
+      need(o.data, static_cast<size_t>(btotal[k]));
+      need(o.offsets, static_cast<size_t>(m + 1) * 4);
+      need(x->offs64, static_cast<size_t>(m + 1) * 8);
+      k++;
     } else {
-      const size_t w = static_cast<size_t>(type_width(col.type));
-      CRGPU_TRY(o.data.ensure((static_cast<size_t>(m > 0 ? m : 1)) * w));
-      CRGPU_TRY(a2a_bytes(x, static_cast<const uint8_t *>(col.data), soff, scnt, o.data.as<uint8_t>(), roff, rcnt, w));
+      need(o.data, static_cast<size_t>(m) * type_width(o.type));
     }
     if (o.nullable) {
-      CRGPU_TRY(x->tmp_a.ensure(static_cast<size_t>(n > 0 ? n : 1)));
-      CRGPU_TRY(x->valid_bytes[c].ensure(static_cast<size_t>(m > 0 ? m : 1)));
-      CRGPU_TRY(o.valid.ensure(static_cast<size_t>((m + 7) / 8 + 1)));
-      if (n > 0) hipLaunchKernelGGL(valid_to_bytes_kernel, dim3(xgrid(n)), dim3(256), 0, st, col.valid, n, x->tmp_a.as<uint8_t>());
-      CRGPU_TRY(a2a_bytes(x, x->tmp_a.as<uint8_t>(), soff, scnt, x->valid_bytes[c].as<uint8_t>(), roff, rcnt, 1));
+      need(x->valid_send[c], static_cast<size_t>(n));
+      need(x->valid_bytes[c], static_cast<size_t>(m));
+      need(o.valid, static_cast<size_t>((m + 7) / 8 + 1));
+    }
+  }
+  {
+    std::vector<uint64_t> st_mine(1, static_cast<uint64_t>(local)), st_all;
+    const crgpu_status gs = gather_words(x, st_mine, st_all);
+    if (gs != CRGPU_OK) return gs;
+    if (local != CRGPU_OK) return local;  // (the message of the failing ensure stands)
+    for (int p = 0; p < W; p++)
+      if (st_all[p] != 0) return fail(static_cast<crgpu_status>(st_all[p]), std::string(who) + ": rank " + std::to_string(p) + " could not allocate its buffers; the exchange is abandoned on every rank");
+  }
+  // ---- 3. the data
+  ProfScope prof("exchange");
+  for (int c = 0, k = 0; c < n_cols; c++) {
+    const crgpu_dcol &col = cols[c];
+    OutCol &o = x->out[c];
+    if (col.type == CRGPU_BYTES) {
+      // lengths travel as a uint32 column; the payload as bytes with its own per-destination byte counts
+      if (n > 0) hipLaunchKernelGGL(offsets_to_lens_kernel, dim3(xgrid(n)), dim3(256), 0, st, col.offsets, n, x->lens_send[c].as<uint32_t>());
+      CRGPU_TRY(a2a_bytes(x, x->lens_send[c].as<uint8_t>(), soff, scnt, x->lens_recv[c].as<uint8_t>(), roff, rcnt, 4));
+      CRGPU_TRY(a2a_bytes(x, static_cast<const uint8_t *>(col.data), bso[k], bs[k], o.data.as<uint8_t>(), bro[k], br[k], 1));
+      // received lengths -> offsets
+      CRGPU_TRY(exclusive_scan_u32(x->lens_recv[c].as<uint32_t>(), m, x->offs64.as<uint64_t>(), x->scratch, nullptr));
+      hipLaunchKernelGGL(narrow_u64_kernel, dim3(xgrid(m + 1)), dim3(256), 0, st, x->offs64.as<uint64_t>(), m + 1, o.offsets.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+      k++;
+    } else {
+      CRGPU_TRY(a2a_bytes(x, static_cast<const uint8_t *>(col.data), soff, scnt, o.data.as<uint8_t>(), roff, rcnt, static_cast<size_t>(type_width(col.type))));
+    }
+    if (o.nullable) {
+      // validity travels as one byte per row (bitmaps of adjacent regions share bytes); a rank that holds no bitmap for
+      // a column some other rank has one for sends "present" for all its rows
+      if (n > 0) {
+        if (col.valid != nullptr) hipLaunchKernelGGL(valid_to_bytes_kernel, dim3(xgrid(n)), dim3(256), 0, st, col.valid, n, x->valid_send[c].as<uint8_t>());
+        else CRGPU_HIP(hipMemsetAsync(x->valid_send[c].p, 1, static_cast<size_t>(n), st));
+      }
+      CRGPU_TRY(a2a_bytes(x, x->valid_send[c].as<uint8_t>(), soff, scnt, x->valid_bytes[c].as<uint8_t>(), roff, rcnt, 1));
       CRGPU_TRY(pack_bitmap(x->valid_bytes[c].as<uint8_t>(), m, o.valid.as<uint8_t>()));
     }
     x->views[c] = o.view();
@@ -279,4 +396,33 @@ extern "C" crgpu_status crgpu_exchange_all_to_all(crgpu_exchange *x, const crgpu
   res->_pad = 0;
   res->cols = x->views.data();
   return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_exchange_all_to_all(crgpu_exchange *x, const crgpu_dcol *cols, int32_t n_cols,
+                                                  const int64_t *send_counts, crgpu_dev_result *res, int64_t *recv_counts) {
+  if (x == nullptr || res == nullptr || send_counts == nullptr || recv_counts == nullptr)
+    return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: null argument");
+  CRGPU_ENTER(x);
+  CRGPU_CHECK_CANCEL(x);
+  if (n_cols < 0 || n_cols > kMaxCols || (n_cols > 0 && cols == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: bad columns");
+  const int W = x->world;
+  std::vector<int64_t> scnt(send_counts, send_counts + W), soff;
+  int64_t n = 0;
+  for (int p = 0; p < W; p++)
+    if (scnt[p] < 0) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_all_to_all: negative count");
+  prefix(scnt, soff, &n);
+  if (n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_exchange_all_to_all: at most 2^31 rows per call");
+  return exchange_impl(x, "crgpu_exchange_all_to_all", cols, n_cols, n, soff, scnt, res, recv_counts);
+}
+
+extern "C" crgpu_status crgpu_exchange_broadcast(crgpu_exchange *x, const crgpu_dcol *cols, int32_t n_cols, int64_t n,
+                                                 crgpu_dev_result *res, int64_t *recv_counts) {
+  if (x == nullptr || res == nullptr || recv_counts == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_broadcast: null argument");
+  CRGPU_ENTER(x);
+  CRGPU_CHECK_CANCEL(x);
+  if (n_cols < 0 || n_cols > kMaxCols || (n_cols > 0 && cols == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_exchange_broadcast: bad columns");
+  if (n < 0 || n > 0x7FFFFFF0ll) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_exchange_broadcast: at most 2^31 rows per call");
+  // every destination's region is the whole input
+  std::vector<int64_t> scnt(x->world, n), soff(x->world, 0);
+  return exchange_impl(x, "crgpu_exchange_broadcast", cols, n_cols, n, soff, scnt, res, recv_counts);
 }

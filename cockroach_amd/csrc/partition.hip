@@ -363,8 +363,9 @@ extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dc
     for (int c = 0; c < nc; c++) {
       OutCol &o = p->out[c];
       o.type = p->types[c];
-      o.nullable = false;
+      o.nullable = cols != nullptr && cols[c].valid != nullptr;  // an empty input keeps its columns' nullability
       CRGPU_TRY(o.data.ensure(16));
+      if (o.nullable) CRGPU_TRY(o.valid.ensure(8));
       if (o.type == CRGPU_BYTES) {
         CRGPU_TRY(o.offsets.ensure(4));
         CRGPU_HIP(hipMemsetAsync(o.offsets.p, 0, 4, st));

@@ -258,11 +258,18 @@ class Exchange:
         _lib.check(_lib.load().crgpu_exchange_unique_id(buf))
         return bytes(buf)
 
-    def __init__(self, uid: bytes, world: int, rank: int):
+    def __init__(self, uid: bytes, world: int, rank: int, _clone_of=None):
         self.world, self.rank = world, rank
-        self._uid = (C.c_uint8 * Exchange.ID_BYTES)(*uid)
         self.h = C.c_void_p()
+        if _clone_of is not None:
+            _lib.check(_lib.load().crgpu_exchange_clone(_clone_of.h, C.byref(self.h)))
+            return
+        self._uid = (C.c_uint8 * Exchange.ID_BYTES)(*uid)
         _lib.check(_lib.load().crgpu_exchange_create(self._uid, world, rank, C.byref(self.h)))
+
+    def clone(self) -> "Exchange":
+        """A second handle on the same communicator (own stream, own result buffers): crgpu_exchange_clone."""
+        return Exchange(None, self.world, self.rank, _clone_of=self)
 
     def all_to_all(self, cols, send_counts):
         """cols: partitioned DeviceColumns; returns (DevResult of the received rows, recv_counts)."""
@@ -270,6 +277,14 @@ class Exchange:
         rc = (C.c_int64 * self.world)()
         res = _lib.DevResult()
         _lib.check(_lib.load().crgpu_exchange_all_to_all(self.h, dcol_array(cols), len(cols), sc, C.byref(res), rc))
+        return res, np.array(list(rc), dtype=np.int64)
+
+    def broadcast(self, cols, n=None):
+        """cols: this rank's rows; returns (DevResult of all ranks' rows in rank order, recv_counts)."""
+        n = (cols[0].n if cols else 0) if n is None else n
+        rc = (C.c_int64 * self.world)()
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_exchange_broadcast(self.h, dcol_array(cols), len(cols), n, C.byref(res), rc))
         return res, np.array(list(rc), dtype=np.int64)
 
     def close(self):

@@ -128,6 +128,24 @@ def tcol_to_vec(c: TCol) -> cd.Vec:
     return cd.Vec(c.type, c.data.cpu().numpy(), valid)
 
 
+def cut_tcol(c: TCol, lo, hi) -> TCol:
+    """Rows [lo, hi) of a TCol."""
+    lo, hi = int(lo), int(hi)
+    valid = c.valid[lo:hi] if c.valid is not None else None
+    if c.type == cd.BYTES:
+        cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=c.lens.device), torch.cumsum(c.lens, 0)])
+        return TCol(cd.BYTES, c.data[int(cs[lo]):int(cs[hi])], valid, c.lens[lo:hi])
+    return TCol(c.type, c.data[lo:hi], valid)
+
+
+def cat_tcols(parts: List[TCol]) -> TCol:
+    """The rows of `parts` one after the other (validity present on all parts or on none)."""
+    t = parts[0].type
+    valid = torch.cat([p.valid for p in parts]) if parts[0].valid is not None else None
+    lens = torch.cat([p.lens for p in parts]) if t == cd.BYTES else None
+    return TCol(t, torch.cat([p.data for p in parts]), valid, lens)
+
+
 def exchange_tcols(cols: List[TCol], send_counts, group=None):
     """Regions of `cols` (rows grouped by destination, `send_counts` rows each) swapped with one all-to-all per tensor.
     The only collective on the data path."""
@@ -193,7 +211,11 @@ class GpuExecutor:
 
     def _from_result(self, res) -> List[TCol]:
         from . import device as dev
-        n = int(res.n)
+        return self.cols_to_tcols(dev.result_columns(res))
+
+    def cols_to_tcols(self, cols) -> List[TCol]:
+        """device.DeviceColumns -> TCols (copies: the TCols own their tensors)."""
+        n = int(cols[0].n) if cols else 0
         out = []
 
         def view(ptr, count, dtype, typestr):
@@ -207,7 +229,7 @@ class GpuExecutor:
             return torch.as_tensor(h, device=self.device).clone()
 
         ts = {cd.BOOL: "|u1", cd.INT16: "<i2", cd.INT32: "<i4", cd.INT64: "<i8", cd.FLOAT64: "<f8"}
-        for c in dev.result_columns(res):
+        for c in cols:
             valid = None
             if c.valid_ptr:
                 bm = view(c.valid_ptr, (n + 7) // 8, torch.uint8, "|u1")

@@ -248,8 +248,8 @@ crgpu_status crgpu_dev_agg_create_fused(const crgpu_agg_spec *spec, int32_t n_vi
  * (sql/colflow/routers.go:683-715).  Rows of `cols` are regrouped by
  * destination = rehash64(init, hash_cols) % num_outputs into one contiguous
  * region per destination; counts_host[p] = rows for output p (host array).
- * The exchange itself (RCCL all-to-all over xGMI) is driven by the host side
- * on the returned device buffers. */
+ * The exchange itself (RCCL all-to-all over xGMI) is crgpu_exchange_all_to_all below,
+ * which takes exactly this result and these counts. */
 typedef struct crgpu_partitioner crgpu_partitioner;
 crgpu_status crgpu_dev_partitioner_create(const int32_t *types, int32_t n_cols, const int32_t *hash_cols,
                                           int32_t n_hash, uint64_t init, int32_t num_outputs,
@@ -269,14 +269,34 @@ void crgpu_dev_partitioner_destroy(crgpu_partitioner *p);
  * context (crgpu_init): one process per GPU, or one thread per GPU.
  * all_to_all: `cols` are this rank's partitioned columns (rows grouped by destination in rank order, send_counts[p]
  * rows for rank p -- exactly crgpu_dev_partition's result and counts); `out` = the rows received, grouped by source
- * rank, recv_counts[p] from rank p (host arrays of `world` entries).  All families incl. BYTES and validity bitmaps;
- * a column must carry a bitmap on every rank or on none.  Collective: every rank calls it with the same schema. */
+ * rank, recv_counts[p] from rank p (host arrays of `world` entries).  All families incl. BYTES and validity bitmaps.
+ * Collective: every rank calls it with the same schema (column count and types).  What may differ per rank is agreed
+ * on inside the call: a column is nullable in the result on every rank as soon as ONE rank passes a validity bitmap
+ * for it (ranks without one send "present"), and failures that only one rank can see after the first collective --
+ * more than 2^31 rows or 4 GiB of one BYTES column arriving somewhere, an allocation that fails -- are gathered, so
+ * that every rank returns the same error instead of leaving its peers blocked in a send/recv.
+ *
+ * crgpu_exchange_broadcast: every rank contributes its n rows of `cols` and EVERY rank receives the concatenation of
+ * all ranks' rows in rank order (recv_counts[p] = rank p's n): the MIRROR router of the reference
+ * (execinfrapb.OutputRouterSpec_MIRROR, sql/execinfrapb/data.proto:153-154: "each row is sent to all output streams")
+ * in place of the BY_HASH routers AddJoinStage puts on both join inputs (sql/physicalplan/physical_plan.go:1086-1157),
+ * for SMALL build sides -- Q9's nation, supplier and filtered part (tpch_vec:20709-20733): every rank then joins its own
+ * shard of the probe side against the whole build side and the probe side does not move at all.  The result set is
+ * the same as with both sides hash-routed (each probe row meets every build row with its key on exactly one rank). */
 #define CRGPU_EXCHANGE_ID_BYTES 128
 typedef struct crgpu_exchange crgpu_exchange;
 crgpu_status crgpu_exchange_unique_id(uint8_t *id_out /* CRGPU_EXCHANGE_ID_BYTES */);
 crgpu_status crgpu_exchange_create(const uint8_t *id, int32_t world, int32_t rank, crgpu_exchange **out);
 crgpu_status crgpu_exchange_all_to_all(crgpu_exchange *x, const crgpu_dcol *cols, int32_t n_cols, const int64_t *send_counts,
                                        crgpu_dev_result *out, int64_t *recv_counts);
+/* A second handle on the SAME communicator (no collective, no bootstrap): its own stream and its own result buffers.
+ * A result is valid until the next call on the handle that produced it, and a plan keeps several exchanged inputs alive
+ * at once (Q9: three broadcast build sides and four hash-routed join inputs); the reference gives every stream its own
+ * colrpc.Inbox the same way (sql/colflow/vectorized_flow.go:749-787).  Calls on handles of one communicator must be
+ * issued in the same order on every rank (one thread per rank does that by construction). */
+crgpu_status crgpu_exchange_clone(crgpu_exchange *x, crgpu_exchange **out);
+crgpu_status crgpu_exchange_broadcast(crgpu_exchange *x, const crgpu_dcol *cols, int32_t n_cols, int64_t n,
+                                      crgpu_dev_result *out, int64_t *recv_counts);
 void crgpu_exchange_destroy(crgpu_exchange *x);
 
 /* ---- the one entry point that allocates nothing.  It has NO counterpart in the reference: it exists for callers

@@ -53,14 +53,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _shard(cd, rank, empty_rank):
+    shard = make_shard(cd, rank)
+    return [v.slice(0, 0) for v in shard] if rank == empty_rank else shard
+
+
+def _worker(rank, world, port, out_dir, empty_rank=-1):
     sys.path.insert(0, ROOT)
     import pickle
     from cockroach_amd import coldata as cd, dist_agg as D
     from oracle import oracle as O
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        shard = make_shard(cd, rank)
+        shard = _shard(cd, rank, empty_rank)
         types = [v.type for v in shard]
         ex = OracleExecutor(O, cd, D)
         out = D.distributed_agg(ex, types, TYPES_GROUP, AGGS, [D.vec_to_tcol(v) for v in shard])
@@ -86,6 +91,19 @@ def test_distributed_group_by_world2(tmp_path, oracle):
     whole = [cd.Vec.from_values(shards[0][c].type, sum((s[c].to_values() for s in shards), [])) for c in range(len(shards[0]))]
     want = oracle.hash_agg(whole, TYPES_GROUP, AGGS)
     H.assert_same_multiset(per_rank[0] + per_rank[1], H.vecs_to_tuples(want), "distributed vs single-stage")
+
+
+def test_distributed_group_by_world2_one_rank_without_rows(tmp_path, oracle):
+    """A rank with no local rows still takes part in every collective with the same column set (its partial result is
+    empty and carries no validity of its own): the other rank's groups come out unchanged."""
+    import pickle
+    from cockroach_amd import coldata as cd
+    from tests import helpers as H
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), 1), nprocs=world, join=True)
+    per_rank = [pickle.load(open(tmp_path / f"rows_{r}.pkl", "rb")) for r in range(world)]
+    want = oracle.hash_agg(make_shard(cd, 0), TYPES_GROUP, AGGS)
+    H.assert_same_multiset(per_rank[0] + per_rank[1], H.vecs_to_tuples(want), "one empty rank")
 
 
 def test_stage_plan_follows_dist_aggregation_table():

@@ -14,21 +14,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _cut(c, lo, hi):
-    """Rows [lo, hi) of a TCol."""
-    from cockroach_amd.dist_agg import TCol
-    valid = c.valid[lo:hi] if c.valid is not None else None
-    if c.type == cd.BYTES:
-        cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=c.lens.device), torch.cumsum(c.lens, 0)])
-        return TCol(cd.BYTES, c.data[int(cs[lo]):int(cs[hi])], valid, c.lens[lo:hi])
-    return TCol(c.type, c.data[lo:hi], valid)
+    from cockroach_amd.dist_agg import cut_tcol
+    return cut_tcol(c, lo, hi)
 
 
 def _cat(parts):
-    from cockroach_amd.dist_agg import TCol
-    t = parts[0].type
-    valid = torch.cat([p.valid for p in parts]) if parts[0].valid is not None else None
-    lens = torch.cat([p.lens for p in parts]) if t == cd.BYTES else None
-    return TCol(t, torch.cat([p.data for p in parts]), valid, lens)
+    from cockroach_amd.dist_agg import cat_tcols
+    return cat_tcols(parts)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -14,6 +14,16 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["rccl", "copy"])
+def self_regions(request, monkeypatch):
+    """With one rank every region is a self-region: "rccl" sends them through ncclSend / ncclRecv like any other region
+    (CRGPU_EXCHANGE_SELF=rccl), "copy" is the default device-to-device copy a rank uses for its own region."""
+    if request.param == "rccl":
+        monkeypatch.setenv("CRGPU_EXCHANGE_SELF", "rccl")
+    else:
+        monkeypatch.delenv("CRGPU_EXCHANGE_SELF", raising=False)
+
+
 @pytest.fixture(scope="module")
 def xch():
     from cockroach_amd import device as dev
