@@ -1030,6 +1030,44 @@ static crgpu_status make_build_keypack(crgpu_join *j, int64_t n, bool *ok) {
   *ok = true;
   return CRGPU_OK;
 }
+// Direct-addressed radix tables (radix.h, RadixDirect) for a build side whose ONE integer key column is dense: its
+// [min, max] is measured (the first 2^16 rows decide whether the full pass over the key column is worth running) and,
+// if the range fits the tables' slots and is at least a quarter full, the join addresses its tables by key - min:
+// nothing is hashed, the table kernel places instead of walking cuckoo chains, a lookup reads one slot.  What CockroachDB's
+// surrogate keys (TPC-H's too: custkey, partkey, suppkey) look like.  CRGPU_JOIN_DIRECT=0 keeps the hashed tables.
+static crgpu_status maybe_direct(crgpu_join *j, int64_t n, RadixSrc *src) {
+  const char *env = std::getenv("CRGPU_JOIN_DIRECT");
+  if (env != nullptr && env[0] == '0') return CRGPU_OK;
+  if (j->kp.n != 1 || !is_int_type(j->kp.c[0].type) || n <= 0) return CRGPU_OK;
+  hipStream_t st = stream();
+  const uint64_t widest = uint64_t(1) << (10 + kRadixMaxSubBits + kRadixDirectBits);
+  long long mm[2 * kMaxPackCols];
+  CRGPU_TRY(j->minmax.ensure(sizeof(mm)));
+  const int64_t sample = n < 65536 ? n : 65536;
+  for (int pass = 0; pass < 2; pass++) {
+    const int64_t rows = pass == 0 ? sample : n;
+    if (pass == 1 && rows == sample) break;
+    for (int c = 0; c < kMaxPackCols; c++) mm[2 * c] = 0x7FFFFFFFFFFFFFFFll, mm[2 * c + 1] = static_cast<long long>(0x8000000000000000ull);
+    CRGPU_HIP(hipMemcpyAsync(j->minmax.p, mm, sizeof(mm), hipMemcpyHostToDevice, st));
+    {
+      ProfScope prof("join_build");
+      hipLaunchKernelGGL(key_minmax_kernel, dim3(grid_for(rows, 256 * 8)), dim3(256), 0, st, j->kp, rows, j->minmax.as<long long>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    CRGPU_HIP(hipMemcpyAsync(mm, j->minmax.p, sizeof(mm), hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (mm[0] > mm[1]) return CRGPU_OK;  // no row has a key
+    if (static_cast<uint64_t>(mm[1]) - static_cast<uint64_t>(mm[0]) >= widest) return CRGPU_OK;  // too wide already
+  }
+  const uint64_t span = static_cast<uint64_t>(mm[1]) - static_cast<uint64_t>(mm[0]) + 1;
+  const int sb = radix_direct_sub_bits(span, n);
+  if (sb < 0) return CRGPU_OK;
+  src->direct.lo = static_cast<uint64_t>(mm[0]);
+  src->direct.span = span;
+  src->direct.sub_bits = static_cast<uint32_t>(sb);
+  return CRGPU_OK;
+}
+
 static KeyPack probe_keypack(const crgpu_join *j, const std::vector<DCol> &left) {
   KeyPack kp = j->kp;
   for (int c = 0; c < kp.n; c++) kp.c[c] = left[j->left_eq[c]];
@@ -1078,8 +1116,13 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
     j->use_radix = false;
     if (radix_eligible(j, n)) {
       RadixSrc src = radix_src(j->kp, (j->covering && j->cover_col >= 0) ? &j->build_cols[j->cover_col] : nullptr);
+      CRGPU_TRY(maybe_direct(j, n, &src));
       bool ok = false;
       CRGPU_TRY(radix_build(j->radix, src, n, &ok));
+      if (!ok && src.direct.span != 0) {  // (a sub-partition overflowed: duplicate keys after all) the hashed tables may still do
+        src.direct = RadixDirect{0, 0, 0, 0};
+        CRGPU_TRY(radix_build(j->radix, src, n, &ok));
+      }
       j->use_radix = ok;
     }
     if (!j->use_radix) {
@@ -1369,7 +1412,9 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
   int64_t cap_rows = n > 0 ? n : 1;
   const int lkc = j->left_eq[0], rkc = j->right_eq[0];
   const DCol &lkey = left[lkc];
-  const bool key_castable = j->kp.n == 1 && lkey.type != CRGPU_FLOAT64;  // the probe key column can be emitted from the key word
+  // the probe key column can be emitted from the key word -- unless the tables are direct-addressed and unmatched rows
+  // are kept: a probe key outside the build side's range has no key word then, yet its value must come out
+  const bool key_castable = j->kp.n == 1 && lkey.type != CRGPU_FLOAT64 && !(keeps_unmatched && j->radix.direct.span != 0 && !j->use_radix_dup);
 
   int pay_col = -1;
   bool need_pairs_p = false;

@@ -40,12 +40,28 @@ struct RadixEmit {
   unsigned long long *out_count;
 };
 
+// Direct-addressed tables ("dense" build keys): when the build side's one integer key column spans a range no wider
+// than the slots of the sub-partition tables (hi - lo < 2^(10 + sub_bits + kRadixDirectBits)), the key word of a row
+// is x = key - lo and NOTHING is hashed: level-1 partition = the top bits of x, sub-partition = the next sub_bits,
+// slot = the low kRadixDirectBits bits.  Unique keys cannot collide, so a sub-partition's table is filled by plain
+// placement (no cuckoo walk) and a lookup reads exactly ONE slot -- the probe kernel is bound by its divergent table
+// reads, 1.6 per row with the 3-way cuckoo tables.  A probe key outside [lo, lo + span) has no key,
+// exactly like a NULL or an out-of-range column of a packed multi-column key.
+static constexpr int kRadixDirectBits = 11;  // 2048 of a table's 3072 slots are addressed directly
+struct RadixDirect {
+  uint64_t lo;        // build side's smallest key (as the packed key word)
+  uint64_t span;      // key words x = key - lo with x < span exist; 0: hashed tables
+  uint32_t sub_bits;  // sub-partition bits the tables were built with
+  uint32_t _pad;
+};
+
 // One side of the join as {packed key, 64-bit payload} rows.
 struct RadixSrc {
   KeyPack kp;          // the key word of a row (device.h)
   const uint8_t *pay;  // payload column, or null => the payload is the row id
   int32_t pay_width;
   int32_t fast;  // int64 key without NULLs + 8-byte payload (or none: the row id), 16-byte aligned: vector loads
+  RadixDirect direct;  // span != 0: direct-addressed tables (set by radix_build / radix_probe from the table)
 };
 
 struct RadixSpecial {  // the one build key whose packed value equals kRadixEmpty
@@ -72,6 +88,7 @@ struct RadixTable {
   uint32_t p_nchunks = 0, p_cell_cap = 0;
   bool cells_failed = false;  // a cell overflowed once (skewed keys): this table's probes use the histogram form
   bool has_dup_keys = false;  // radix_build(check_dup): two build rows share a key (the table keeps one of them)
+  RadixDirect direct = {0, 0, 0, 0};  // span != 0: the tables are direct-addressed (radix_build with src.direct set)
 };
 
 // Level 1 only: t.rows_a holds partition p's rows in [starts[p], starts[p] + totals[p]) (uint32 arrays of kRadixP1).
@@ -102,7 +119,11 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
 // kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
 // check_dup: the table kernels also verify that the build keys are unique and report it in t.has_dup_keys (the join
 // paths do not need it: first writer wins and they want one match; the fused group-join does).
+// src.direct.span != 0 asks for direct-addressed tables (the caller measured the key range: radix_direct_fits).
 crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, bool check_dup = false);
+// The sub-partition bits direct-addressed tables need for a key range of `span` values, or -1 when the range is too
+// wide for them (or so sparse -- fewer than span / 4 build rows -- that hashed tables are the better use of memory).
+int radix_direct_sub_bits(uint64_t span, int64_t n_build);
 // Probes n rows.  partitioned: radix-partition the probe rows first (large probes);
 // otherwise look every row up directly (three dependent random reads per row).
 // nulls_pass: additionally emit the probe rows whose key is NULL as unmatched

@@ -36,6 +36,17 @@ __device__ __forceinline__ void rslots(uint64_t h, uint32_t *s) {
   s[2] = rscale(static_cast<uint32_t>(g >> 32));
 }
 
+// Key word -> the 64-bit value whose bit fields address the tables.  Hashed tables: fmix64.  Direct-addressed tables
+// (radix.h, RadixDirect): the key word x = key - lo itself, laid out so that rpart / rsub read the same fields --
+// [63:54] = x >> (kRadixDirectBits + sub_bits) (< 1024 by the span limit), [47 + sub_bits - 1 : 47] = the next
+// sub_bits bits of x, [kRadixDirectBits - 1 : 0] = the slot.
+template <bool DIRECT>
+__device__ __forceinline__ uint64_t rhash(uint64_t k, uint32_t sub_bits) {
+  if (!DIRECT) return fmix64(k);
+  const uint64_t hi = k >> kRadixDirectBits;
+  return ((hi >> sub_bits) << 54) | ((hi & ((1ull << sub_bits) - 1ull)) << 47) | (k & ((1ull << kRadixDirectBits) - 1ull));
+}
+
 __device__ __forceinline__ uint64_t rload(const uint8_t *src, int64_t i, int width) {
   switch (width) {
     case 1: return src[i];
@@ -58,7 +69,8 @@ __device__ __forceinline__ void rstore(uint8_t *dst, int64_t pos, int width, uin
 // rows r0, r0+1 (r0 even) of one join side as {packed key, payload}
 // FAST: 0 generic loader; 1 vector loads of key and payload; 2 vector load of the key, the payload is the row id (a
 // compile-time form of its own: a run-time test of s.pay inside form 1 cost config J's probe-side scatter 0.2 ms)
-template <int FAST>
+// DIRECT: the key word becomes x = key - lo; a key outside the build side's range has no key (ok = false)
+template <int FAST, bool DIRECT = false>
 __device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64_t hi, uint64_t *k, uint64_t *v,
                                             bool *ok) {
   if (FAST != 0 && r0 + 1 < hi) {
@@ -71,19 +83,36 @@ __device__ __forceinline__ void radix_load2(const RadixSrc &s, int64_t r0, int64
       v[0] = static_cast<uint64_t>(r0), v[1] = static_cast<uint64_t>(r0 + 1);
     }
     ok[0] = ok[1] = true;
-    return;
-  }
+  } else {
 #pragma unroll
-  for (int t = 0; t < 2; t++) {
-    const int64_t r = r0 + t;
-    k[t] = 0, v[t] = 0;
-    ok[t] = r < hi && key_pack(s.kp, r, k[t]);
-    if (ok[t]) v[t] = s.pay ? rload(s.pay, r, s.pay_width) : static_cast<uint64_t>(r);
+    for (int t = 0; t < 2; t++) {
+      const int64_t r = r0 + t;
+      k[t] = 0, v[t] = 0;
+      ok[t] = r < hi && key_pack(s.kp, r, k[t]);
+      if (ok[t]) v[t] = s.pay ? rload(s.pay, r, s.pay_width) : static_cast<uint64_t>(r);
+    }
   }
+  if (DIRECT) {
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      k[t] -= s.direct.lo;  // (wraps far above the span when the key is below lo)
+      ok[t] = ok[t] && k[t] < s.direct.span;
+    }
+  }
+}
+// one row's key word (the probe kernel's unpartitioned modes)
+template <bool DIRECT>
+__device__ __forceinline__ bool radix_key(const RadixSrc &s, int64_t r, uint64_t &k) {
+  bool ok = key_pack(s.kp, r, k);
+  if (DIRECT) {
+    k -= s.direct.lo;
+    ok = ok && k < s.direct.span;
+  }
+  return ok;
 }
 
 // ------------------------------------------------------------------ level 1: histogram per chunk
-template <bool FAST>
+template <bool FAST, bool DIRECT = false>
 __global__ __launch_bounds__(1024) void radix_hist_kernel(RadixSrc src, int64_t n, int64_t chunk_rows,
                                                           uint32_t *__restrict__ hist) {
   __shared__ uint32_t h[kRadixP1];
@@ -93,18 +122,12 @@ __global__ __launch_bounds__(1024) void radix_hist_kernel(RadixSrc src, int64_t 
   int64_t hi = lo + chunk_rows;
   if (hi > n) hi = n;
   for (int64_t r0 = lo + 2 * static_cast<int64_t>(threadIdx.x); r0 < hi; r0 += 2048) {
-    if (FAST && r0 + 1 < hi) {
-      const ulonglong2 a = reinterpret_cast<const ulonglong2 *>(src.kp.c[0].data)[r0 >> 1];
-      atomicAdd(&h[rpart(fmix64(a.x))], 1u);
-      atomicAdd(&h[rpart(fmix64(a.y))], 1u);
-    } else {
+    uint64_t kk[2], vv[2];
+    bool ok[2];
+    radix_load2<FAST ? 2 : 0, DIRECT>(src, r0, hi, kk, vv, ok);  // (form 2: the payload is not loaded)
 #pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int64_t r = r0 + t;
-        uint64_t kk;
-        if (r < hi && key_pack(src.kp, r, kk)) atomicAdd(&h[rpart(fmix64(kk))], 1u);
-      }
-    }
+    for (int t = 0; t < 2; t++)
+      if (ok[t]) atomicAdd(&h[rpart(rhash<DIRECT>(kk[t], src.direct.sub_bits))], 1u);
   }
   __syncthreads();
   hist[static_cast<int64_t>(blockIdx.x) * kRadixP1 + threadIdx.x] = h[threadIdx.x];
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(1024) void radix_offs_kernel(uint32_t *__restrict__
 // beyond the capacity are dropped and the flag is raised (skewed keys: the caller repeats the pass with offsets from a
 // histogram).  For hashed keys a cell holds chunk_rows / 1024 rows on average with a standard deviation of its square
 // root, so a capacity eight deviations above the mean practically never overflows.
-template <int FAST, bool CELLS>
+template <int FAST, bool CELLS, bool DIRECT = false>
 __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64_t n, int64_t chunk_rows,
                                                              const uint32_t *__restrict__ offs,
                                                              ulonglong2 *__restrict__ out, uint32_t cell_cap,
@@ -204,18 +227,18 @@ __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64
   bool nok[ROWS];
 #pragma unroll
   for (int j = 0; j < ROWS / 2; j++)
-    radix_load2<FAST>(src, lo + static_cast<int64_t>(j * THREADS + threadIdx.x) * 2, hi, nk + 2 * j, nv + 2 * j, nok + 2 * j);
+    radix_load2<FAST, DIRECT>(src, lo + static_cast<int64_t>(j * THREADS + threadIdx.x) * 2, hi, nk + 2 * j, nv + 2 * j, nok + 2 * j);
   for (int64_t t0 = lo; t0 < hi; t0 += TILE) {
     uint64_t kk[ROWS], vv[ROWS];
     uint32_t pp[ROWS], rk[ROWS], nfl[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; j++) {
       kk[j] = nk[j], vv[j] = nv[j];
-      pp[j] = nok[j] ? rpart(fmix64(kk[j])) : 0xFFFFFFFFu;
+      pp[j] = nok[j] ? rpart(rhash<DIRECT>(kk[j], src.direct.sub_bits)) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int j = 0; j < ROWS / 2; j++)  // prefetch the next tile while this one is ranked and flushed
-      radix_load2<FAST>(src, t0 + TILE + static_cast<int64_t>(j * THREADS + threadIdx.x) * 2, hi, nk + 2 * j, nv + 2 * j,
+      radix_load2<FAST, DIRECT>(src, t0 + TILE + static_cast<int64_t>(j * THREADS + threadIdx.x) * 2, hi, nk + 2 * j, nv + 2 * j,
                         nok + 2 * j);
     // A: rank among the partition's pending rows
 #pragma unroll
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(1024) void radix_scatter_kernel(RadixSrc src, int64
 // that draws more than kSkewLimit of them (64 expected, standard deviation 8) holds well over its share of the rows
 // -- a hot key -- and would overflow its cells; the probe then partitions with the full histogram instead.
 static constexpr int kSkewSample = 65536, kSkewLimit = 100;
-template <bool FAST>
+template <bool FAST, bool DIRECT = false>
 __global__ __launch_bounds__(1024) void radix_skew_sample_kernel(RadixSrc src, int64_t n, int64_t stride,
                                                                  uint32_t *__restrict__ hist) {
   const int64_t i = (static_cast<int64_t>(blockIdx.x) * 1024 + threadIdx.x) * stride;
@@ -280,7 +303,11 @@ __global__ __launch_bounds__(1024) void radix_skew_sample_kernel(RadixSrc src, i
   bool ok = true;
   if (FAST) kk = reinterpret_cast<const uint64_t *>(src.kp.c[0].data)[i];
   else ok = key_pack(src.kp, i, kk);
-  if (ok) atomicAdd(&hist[rpart(fmix64(kk))], 1u);
+  if (DIRECT) {
+    kk -= src.direct.lo;
+    ok = ok && kk < src.direct.span;
+  }
+  if (ok) atomicAdd(&hist[rpart(rhash<DIRECT>(kk, src.direct.sub_bits))], 1u);
 }
 __global__ __launch_bounds__(1024) void radix_skew_check_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ flag) {
   if (hist[threadIdx.x] > static_cast<uint32_t>(kSkewLimit)) atomicOr(flag, 1u);
@@ -313,6 +340,7 @@ __global__ __launch_bounds__(512) void radix_cell_prefix_kernel(const uint32_t *
 // sub-partition in LDS and written out as runs (~64 rows = 1 KiB per run, coalesced).
 // sub_count[p][s] = rows written; a region that would overflow raises the flag (the caller
 // falls back to the classic table) and the excess rows are dropped.
+template <bool DIRECT>
 __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__restrict__ in,
                                                            const uint32_t *__restrict__ starts,
                                                            const uint32_t *__restrict__ totals, uint32_t smask,
@@ -337,7 +365,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
       sp[j] = 0xFFFFFFFFu;
       if (i < n) {
         row[j] = in[s0 + i];
-        sp[j] = rsub(fmix64(row[j].x), smask);
+        sp[j] = DIRECT ? static_cast<uint32_t>(row[j].x >> kRadixDirectBits) & smask : rsub(fmix64(row[j].x), smask);
         rk[j] = atomicAdd(&tcnt[sp[j]], 1u);
       }
     }
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
     const uint32_t tile_rows = n - t0 < static_cast<uint32_t>(TILE) ? n - t0 : TILE;
     for (uint32_t i = threadIdx.x; i < tile_rows; i += THREADS) {
       const ulonglong2 r = stage[i];
-      const uint32_t s = rsub(fmix64(r.x), smask);
+      const uint32_t s = DIRECT ? static_cast<uint32_t>(r.x >> kRadixDirectBits) & smask : rsub(fmix64(r.x), smask);
       const uint32_t pos = cur[s] + (i - tstart[s]);
       if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
     }
@@ -670,6 +698,38 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
   }
 }
 
+// ------------------------------------------------------------------ level 3, direct-addressed form
+// The key words of a sub-partition are x = key - lo with the same high bits: slot = the low kRadixDirectBits bits, and
+// unique keys cannot collide.  The image is assembled in LDS (a row id per slot, claimed with a CAS so that one row of a
+// duplicated key wins as a whole) and written out coalesced; unclaimed slots hold the EMPTY marker, which no key word
+// of a direct table equals (x < 2^28).  Only the first 2^kRadixDirectBits slots of the table are ever read.
+template <bool CHECK_DUP>
+__global__ __launch_bounds__(512) void radix_direct_table_kernel(const ulonglong2 *__restrict__ rows,
+                                                                 const uint32_t *__restrict__ sub_count,
+                                                                 ulonglong2 *__restrict__ table, uint32_t *__restrict__ failed) {
+  constexpr int THREADS = 512, SLOTS = 1 << kRadixDirectBits;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  __shared__ uint32_t tab[SLOTS];
+  const int q = blockIdx.x;
+  const int64_t base = static_cast<int64_t>(q) * kRadixSubCap;
+  uint32_t n = sub_count[q];
+  if (n > static_cast<uint32_t>(kRadixSubCap)) n = kRadixSubCap;  // overflow is reported by the split kernel
+  for (int i = threadIdx.x; i < SLOTS; i += THREADS) tab[i] = kNone;
+  __syncthreads();
+  bool dup = false;
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    const uint32_t slot = static_cast<uint32_t>(rows[base + i].x) & (SLOTS - 1);
+    dup = dup || atomicCAS(&tab[slot], kNone, i) != kNone;  // first writer wins, as in the cuckoo table
+  }
+  if (CHECK_DUP && dup) atomicOr(failed, 8u);
+  __syncthreads();
+  ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
+  for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
+    const uint32_t id = tab[i];
+    dst[i] = id == kNone ? make_ulonglong2(kRadixEmpty, 0) : rows[base + id];
+  }
+}
+
 // ------------------------------------------------------------------ level 3, perfect-hash form
 // The probe kernel is bound by the number of divergent table reads it issues, and a cuckoo lookup costs
 // 1.5 of them on average.  A sub-partition's keys are known when its table is built, so the table can be a PERFECT
@@ -940,6 +1000,7 @@ struct RadixProbeArgs {
   // CELLS (MODE 0): the partitioned rows live in fixed-capacity cells (radix_scatter_kernel<.., true>)
   const uint32_t *cell_pref;  // [partition][nchunks + 1]
   uint32_t nchunks, cell_cap;
+  uint64_t key_add;  // direct-addressed tables: lo, added to a key word that is emitted as a key column
   RadixEmit emit;
 };
 
@@ -948,8 +1009,11 @@ struct RadixProbeArgs {
 //         read from HBM once and then served by that XCD's L2);
 // MODE 1: direct lookups of unpartitioned probe rows (small probes);
 // MODE 2: only the rows whose key is NULL, as unmatched (LEFT OUTER / LEFT ANTI).
-template <int JT, int MODE, int TB, int RPT, bool CHD, bool CELLS = false>
+// TBL: 0 three-way cuckoo tables, 1 perfect-hash (CHD) tables, 2 direct-addressed tables (one slot read per row, nothing hashed).
+template <int JT, int MODE, int TB, int RPT, int TBL, bool CELLS = false>
 __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
+  constexpr bool CHD = TBL == 1;
+  constexpr bool DIRECT = TBL == 2;
   constexpr int kWaves = TB / 64;
   constexpr int kTile = TB * RPT;
   __shared__ uint32_t s_cnt[RPT * kWaves];
@@ -1015,7 +1079,7 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
           look[j] = true;
         }
       } else if (inb[j]) {
-        knull[j] = !key_pack(a.src.kp, r, k[j]);  // NULL, or outside the build side's key range: matches nothing
+        knull[j] = !radix_key<DIRECT>(a.src, r, k[j]);  // NULL, or outside the build side's key range: matches nothing
         if (MODE == 2) {
           inb[j] = knull[j];  // this pass only sees the rows without a key
         } else {
@@ -1053,6 +1117,23 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
 #pragma unroll
       for (int j = 0; j < RPT; j++)
         if (look[j]) rw[j] = tb[j][chd_slot(sa[j], sb[j], db[j])];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (look[j] && rw[j].x == k[j]) {
+          found[j] = true;
+          val[j] = rw[j].y;
+        }
+      }
+    } else if (MODE != 2 && DIRECT) {
+      // direct-addressed tables: the key word IS the address -- partition, sub-partition and slot are bit fields of x
+      ulonglong2 rw[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        if (look[j]) {
+          const uint64_t q = k[j] >> kRadixDirectBits;  // (partition << sub_bits) | sub-partition
+          rw[j] = a.table[static_cast<int64_t>(q) * kRadixSlots + (k[j] & ((1ull << kRadixDirectBits) - 1ull))];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < RPT; j++) {
         if (look[j] && rw[j].x == k[j]) {
@@ -1151,12 +1232,12 @@ __global__ __launch_bounds__(TB) void radix_probe_kernel(RadixProbeArgs a) {
         uint64_t v;
         uint32_t present = 1;
         if (cc.side == R_KEY) {
-          v = k[j];
+          v = DIRECT ? k[j] + a.key_add : k[j];
           present = !knull[j];
         } else if (cc.side == R_PROBE_PAY) {
           v = pay[j];
         } else {  // build side: NULL when a LEFT OUTER row has no match (hashjoiner.go:671-682)
-          v = cc.side == R_BUILD_KEY ? k[j] : val[j];
+          v = cc.side == R_BUILD_KEY ? (DIRECT ? k[j] + a.key_add : k[j]) : val[j];
           present = found[j];
         }
         rstore(cc.dst, pos[j], cc.width, v);
@@ -1531,10 +1612,15 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
   CRGPU_TRY(rows.ensure(static_cast<size_t>(n + 8 * kRadixP1 + extra_rows) * 16));
   {
     ProfScope prof(prof_hist);
-    if (src.fast)
-      hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
+    const bool direct = src.direct.span != 0;
+    if (src.fast && direct)
+      hipLaunchKernelGGL((radix_hist_kernel<true, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
+    else if (src.fast)
+      hipLaunchKernelGGL((radix_hist_kernel<true, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
+    else if (direct)
+      hipLaunchKernelGGL((radix_hist_kernel<false, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
     else
-      hipLaunchKernelGGL(radix_hist_kernel<false>, dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
+      hipLaunchKernelGGL((radix_hist_kernel<false, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, hist.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
     hipLaunchKernelGGL(radix_colsum_kernel, dim3(kRadixP1 / 64), dim3(1024), 0, st, hist.as<uint32_t>(), nchunks,
                        totals.as<uint32_t>());
@@ -1545,15 +1631,20 @@ static crgpu_status radix_partition(const RadixSrc &src, int64_t n, DevBuf &hist
   }
   {
     ProfScope prof(prof_scatter);
-    if (src.fast && src.pay != nullptr)
-      hipLaunchKernelGGL((radix_scatter_kernel<1, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
-                         hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
-    else if (src.fast)
-      hipLaunchKernelGGL((radix_scatter_kernel<2, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
-                         hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
-    else
-      hipLaunchKernelGGL((radix_scatter_kernel<0, false>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows,
-                         hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr);
+    const int form = src.fast ? (src.pay != nullptr ? 1 : 2) : 0;
+#define CRGPU_SCATTER(F, D)                                                                                            \
+  hipLaunchKernelGGL((radix_scatter_kernel<F, false, D>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, \
+                     hist.as<uint32_t>(), rows.as<ulonglong2>(), 0u, nullptr, nullptr)
+    if (src.direct.span != 0) {
+      if (form == 1) CRGPU_SCATTER(1, true);
+      else if (form == 2) CRGPU_SCATTER(2, true);
+      else CRGPU_SCATTER(0, true);
+    } else {
+      if (form == 1) CRGPU_SCATTER(1, false);
+      else if (form == 2) CRGPU_SCATTER(2, false);
+      else CRGPU_SCATTER(0, false);
+    }
+#undef CRGPU_SCATTER
     CRGPU_HIP(hipGetLastError());
   }
   return CRGPU_OK;
@@ -1582,10 +1673,15 @@ static crgpu_status radix_partition_cells(RadixTable &t, const RadixSrc &src, in
     CRGPU_TRY(t.p_hist.ensure(kRadixP1 * 4));
     CRGPU_HIP(hipMemsetAsync(t.p_hist.p, 0, kRadixP1 * 4, st));
     const int64_t stride = n / kSkewSample > 0 ? n / kSkewSample : 1;
-    if (src.fast)
-      hipLaunchKernelGGL(radix_skew_sample_kernel<true>, dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
+    const bool direct = src.direct.span != 0;
+    if (src.fast && direct)
+      hipLaunchKernelGGL((radix_skew_sample_kernel<true, true>), dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
+    else if (src.fast)
+      hipLaunchKernelGGL((radix_skew_sample_kernel<true, false>), dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
+    else if (direct)
+      hipLaunchKernelGGL((radix_skew_sample_kernel<false, true>), dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
     else
-      hipLaunchKernelGGL(radix_skew_sample_kernel<false>, dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
+      hipLaunchKernelGGL((radix_skew_sample_kernel<false, false>), dim3(kSkewSample / 1024), dim3(1024), 0, st, src, n, stride, t.p_hist.as<uint32_t>());
     hipLaunchKernelGGL(radix_skew_check_kernel, dim3(1), dim3(1024), 0, st, t.p_hist.as<uint32_t>(), t.flag.as<uint32_t>());
     CRGPU_HIP(hipGetLastError());
     uint32_t skewed = 0;
@@ -1595,15 +1691,20 @@ static crgpu_status radix_partition_cells(RadixTable &t, const RadixSrc &src, in
   }
   {
     ProfScope prof("radix_probe_scatter");
-    if (src.fast && src.pay != nullptr)
-      hipLaunchKernelGGL((radix_scatter_kernel<1, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
-                         t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
-    else if (src.fast)
-      hipLaunchKernelGGL((radix_scatter_kernel<2, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
-                         t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
-    else
-      hipLaunchKernelGGL((radix_scatter_kernel<0, true>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr,
-                         t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>());
+    const int form = src.fast ? (src.pay != nullptr ? 1 : 2) : 0;
+#define CRGPU_SCATTER(F, D)                                                                                                  \
+  hipLaunchKernelGGL((radix_scatter_kernel<F, true, D>), dim3(nchunks), dim3(1024), 0, st, src, n, chunk_rows, nullptr, \
+                     t.p_rows.as<ulonglong2>(), cap, t.p_cell_cnt.as<uint32_t>(), t.flag.as<uint32_t>())
+    if (src.direct.span != 0) {
+      if (form == 1) CRGPU_SCATTER(1, true);
+      else if (form == 2) CRGPU_SCATTER(2, true);
+      else CRGPU_SCATTER(0, true);
+    } else {
+      if (form == 1) CRGPU_SCATTER(1, false);
+      else if (form == 2) CRGPU_SCATTER(2, false);
+      else CRGPU_SCATTER(0, false);
+    }
+#undef CRGPU_SCATTER
     CRGPU_HIP(hipGetLastError());
     hipLaunchKernelGGL(radix_cell_prefix_kernel, dim3(kRadixP1), dim3(512), 0, st, t.p_cell_cnt.as<uint32_t>(),
                        static_cast<uint32_t>(nchunks), t.p_cell_pref.as<uint32_t>(), t.p_totals.as<uint32_t>());
@@ -1638,6 +1739,8 @@ crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n
   int sb = lg - 10 - log2_rows_per_sub;  // 1024 level-1 partitions, then ~2^log2_rows_per_sub rows per sub-partition
   if (sb < 0) sb = 0;
   if (sb > max_sub_bits) sb = max_sub_bits;
+  const bool direct = src.direct.span != 0;
+  if (direct) sb = static_cast<int>(src.direct.sub_bits);  // the key range decides, not the row count
   t.sub_bits = sb;
   const uint32_t nsub = 1u << sb;
   CRGPU_TRY(radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter"));
@@ -1647,9 +1750,14 @@ crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n
   CRGPU_HIP(hipMemsetAsync(t.flag.p, 0, 4, st));
   {
     ProfScope prof("radix_build_split");
-    hipLaunchKernelGGL(radix_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
-                       t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
-                       t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>(), subcap);
+    if (direct)
+      hipLaunchKernelGGL(radix_split_kernel<true>, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
+                         t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
+                         t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>(), subcap);
+    else
+      hipLaunchKernelGGL(radix_split_kernel<false>, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
+                         t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
+                         t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>(), subcap);
     CRGPU_HIP(hipGetLastError());
   }
   uint32_t overflow = 0;
@@ -1718,10 +1826,20 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
   return CRGPU_OK;
 }
 
+int radix_direct_sub_bits(uint64_t span, int64_t n_build) {
+  if (span == 0 || n_build <= 0) return -1;
+  int sb = 0;
+  while (sb <= kRadixMaxSubBits && (uint64_t(1) << (10 + sb + kRadixDirectBits)) < span) sb++;
+  if (sb > kRadixMaxSubBits) return -1;                     // wider than every slot of the largest table set
+  if (static_cast<uint64_t>(n_build) < span / 4) return -1;  // sparse keys: hashed tables
+  return sb;
+}
+
 crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, bool check_dup) {
   hipStream_t st = stream();
   *ok = false;
   t.has_dup_keys = false;
+  t.direct = RadixDirect{0, 0, 0, 0};
   bool split_ok = false;
   CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap, 11, kRadixMaxSubBits));
   if (!split_ok) return CRGPU_OK;  // duplicate-heavy build side: the caller uses the classic table
@@ -1733,6 +1851,27 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
   t.chd = false;
   t.dup = false;
   t.cells_failed = false;
+  if (src.direct.span != 0) {  // direct-addressed tables: plain placement, no hashing anywhere
+    {
+      ProfScope prof("radix_build_table");
+      if (check_dup)
+        hipLaunchKernelGGL(radix_direct_table_kernel<true>, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                           t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.flag.as<uint32_t>());
+      else
+        hipLaunchKernelGGL(radix_direct_table_kernel<false>, dim3(kRadixP1 * nsub), dim3(512), 0, st, t.rows_b.as<ulonglong2>(),
+                           t.sub_count.as<uint32_t>(), t.table.as<ulonglong2>(), t.flag.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    if (check_dup) {
+      CRGPU_HIP(hipMemcpyAsync(&overflow, t.flag.p, 4, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipStreamSynchronize(st));
+      t.has_dup_keys = (overflow & 8u) != 0;
+    }
+    t.direct = src.direct;
+    t.ready = true;
+    *ok = true;
+    return CRGPU_OK;
+  }
   // The perfect-hash form takes 1.06 ms off the probe of config J (6.78 -> 5.72 ms: one slot read per row instead of 1.5)
   // but its build costs 3.8 ms against the cuckoo kernel's 1.7 (size-ordered displacement searches are latency chains
   // of LDS atomics), so it only pays when the probe side is >~ 14 x the build side: opt-in, CRGPU_RADIX_TABLE=chd.
@@ -1791,8 +1930,16 @@ crgpu_status radix_build(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok
 template <int JT, int MODE, int TB, int RPT>
 static crgpu_status launch_probe_jt(const RadixProbeArgs &a, int grid) {
   hipStream_t st = stream();
+  if (a.src.direct.span != 0) {  // direct-addressed tables
+    if (MODE == 0 && a.cell_pref != nullptr)
+      hipLaunchKernelGGL((radix_probe_kernel<JT, MODE == 0 ? 0 : MODE, TB, RPT, 2, MODE == 0>), dim3(grid), dim3(TB), 0, st, a);
+    else
+      hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, 2>), dim3(grid), dim3(TB), 0, st, a);
+    CRGPU_HIP(hipGetLastError());
+    return CRGPU_OK;
+  }
   if (MODE == 0 && a.cell_pref != nullptr && a.disp == nullptr) {  // rows in cells (cuckoo tables)
-    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE == 0 ? 0 : MODE, TB, RPT, false, MODE == 0>), dim3(grid), dim3(TB), 0, st, a);
+    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE == 0 ? 0 : MODE, TB, RPT, 0, MODE == 0>), dim3(grid), dim3(TB), 0, st, a);
     CRGPU_HIP(hipGetLastError());
     return CRGPU_OK;
   }
@@ -1801,14 +1948,14 @@ static crgpu_status launch_probe_jt(const RadixProbeArgs &a, int grid) {
     if (lds > 48 * 1024) {
       static DeviceOnce attr_set;  // per instantiation
       if (attr_set.need()) {
-        CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_probe_kernel<JT, MODE, TB, RPT, true>),
+        CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&radix_probe_kernel<JT, MODE, TB, RPT, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * kRadixBuckets));
         attr_set.mark();
       }
     }
-    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, true>), dim3(grid), dim3(TB), lds, st, a);
+    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, 1>), dim3(grid), dim3(TB), lds, st, a);
   } else {
-    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, false>), dim3(grid), dim3(TB), 0, st, a);
+    hipLaunchKernelGGL((radix_probe_kernel<JT, MODE, TB, RPT, 0>), dim3(grid), dim3(TB), 0, st, a);
   }
   CRGPU_HIP(hipGetLastError());
   return CRGPU_OK;
@@ -1831,13 +1978,16 @@ static crgpu_status launch_probe(int jt, const RadixProbeArgs &a, int grid) {
   return launch_probe_cfg<MODE, kProbeTB, kProbeRPT>(jt, a, grid);
 }
 
-crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, const RadixEmit &emit, bool partitioned) {
+crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src_in, int64_t n, const RadixEmit &emit, bool partitioned) {
   if (!t.ready) return fail(CRGPU_ERR_STATE, "radix probe: table not built");
   if (n <= 0) return CRGPU_OK;
   constexpr int kTile = kProbeTile;
+  RadixSrc src = src_in;
+  src.direct = t.direct;  // the probe rows are addressed the way the tables were built
   RadixProbeArgs a;
   std::memset(&a, 0, sizeof(a));
   a.src = src;
+  a.key_add = t.direct.lo;
   a.n = n;
   a.table = t.table.as<ulonglong2>();
   a.special = t.special.as<RadixSpecial>();
@@ -1876,7 +2026,7 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src, int64_t n, 
     ProfScope prof("join_probe");
     CRGPU_TRY(launch_probe<1>(jt, a, static_cast<int>(tiles < cap ? tiles : cap)));
   }
-  bool keyless = src.kp.n > 1;  // a multi-column key: probe values may lie outside the build side's range
+  bool keyless = src.kp.n > 1 || t.direct.span != 0;  // probe values may lie outside the build side's range
   for (int c = 0; c < src.kp.n; c++) keyless = keyless || src.kp.c[c].valid != nullptr;
   if (keeps_unmatched && keyless) {  // rows without a key (NULL / out of range) never match but LEFT OUTER / ANTI keep them
     int64_t tiles = (n + kTile - 1) / kTile;
@@ -1890,6 +2040,7 @@ crgpu_status radix_build_dup(RadixTable &t, const RadixSrc &src, int64_t n, bool
   hipStream_t st = stream();
   *ok = false;
   t.dup = false;
+  t.direct = RadixDirect{0, 0, 0, 0};
   bool split_ok = false;
   CRGPU_TRY(radix_partition_split(t, src, n, &split_ok, kRadixSubCap, 11, kRadixMaxSubBits));
   if (!split_ok) return CRGPU_OK;  // heavily skewed keys: a sub-partition overflowed, the caller uses the chained table

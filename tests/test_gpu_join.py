@@ -237,14 +237,19 @@ def test_join_probe_selected_equals_deselect_then_probe(oracle, jt, table, monke
 # radix-partitioned path (csrc/radix.hip): forced on for small inputs through the
 # CRGPU_RADIX_MIN_BUILD / CRGPU_RADIX_MIN_PROBE environment overrides
 # ---------------------------------------------------------------------------
-@pytest.fixture(params=["partitioned", "direct", "partitioned-chd", "direct-chd"])
+@pytest.fixture(params=["partitioned", "direct", "partitioned-chd", "direct-chd", "partitioned-dense", "direct-dense"])
 def radix_env(request, monkeypatch):
     """partitioned / direct: the probe side is radix-partitioned first / looked up row by row; -chd: the sub-partition
-    tables are perfect-hash tables (CRGPU_RADIX_TABLE=chd, one slot read per lookup) instead of 3-way cuckoo tables."""
+    tables are perfect-hash tables (CRGPU_RADIX_TABLE=chd, one slot read per lookup) instead of 3-way cuckoo tables;
+    -dense: the library's default choice -- direct-addressed tables (key - min is the address, nothing hashed) when the
+    build side's one integer key column is dense, hashed tables otherwise; the other forms pin the hashed tables
+    (CRGPU_JOIN_DIRECT=0)."""
     monkeypatch.setenv("CRGPU_RADIX_MIN_BUILD", "1")
     monkeypatch.setenv("CRGPU_RADIX_MIN_PROBE", "1" if request.param.startswith("partitioned") else str(1 << 40))
     if request.param.endswith("-chd"):
         monkeypatch.setenv("CRGPU_RADIX_TABLE", "chd")
+    if not request.param.endswith("-dense"):
+        monkeypatch.setenv("CRGPU_JOIN_DIRECT", "0")
     return request.param
 
 
@@ -286,6 +291,53 @@ def test_join_radix_vs_oracle(oracle, radix_env, jt, shape):
     want = oracle.hash_join(H.JOIN_TYPE[jt], left, right, [0], [0], True)
     got = G.gpu_join(jt, left, right, [0], [0], True, probe_chunks=2)
     H.assert_same_multiset(got, H.vecs_to_tuples(want), f"{jt} {shape} {radix_env}")
+
+
+@pytest.mark.parametrize("jt", ["INNER", "LEFT_OUTER", "LEFT_SEMI", "LEFT_ANTI"])
+def test_join_direct_addressed_tables_at_real_thresholds(oracle, jt):
+    """2^22 dense build keys (a shuffled range with holes, negative lower bound, one key held twice) x 2^23 probe rows
+    with keys inside the range, in its holes, outside it on both sides and NULL: the library picks direct-addressed
+    tables by itself (no environment overrides).  Against numpy row by row."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(77)
+    nb, npr = 1 << 22, 1 << 23
+    lo = -123_456
+    keys = rng.permutation(nb + nb // 8)[:nb].astype(np.int64) + lo  # 1/9 of the range are holes
+    bv = keys * 5 + 2
+    pk = rng.integers(lo - 50_000, lo + nb + nb // 8 + 50_000, size=npr, dtype=np.int64)
+    pvalid = rng.random(npr) > 0.01
+    pw = np.arange(npr, dtype=np.int64)
+    j = dev.Join(H.JOIN_TYPE[jt], [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], True)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    j.build([dev.upload(cd.Vec.from_numpy(cd.INT64, keys)), dev.upload(cd.Vec.from_numpy(cd.INT64, bv))], nb)
+    res = dev.result_to_vecs(j.probe([dev.upload(cd.Vec.from_numpy(cd.INT64, pk, pvalid)), dev.upload(cd.Vec.from_numpy(cd.INT64, pw))], npr))
+    assert dev.prof_get("radix_build_table")[1] == 1 and dev.prof_get("radix_build_split")[1] == 1
+    dev.prof_enable(False)
+    j.close()
+    present = np.zeros(nb + nb // 8, dtype=bool)
+    present[keys - lo] = True
+    inr = pvalid & (pk >= lo) & (pk < lo + nb + nb // 8)
+    hit = inr.copy()
+    hit[inr] = present[pk[inr] - lo]
+    order = np.argsort(res[1].data, kind="stable")  # by w = the probe row id
+    if jt in ("INNER", "LEFT_SEMI"):
+        rows = np.nonzero(hit)[0]
+    elif jt == "LEFT_ANTI":
+        rows = np.nonzero(~hit)[0]
+    else:
+        rows = np.arange(npr)
+    assert len(res[0]) == len(rows)
+    assert np.array_equal(res[1].data[order], pw[rows])
+    kv = res[0].present()[order] if res[0].valid is not None else np.ones(len(rows), dtype=bool)
+    assert np.array_equal(kv, pvalid[rows])                                    # the probe key column: NULL where it was NULL ...
+    assert np.array_equal(res[0].data[order][kv], pk[rows][pvalid[rows]])       # ... its own value everywhere else, out of range or not
+    if jt == "INNER":
+        assert np.array_equal(res[2].data[order], pk[rows]) and np.array_equal(res[3].data[order], pk[rows] * 5 + 2)
+    if jt == "LEFT_OUTER":
+        bp = res[3].present()[order]
+        assert np.array_equal(bp, hit) and np.array_equal(res[3].data[order][bp], pk[hit] * 5 + 2)
+        assert np.array_equal(res[2].present()[order], hit) and np.array_equal(res[2].data[order][bp], pk[hit])
 
 
 def test_join_radix_duplicate_build_keys_fall_back(oracle, radix_env):
