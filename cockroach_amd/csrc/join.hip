@@ -742,6 +742,53 @@ __global__ __launch_bounds__(256) void key_minmax_kernel(KeyPack kp, int64_t n, 
   }
 }
 
+// [min, max] of an INT64 column without NULLs (16-byte aligned): vector loads, one atomic pair per wave
+typedef long long ll2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(512) void i64_minmax_kernel(const ll2v *__restrict__ col, int64_t n, long long *__restrict__ mm) {
+  long long lo = 0x7FFFFFFFFFFFFFFFll, hi = static_cast<long long>(0x8000000000000000ull);
+  const int64_t pairs = n >> 1, stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < pairs; i += 4 * stride) {
+    ll2v v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(col + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      lo = v[u].x < lo ? v[u].x : lo, lo = v[u].y < lo ? v[u].y : lo;
+      hi = v[u].x > hi ? v[u].x : hi, hi = v[u].y > hi ? v[u].y : hi;
+    }
+  }
+  for (; i < pairs; i += stride) {
+    const ll2v v = col[i];
+    lo = v.x < lo ? v.x : lo, lo = v.y < lo ? v.y : lo;
+    hi = v.x > hi ? v.x : hi, hi = v.y > hi ? v.y : hi;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long v = reinterpret_cast<const long long *>(col)[n - 1];
+    lo = v < lo ? v : lo, hi = v > hi ? v : hi;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const long long l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  // one atomic pair per WORKGROUP: same-address atomics serialise at ~10 ns each
+  __shared__ long long s_lo[8], s_hi[8];
+  if (lane_id() == 0) s_lo[threadIdx.x >> 6] = lo, s_hi[threadIdx.x >> 6] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 8; w++) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+    if (lo <= hi) {
+      atomicMin(&mm[0], lo);
+      atomicMax(&mm[1], hi);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void flag_eq_kernel(const uint8_t *__restrict__ in, int64_t n, uint8_t want,
                                                       uint8_t *__restrict__ out) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -1051,7 +1098,16 @@ static crgpu_status maybe_direct(crgpu_join *j, int64_t n, RadixSrc *src) {
     CRGPU_HIP(hipMemcpyAsync(j->minmax.p, mm, sizeof(mm), hipMemcpyHostToDevice, st));
     {
       ProfScope prof("join_build");
-      hipLaunchKernelGGL(key_minmax_kernel, dim3(grid_for(rows, 256 * 8)), dim3(256), 0, st, j->kp, rows, j->minmax.as<long long>());
+      const DCol &kc = j->kp.c[0];
+      if (kc.type == CRGPU_INT64 && kc.valid == nullptr && aligned16(kc.data)) {
+        int64_t blocks = (rows / 2 + 512 * 8 - 1) / (512 * 8);
+        const int64_t cap = static_cast<int64_t>(num_cus()) * 4;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(i64_minmax_kernel, dim3(static_cast<int>(blocks < cap ? blocks : cap)), dim3(512), 0, st,
+                           static_cast<const ll2v *>(kc.data), rows, j->minmax.as<long long>());
+      } else {
+        hipLaunchKernelGGL(key_minmax_kernel, dim3(grid_for(rows, 256 * 8)), dim3(256), 0, st, j->kp, rows, j->minmax.as<long long>());
+      }
       CRGPU_HIP(hipGetLastError());
     }
     CRGPU_HIP(hipMemcpyAsync(mm, j->minmax.p, sizeof(mm), hipMemcpyDeviceToHost, st));
