@@ -700,34 +700,38 @@ __global__ __launch_bounds__(512) void radix_table_kernel(const ulonglong2 *__re
 
 // ------------------------------------------------------------------ level 3, direct-addressed form
 // The key words of a sub-partition are x = key - lo with the same high bits: slot = the low kRadixDirectBits bits, and
-// unique keys cannot collide.  The image is assembled in LDS (a row id per slot, claimed with a CAS so that one row of a
-// duplicated key wins as a whole) and written out coalesced; unclaimed slots hold the EMPTY marker, which no key word
-// of a direct table equals (x < 2^28).  Only the first 2^kRadixDirectBits slots of the table are ever read.
+// unique keys cannot collide.  The image is assembled in LDS by plain stores and written out coalesced; untouched slots
+// hold the EMPTY marker, which no key word of a direct table equals (x < 2^28).  Only the first 2^kRadixDirectBits
+// slots of the table are ever read.
 template <bool CHECK_DUP>
 __global__ __launch_bounds__(512) void radix_direct_table_kernel(const ulonglong2 *__restrict__ rows,
                                                                  const uint32_t *__restrict__ sub_count,
                                                                  ulonglong2 *__restrict__ table, uint32_t *__restrict__ failed) {
   constexpr int THREADS = 512, SLOTS = 1 << kRadixDirectBits;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
-  __shared__ uint32_t tab[SLOTS];
+  __shared__ ulonglong2 img[SLOTS];                 // 32 KiB: the table image
+  __shared__ uint32_t claim[CHECK_DUP ? SLOTS : 1];  // CHECK_DUP: which row took the slot
   const int q = blockIdx.x;
   const int64_t base = static_cast<int64_t>(q) * kRadixSubCap;
   uint32_t n = sub_count[q];
   if (n > static_cast<uint32_t>(kRadixSubCap)) n = kRadixSubCap;  // overflow is reported by the split kernel
-  for (int i = threadIdx.x; i < SLOTS; i += THREADS) tab[i] = kNone;
+  for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
+    img[i] = make_ulonglong2(kRadixEmpty, 0);
+    if (CHECK_DUP) claim[i] = kNone;
+  }
   __syncthreads();
   bool dup = false;
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-    const uint32_t slot = static_cast<uint32_t>(rows[base + i].x) & (SLOTS - 1);
-    dup = dup || atomicCAS(&tab[slot], kNone, i) != kNone;  // first writer wins, as in the cuckoo table
+    const ulonglong2 r = rows[base + i];
+    const uint32_t slot = static_cast<uint32_t>(r.x) & (SLOTS - 1);
+    if (CHECK_DUP) dup = dup || atomicCAS(&claim[slot], kNone, i) != kNone;
+    // two rows of one key may both store here: the slot ends up with that key and the payload of one of them
+    img[slot] = r;
   }
   if (CHECK_DUP && dup) atomicOr(failed, 8u);
   __syncthreads();
   ulonglong2 *dst = table + static_cast<int64_t>(q) * kRadixSlots;
-  for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
-    const uint32_t id = tab[i];
-    dst[i] = id == kNone ? make_ulonglong2(kRadixEmpty, 0) : rows[base + id];
-  }
+  for (int i = threadIdx.x; i < SLOTS; i += THREADS) dst[i] = img[i];
 }
 
 // ------------------------------------------------------------------ level 3, perfect-hash form
