@@ -1976,7 +1976,7 @@ static crgpu_status launch_probe_cfg(int jt, const RadixProbeArgs &a, int grid) 
 }
 // 512 threads x 4 rows per tile, 64 workgroups per partition: the best of the shapes measured
 // ((256,4) 7.5 ms, (1024,2) 7.3, (512,2) 6.9, (256,8) 8.3, (512,8) 8.6 against 6.6 on config J).
-static constexpr int kProbeTB = 512, kProbeRPT = 4, kProbeTile = kProbeTB * kProbeRPT, kProbeWgPerPart = 64;
+static constexpr int kProbeTB = 512, kProbeRPT = 4, kProbeTile = kProbeTB * kProbeRPT, kProbeWgPerPart = 64, kProbeWgPerPartDirect = 96;
 template <int MODE>
 static crgpu_status launch_probe(int jt, const RadixProbeArgs &a, int grid) {
   return launch_probe_cfg<MODE, kProbeTB, kProbeRPT>(jt, a, grid);
@@ -2020,7 +2020,10 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src_in, int64_t 
     a.pcount = t.p_totals.as<uint32_t>();
     int64_t w = (n / kRadixP1 + kTile - 1) / kTile;
     if (w < 1) w = 1;
-    if (w > kProbeWgPerPart) w = kProbeWgPerPart;  // = the workgroups resident on one XCD (32 CUs x 2)
+    // = the workgroups resident on one XCD: 32 CUs x 2 with the cuckoo / perfect-hash lookups (86 VGPRs), x 3 with the
+    // direct-addressed ones (72 VGPRs; measured on config J: 64 per partition 5.79 ms, 96 5.21, 128 5.18-5.46, 256 5.54)
+    const int64_t wmax = t.direct.span != 0 ? kProbeWgPerPartDirect : kProbeWgPerPart;
+    if (w > wmax) w = wmax;
     a.wg_per_part = static_cast<int32_t>(w);
     ProfScope prof("join_probe");
     CRGPU_TRY(launch_probe<0>(jt, a, kRadixP1 * static_cast<int>(w)));
