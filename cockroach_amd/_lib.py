@@ -75,7 +75,9 @@ class FetchSpec(C.Structure):  # crgpu_fetch_spec
     _fields_ = [("key_prefix_len", C.c_int32), ("n_key_cols", C.c_int32), ("key_types", C.POINTER(C.c_int32)),
                 ("key_dirs", C.POINTER(C.c_int32)), ("key_out", C.POINTER(C.c_int32)), ("n_val_cols", C.c_int32),
                 ("n_out_cols", C.c_int32), ("val_col_ids", C.POINTER(C.c_int32)), ("val_types", C.POINTER(C.c_int32)),
-                ("val_out", C.POINTER(C.c_int32)), ("out_types", C.POINTER(C.c_int32))]
+                ("val_out", C.POINTER(C.c_int32)), ("out_types", C.POINTER(C.c_int32)),
+                ("max_keys_per_row", C.c_int32), ("max_family_id", C.c_int32), ("n_family_defaults", C.c_int32),
+                ("_pad", C.c_int32), ("family_ids", C.POINTER(C.c_int32)), ("family_default_col_ids", C.POINTER(C.c_int32))]
 
 
 class Col(C.Structure):  # crgpu_col (host, coldata layout)

@@ -27,7 +27,7 @@
 
 namespace crgpu {
 
-static constexpr int kMaxKeyFetch = 8, kMaxValFetch = 32, kMaxOutFetch = 32;
+static constexpr int kMaxKeyFetch = 8, kMaxValFetch = 32, kMaxOutFetch = 32, kMaxFamilies = 16;
 static constexpr int kWalkWindow = 8192;
 
 struct FetchSpec {
@@ -35,6 +35,9 @@ struct FetchSpec {
   int32_t key_types[kMaxKeyFetch], key_dirs[kMaxKeyFetch], key_out[kMaxKeyFetch];
   int32_t val_ids[kMaxValFetch], val_types[kMaxValFetch], val_out[kMaxValFetch];
   int32_t out_types[kMaxOutFetch];
+  // column families (fetchpb.IndexFetchSpec.MaxKeysPerRow / MaxFamilyID / FamilyDefaultColumns)
+  int32_t max_keys_per_row, max_family_id, n_fam_defaults;
+  int32_t fam_ids[kMaxFamilies], fam_default_val[kMaxFamilies];  // family id -> index into val_* of its default column, -1: not fetched
 };
 struct FetchOut {
   void *data[kMaxOutFetch];        // fixed-width values, or the BYTES payload buffer (pass 1)
@@ -42,10 +45,15 @@ struct FetchOut {
   uint32_t *lens[kMaxOutFetch];    // BYTES: decoded length per row (pass 0)
   const uint32_t *offs[kMaxOutFetch];  // BYTES: offsets (pass 1)
   uint32_t *src[kMaxOutFetch];     // BYTES value columns: payload position inside the record (pass 0), so that
-                                   // pass 1 is a plain copy and does not parse the row again
+                                   // pass 1 is a plain copy and does not parse the row again (rows of several KVs:
+                                   // relative to the row's first record)
+  // rows of several KVs (column families): the row of every KV, whether it opens its row, where a row's first record is
+  const uint32_t *row_of;
+  const uint8_t *is_first;
+  const int64_t *row_first;
 };
 
-enum : int32_t { KV_OK = 0, KV_TRUNCATED = 1, KV_BAD_MVCC_KEY = 2, KV_BAD_KEY = 3, KV_NOT_TUPLE = 4, KV_BAD_VALUE = 5 };
+enum : int32_t { KV_OK = 0, KV_TRUNCATED = 1, KV_BAD_MVCC_KEY = 2, KV_BAD_KEY = 3, KV_NO_DEFAULT_COLUMN = 4, KV_BAD_VALUE = 5 };
 struct KvError {
   unsigned long long first_row;  // smallest failing row (atomicMin)
   int32_t code;
@@ -390,11 +398,65 @@ __device__ __forceinline__ void put_fixed(void *dst, int type, int64_t row, int6
   }
 }
 
+// The key columns of one KV, decoded (first KV of a row) or only measured: DecodeKeyValsToCols (key_encoding.go:43-81).
+// Returns the bytes they take, or -1.  `o` / `row` / `seen` are used when WRITE.
+template <int PASS, bool WRITE>
+__device__ __forceinline__ int64_t kv_key_cols(const uint8_t *key, int64_t klen, int64_t row, const FetchSpec &f, const FetchOut &o,
+                                               uint32_t *seen) {
+  const uint8_t *k0 = key;
+  for (int c = 0; c < f.n_key; c++) {
+    const bool desc = f.key_dirs[c] != 0;
+    const int oc = f.key_out[c];
+    if (klen <= 0) return -1;
+    if (key[0] == (desc ? 0xff : 0x00)) {  // NULL (DecodeIfNull, :101-104)
+      if (WRITE && oc >= 0) {
+        *seen |= 1u << oc;
+        if (PASS == 0) {
+          o.valid[oc][row] = 0;
+          if (f.out_types[oc] == CRGPU_BYTES) o.lens[oc][row] = 0;
+          else put_fixed(o.data[oc], f.out_types[oc], row, 0, 0);
+        }
+      }
+      key++, klen--;
+      continue;
+    }
+    int64_t used;
+    if (f.key_types[c] == CRGPU_FLOAT64) {
+      double d;
+      used = dec_float_key(key, klen, desc, &d);
+      if (WRITE && used >= 0 && oc >= 0 && PASS == 0) put_fixed(o.data[oc], CRGPU_FLOAT64, row, 0, d);
+    } else if (f.key_types[c] == CRGPU_BYTES) {
+      uint32_t dl = 0;
+      uint8_t *dst = (WRITE && PASS == 1 && oc >= 0) ? static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row] : nullptr;
+      used = dec_bytes_key(key, klen, desc, dst, &dl);
+      if (WRITE && used >= 0 && oc >= 0 && PASS == 0) o.lens[oc][row] = dl;
+    } else {
+      int64_t v;
+      used = dec_varint_asc(key, klen, &v);
+      if (desc) v = ~v;  // DecodeVarintDescending (:407-410)
+      if (WRITE && used >= 0 && oc >= 0 && PASS == 0) put_fixed(o.data[oc], f.out_types[oc], row, v, 0);
+    }
+    if (used < 0) return -1;
+    if (WRITE && oc >= 0) {
+      *seen |= 1u << oc;
+      if (PASS == 0) o.valid[oc][row] = 1;
+    }
+    key += used, klen -= used;
+  }
+  return key - k0;
+}
+
 // PASS 0: fixed-width values, validity bytes, BYTES lengths.  PASS 1: BYTES payloads.
-template <int PASS>
-__device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, const FetchSpec &f, const FetchOut &o,
+// FAM: rows of several KVs (column families): `kv` is the record, o.row_of / o.is_first say which row it belongs to
+// and whether it opens it; validity bytes, lengths and values were zeroed before (a column no KV of the row carries is
+// NULL: fillNulls), every KV writes the columns its family holds.
+template <int PASS, bool FAM>
+__device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t kv, int64_t rec_off_kv, const FetchSpec &f, const FetchOut &o,
                                              KvError *__restrict__ err) {
   {
+    const int64_t row = FAM ? static_cast<int64_t>(o.row_of[kv]) : kv;
+    const bool first = FAM ? o.is_first[kv] != 0 : true;
+    const uint32_t rel_base = FAM ? static_cast<uint32_t>(rec_off_kv - o.row_first[row]) : 0u;
     const uint32_t vl = p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
     const uint32_t kl = p[4] | (p[5] << 8) | (p[6] << 16) | (static_cast<uint32_t>(p[7]) << 24);
     const uint8_t *mk = p + 8, *val = p + 8 + kl;
@@ -407,59 +469,34 @@ __device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, cons
     const uint8_t *key = mk + f.key_prefix_len;
     int64_t klen = key_end - f.key_prefix_len;
     if (code == KV_OK && klen < 0) code = KV_BAD_KEY;
-    // DecodeKeyValsToCols (key_encoding.go:43-81)
-    for (int c = 0; c < f.n_key && code == KV_OK; c++) {
-      const bool desc = f.key_dirs[c] != 0;
-      const int oc = f.key_out[c];
-      if (klen <= 0) {
-        code = KV_BAD_KEY;
-        break;
-      }
-      if (key[0] == (desc ? 0xff : 0x00)) {  // NULL (DecodeIfNull, :101-104)
-        if (oc >= 0) {
-          seen |= 1u << oc;
-          if (PASS == 0) {
-            o.valid[oc][row] = 0;
-            if (f.out_types[oc] == CRGPU_BYTES) o.lens[oc][row] = 0;
-            else put_fixed(o.data[oc], f.out_types[oc], row, 0, 0);
-          }
-        }
-        key++, klen--;
-        continue;
-      }
-      int64_t used;
-      if (f.key_types[c] == CRGPU_FLOAT64) {
-        double d;
-        used = dec_float_key(key, klen, desc, &d);
-        if (used >= 0 && oc >= 0 && PASS == 0) put_fixed(o.data[oc], CRGPU_FLOAT64, row, 0, d);
-      } else if (f.key_types[c] == CRGPU_BYTES) {
-        uint32_t dl = 0;
-        uint8_t *dst = (PASS == 1 && oc >= 0) ? static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row] : nullptr;
-        used = dec_bytes_key(key, klen, desc, dst, &dl);
-        if (used >= 0 && oc >= 0 && PASS == 0) o.lens[oc][row] = dl;
-      } else {
-        int64_t v;
-        used = dec_varint_asc(key, klen, &v);
-        if (desc) v = ~v;  // DecodeVarintDescending (:407-410)
-        if (used >= 0 && oc >= 0 && PASS == 0) put_fixed(o.data[oc], f.out_types[oc], row, v, 0);
-      }
+    int32_t family_id = 0;
+    if (code == KV_OK) {
+      // the first KV of a row decodes its key columns (stateDecodeFirstKVOfRow, cfetcher.go:830-858); a later KV of the
+      // row only carries the row prefix in front of its family id
+      const int64_t used = first ? kv_key_cols<PASS, true>(key, klen, row, f, o, &seen) : kv_key_cols<PASS, false>(key, klen, row, f, o, &seen);
       if (used < 0) {
         code = KV_BAD_KEY;
-        break;
+      } else if (f.max_family_id != 0) {  // getCurrentColumnFamilyID (cfetcher.go:1447-1467)
+        uint64_t id;
+        if (dec_uvarint_asc(key + used, klen - used, &id) < 0) code = KV_BAD_KEY;
+        family_id = static_cast<int32_t>(id);
       }
-      if (oc >= 0) {
-        seen |= 1u << oc;
-        if (PASS == 0) o.valid[oc][row] = 1;
-      }
-      key += used, klen -= used;
     }
-    // processValue (cfetcher.go:1167-1190): RawBytes = checksum[4] tag[1] payload
-    if (code == KV_OK && f.n_val > 0 && vl != 0) {
-      if (vl < 5 || val[4] != 10) {
-        code = KV_NOT_TUPLE;
-      } else {
-        const uint8_t *vb = val + 5;
-        int64_t vrem = static_cast<int64_t>(vl) - 5;
+    // processValue (cfetcher.go:1136-1217).  RawBytes = [BE32 header length, 0x65, MVCC value header] checksum[4] tag[1]
+    // data: Value.GetTag / dataBytes with the extended encoding (roachpb/data.go:336-338, 436-448, 479-489)
+    if (code == KV_OK && f.n_out > 0) {
+      int64_t simple = 0;
+      const bool extended = vl > 5 && val[4] == 101;
+      if (extended) simple = 5 + ((static_cast<int64_t>(val[0]) << 24) | (val[1] << 16) | (val[2] << 8) | val[3]);
+      int tag = 0;  // ValueType_UNKNOWN
+      if (!extended) {
+        if (vl > 4) tag = val[4];
+      } else if (static_cast<int64_t>(vl) > simple + 4) {
+        tag = val[simple + 4];
+      }
+      const uint8_t *vb = val + simple + 5;
+      int64_t vrem = static_cast<int64_t>(vl) - simple - 5;
+      if (tag == 10) {  // TUPLE
         int32_t last_id = 0;
         int idx = 0, remaining = f.n_val;
         while (vrem > 0 && remaining > 0) {  // processValueBytes (:1342-1394)
@@ -521,7 +558,7 @@ __device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, cons
             else {
               if (PASS == 0) {
                 o.lens[oc][row] = static_cast<uint32_t>(l);
-                o.src[oc][row] = static_cast<uint32_t>(d + nn - p);
+                o.src[oc][row] = rel_base + static_cast<uint32_t>(d + nn - p);
               } else {
                 uint8_t *dst = static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row];
                 for (uint64_t t = 0; t < l; t++) dst[t] = d[nn + t];
@@ -541,15 +578,54 @@ __device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, cons
           if (PASS == 0) o.valid[oc][row] = 1;
           vb += doff + used, vrem -= doff + used;
         }
+      } else if (family_id != 0) {
+        // a single-column family in the legacy form (:1191-1213): the value's tag names the type, its data is the datum
+        // (processValueSingle :1280-1311, colencoding.UnmarshalColumnValueToCol key_encoding.go:226-297)
+        int vec = -2;  // -2: the family has no default column
+        for (int i = 0; i < f.n_fam_defaults; i++)
+          if (f.fam_ids[i] == family_id) vec = f.fam_default_val[i];
+        if (vec == -2) {
+          code = KV_NO_DEFAULT_COLUMN;
+        } else if (vec >= 0 && vl != 0 && !(extended && static_cast<int64_t>(vl) <= simple)) {  // fetched, and Value.IsPresent (data.go:396-411)
+          const int oc = f.val_out[vec];
+          const int vt = f.val_types[vec];
+          if (vrem < 0) {
+            code = KV_BAD_VALUE;
+          } else if (vt == CRGPU_FLOAT64) {  // GetFloat (data.go:699-712)
+            if (tag != 2 || vrem != 8) code = KV_BAD_VALUE;
+            else if (PASS == 0) put_fixed(o.data[oc], vt, row, 0, __longlong_as_double(static_cast<long long>(get_be64(vb))));
+          } else if (vt == CRGPU_BYTES) {  // GetBytes (:689-694): the rest of the value
+            if (tag != 3) code = KV_BAD_VALUE;
+            else if (PASS == 0) {
+              o.lens[oc][row] = static_cast<uint32_t>(vrem);
+              o.src[oc][row] = rel_base + static_cast<uint32_t>(vb - p);
+            } else {
+              uint8_t *dst = static_cast<uint8_t *>(o.data[oc]) + o.offs[oc][row];
+              for (int64_t t = 0; t < vrem; t++) dst[t] = vb[t];
+            }
+          } else {  // GetInt / GetBool (:765-790)
+            int64_t v;
+            if (tag != 1 || dec_stdlib_varint(vb, vrem, &v) <= 0 || (vt == CRGPU_BOOL && (v > 1 || v < 0))) code = KV_BAD_VALUE;
+            else if (PASS == 0) put_fixed(o.data[oc], vt, row, v, 0);
+          }
+          if (code == KV_OK) {
+            seen |= 1u << oc;
+            if (PASS == 0) o.valid[oc][row] = 1;
+          }
+        }
       }
+      // (family 0 with another tag: the row sentinel of the pre-family format, no value expected, :1192-1196)
     }
     if (PASS == 0) {
-      // fillNulls (cfetcher.go:1401-1427); a failed row is zero-filled so that later passes stay in bounds
-      for (int c = 0; c < f.n_out; c++) {
-        if (code != KV_OK || !(seen & (1u << c))) {
-          o.valid[c][row] = 0;
-          if (f.out_types[c] == CRGPU_BYTES) o.lens[c][row] = 0;
-          else put_fixed(o.data[c], f.out_types[c], row, 0, 0);
+      // fillNulls (cfetcher.go:1401-1427); a failed row is zero-filled so that later passes stay in bounds.  FAM: the
+      // outputs were zeroed before the pass, only a failing KV clears what it may have half-written.
+      if (!FAM || code != KV_OK) {
+        for (int c = 0; c < f.n_out; c++) {
+          if (code != KV_OK || !(seen & (1u << c))) {
+            o.valid[c][row] = 0;
+            if (f.out_types[c] == CRGPU_BYTES) o.lens[c][row] = 0;
+            else put_fixed(o.data[c], f.out_types[c], row, 0, 0);
+          }
         }
       }
       if (code != KV_OK) {
@@ -560,13 +636,79 @@ __device__ __forceinline__ void kv_parse_row(const uint8_t *p, int64_t row, cons
   }
 }
 
+// Rows of several KVs: does KV i open a row?  The reference decides KV by KV (cfetcher.go:946-1020): a KV belongs to
+// the unfinished row when its key starts with the row prefix (the bytes up to the end of the key columns of the row's
+// first KV), and the KV of the last family (MaxFamilyID) ends the row.  Row-parallel form: all KVs of a row repeat the
+// row's key columns byte for byte, so KV i continues KV i-1's row exactly when its key starts with KV i-1's OWN key
+// columns -- unless KV i-1 was itself a continuation carrying the last family.  (Deeper chains of KVs that repeat a
+// prefix after the last family cannot be written by EncodePrimaryIndex.)
+__device__ __forceinline__ bool kv_key_of(const uint8_t *repr, int64_t off, const FetchSpec &f, const FetchOut &o, const uint8_t **key,
+                                          int64_t *klen, int64_t *cols_len, int32_t *family) {
+  const uint8_t *p = repr + off;
+  const uint32_t kl = p[4] | (p[5] << 8) | (p[6] << 16) | (static_cast<uint32_t>(p[7]) << 24);
+  const uint8_t *mk = p + 8;
+  const int ts_len = kl ? mk[kl - 1] : 1;
+  const int64_t key_end = static_cast<int64_t>(kl) - 1 - ts_len;
+  *cols_len = -1;
+  *family = -1;
+  if (kl == 0 || ts_len == 1 || key_end < f.key_prefix_len) return false;
+  *key = mk + f.key_prefix_len;
+  *klen = key_end - f.key_prefix_len;
+  uint32_t seen = 0;
+  const int64_t used = kv_key_cols<0, false>(*key, *klen, 0, f, o, &seen);
+  if (used < 0) return false;
+  *cols_len = used;
+  uint64_t id;
+  if (f.max_family_id != 0 && dec_uvarint_asc(*key + used, *klen - used, &id) >= 0) *family = static_cast<int32_t>(id);
+  return true;
+}
+__device__ __forceinline__ bool kv_continues(const uint8_t *key, int64_t klen, const uint8_t *pkey, int64_t pcols) {
+  if (pcols < 0 || klen < pcols) return false;
+  for (int64_t i = 0; i < pcols; i++)
+    if (key[i] != pkey[i]) return false;
+  return true;
+}
+__global__ __launch_bounds__(256) void kv_row_first_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ rec_off, int64_t n,
+                                                           FetchSpec f, FetchOut o, uint8_t *__restrict__ is_first, uint32_t *__restrict__ first32) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    bool first = true;
+    if (i > 0) {
+      const uint8_t *key = nullptr, *k1 = nullptr, *k2 = nullptr;
+      int64_t klen = 0, cols = 0, kl1 = 0, c1 = 0, kl2 = 0, c2 = 0;
+      int32_t fam = 0, fam1 = 0, fam2 = 0;
+      const bool ok0 = kv_key_of(repr, rec_off[i], f, o, &key, &klen, &cols, &fam);
+      const bool ok1 = kv_key_of(repr, rec_off[i - 1], f, o, &k1, &kl1, &c1, &fam1);
+      bool cont = ok0 && ok1 && kv_continues(key, klen, k1, c1);
+      if (cont && fam1 == f.max_family_id && i > 1) {  // did KV i-1 end its row as a continuation with the last family?
+        const bool ok2 = kv_key_of(repr, rec_off[i - 2], f, o, &k2, &kl2, &c2, &fam2);
+        if (ok2 && kv_continues(k1, kl1, k2, c2)) cont = false;
+      }
+      first = !cont;
+    }
+    is_first[i] = first;
+    first32[i] = first;
+  }
+}
+// row_of[kv] = (rows opened up to and including kv) - 1; row_first[row] = the offset of its first record
+__global__ __launch_bounds__(256) void kv_row_index_kernel(const uint64_t *__restrict__ excl, const uint8_t *__restrict__ is_first,
+                                                           const int64_t *__restrict__ rec_off, int64_t n, uint32_t *__restrict__ row_of,
+                                                           int64_t *__restrict__ row_first) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t r = static_cast<uint32_t>(excl[i]) + (is_first[i] ? 1u : 0u) - 1u;
+    row_of[i] = r;
+    if (is_first[i]) row_first[r] = rec_off[i];
+  }
+}
+
 // One lane per KV.  The records of a 256-row tile are contiguous in the batch (~45 KiB for
 // lineitem): the tile is copied into LDS with coalesced 16-byte loads and parsed from there
 // (byte-serial parsing straight from global memory ran at 0.35 TB/s: one load instruction per
 // byte).  A tile whose span does not fit (huge values, or rows of different buffers) is parsed
 // from global memory.
 static constexpr int kDecodeStage = 60 * 1024;
-template <int PASS>
+template <int PASS, bool FAM>
 __global__ __launch_bounds__(256) void kv_decode_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ rec_off,
                                                         int64_t n, FetchSpec f_arg, FetchOut o_arg, KvError *__restrict__ err) {
   __shared__ __align__(16) uint8_t stage[kDecodeStage];
@@ -606,19 +748,20 @@ __global__ __launch_bounds__(256) void kv_decode_kernel(const uint8_t *__restric
     __syncthreads();
     if (row < n) {
       const int64_t off = rec_off[row];
-      if (staged && off >= span_lo && off < s_end) kv_parse_row<PASS>(stage + (off - span_lo), row, f, o, err);
-      else kv_parse_row<PASS>(repr + off, row, f, o, err);
+      if (staged && off >= span_lo && off < s_end) kv_parse_row<PASS, FAM>(stage + (off - span_lo), row, off, f, o, err);
+      else kv_parse_row<PASS, FAM>(repr + off, row, off, f, o, err);
     }
     __syncthreads();
   }
 }
 
 // Pass 1 when no BYTES KEY column is fetched (those need unescaping): copy the value payloads found by pass 0.
-__global__ __launch_bounds__(256) void kv_copy_bytes_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ rec_off,
+// (row_start[row]: the row's record, or the first record of a row of several KVs)
+__global__ __launch_bounds__(256) void kv_copy_bytes_kernel(const uint8_t *__restrict__ repr, const int64_t *__restrict__ row_start,
                                                             int64_t n, FetchSpec f, FetchOut o) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t row = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; row < n; row += stride) {
-    const uint8_t *rec = repr + rec_off[row];
+    const uint8_t *rec = repr + row_start[row];
     for (int c = 0; c < f.n_out; c++) {
       if (f.out_types[c] != CRGPU_BYTES) continue;
       const uint32_t a0 = o.offs[c][row], len = o.offs[c][row + 1] - a0;
@@ -652,6 +795,7 @@ struct crgpu_decoder : crgpu::Handle {
   std::vector<KvSeg> segs_host;
   DevBuf seg_rel;
   DevBuf segs, seg_start, seg_stop, seg_count, seg_err, seg_flag, seg_base, nbad, rec_off, err, scratch, offs64;
+  DevBuf is_first, first32, first_scan, row_of, row_first;  // rows of several KVs (column families)
   std::vector<OutCol> out;
   std::vector<DevBuf> valid_bytes, lens, srcpos, offs64c;
   std::vector<crgpu_dcol> views;
@@ -738,6 +882,19 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
     used |= 1u << f.val_out[c];
   }
   if (f.n_out < 32 && used != (1u << f.n_out) - 1) return bad("crgpu_dev_decoder_create: an output column has no source");
+  // column families
+  f.max_keys_per_row = s->max_keys_per_row;
+  f.max_family_id = s->max_family_id;
+  f.n_fam_defaults = s->n_family_defaults;
+  if (f.max_keys_per_row < 0 || f.max_family_id < 0 || f.n_fam_defaults < 0 || f.n_fam_defaults > kMaxFamilies ||
+      (f.n_fam_defaults > 0 && (s->family_ids == nullptr || s->family_default_col_ids == nullptr)))
+    return bad("crgpu_dev_decoder_create: bad column family description (at most 16 family default columns)");
+  for (int i = 0; i < f.n_fam_defaults; i++) {
+    f.fam_ids[i] = s->family_ids[i];
+    f.fam_default_val[i] = -1;  // the family's default column is not fetched: its values are skipped
+    for (int c = 0; c < f.n_val; c++)
+      if (f.val_ids[c] == s->family_default_col_ids[i]) f.fam_default_val[i] = c;
+  }
   d->out = std::vector<OutCol>(f.n_out);
   d->valid_bytes = std::vector<DevBuf>(f.n_out);
   d->lens = std::vector<DevBuf>(f.n_out);
@@ -760,7 +917,7 @@ static crgpu_status kv_check_error(crgpu_decoder *d, const char *phase) {
   CRGPU_HIP(hipStreamSynchronize(stream()));
   if (e.first_row == ~0ull) return CRGPU_OK;
   static const char *names[] = {"", "truncated batch response", "invalid MVCC key", "key column decode error",
-                                "value is not a TUPLE", "value column decode error"};
+                                "single entry value with no default column", "value column decode error"};
   return fail(CRGPU_ERR_INVALID, std::string("crgpu_dev_decode_kv: ") + names[e.code >= 1 && e.code <= 5 ? e.code : 0] +
                                      " (" + phase + " " + std::to_string(e.first_row) + ")");
 }
@@ -878,9 +1035,35 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
       CRGPU_HIP(hipGetLastError());
     }
   }
-  const int64_t cap = n > 0 ? n : 1;
+  // Rows of several KVs: which KV opens a row, the row of every KV, every row's first record.  From here on n counts ROWS
+  // and nkv the records.
+  const int64_t nkv = n;
+  const bool fam_rows = f.max_keys_per_row > 1 && nkv > 0;
   FetchOut o;
   std::memset(&o, 0, sizeof(o));
+  if (fam_rows) {
+    CRGPU_TRY(d->is_first.ensure(static_cast<size_t>(nkv)));
+    CRGPU_TRY(d->first32.ensure(static_cast<size_t>(nkv) * 4));
+    CRGPU_TRY(d->first_scan.ensure(static_cast<size_t>(nkv + 1) * 8));
+    CRGPU_TRY(d->row_of.ensure(static_cast<size_t>(nkv) * 4));
+    CRGPU_TRY(d->row_first.ensure(static_cast<size_t>(nkv) * 8));
+    uint64_t nrows = 0;
+    {
+      ProfScope prof("kv_decode");
+      hipLaunchKernelGGL(kv_row_first_kernel, dim3(kv_grid(nkv, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), nkv, f, o,
+                         d->is_first.as<uint8_t>(), d->first32.as<uint32_t>());
+      CRGPU_HIP(hipGetLastError());
+      CRGPU_TRY(exclusive_scan_u32(d->first32.as<uint32_t>(), nkv, d->first_scan.as<uint64_t>(), d->scratch, &nrows));
+      hipLaunchKernelGGL(kv_row_index_kernel, dim3(kv_grid(nkv, 256)), dim3(256), 0, st, d->first_scan.as<uint64_t>(),
+                         d->is_first.as<uint8_t>(), d->rec_off.as<int64_t>(), nkv, d->row_of.as<uint32_t>(), d->row_first.as<int64_t>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    n = static_cast<int64_t>(nrows);
+    o.row_of = d->row_of.as<uint32_t>();
+    o.is_first = d->is_first.as<uint8_t>();
+    o.row_first = d->row_first.as<int64_t>();
+  }
+  const int64_t cap = n > 0 ? n : 1;
   bool any_bytes = false;
   for (int c = 0; c < f.n_out; c++) {
     OutCol &oc = d->out[c];
@@ -897,16 +1080,24 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
       CRGPU_TRY(d->srcpos[c].ensure(static_cast<size_t>(cap) * 4));
       o.src[c] = d->srcpos[c].as<uint32_t>();
       if (n == 0) CRGPU_HIP(hipMemsetAsync(oc.offsets.p, 0, 4, st));
+      if (fam_rows) CRGPU_HIP(hipMemsetAsync(o.lens[c], 0, static_cast<size_t>(cap) * 4, st));
     } else {
       CRGPU_TRY(oc.data.ensure(static_cast<size_t>(cap) * type_width(oc.type)));
       o.data[c] = oc.data.p;
+      if (fam_rows) CRGPU_HIP(hipMemsetAsync(o.data[c], 0, static_cast<size_t>(cap) * type_width(oc.type), st));
     }
+    // rows of several KVs: a column that no KV of the row carries is NULL (fillNulls); every KV sets what it holds
+    if (fam_rows) CRGPU_HIP(hipMemsetAsync(o.valid[c], 0, static_cast<size_t>(cap), st));
   }
   if (n > 0) {
     {
       ProfScope prof("kv_decode");
-      hipLaunchKernelGGL(kv_decode_kernel<0>, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
-                         d->err.as<KvError>());
+      if (fam_rows)
+        hipLaunchKernelGGL((kv_decode_kernel<0, true>), dim3(kv_grid(nkv, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), nkv, f, o,
+                           d->err.as<KvError>());
+      else
+        hipLaunchKernelGGL((kv_decode_kernel<0, false>), dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
+                           d->err.as<KvError>());
       CRGPU_HIP(hipGetLastError());
     }
     // BYTES columns: lengths -> offsets; all scans are queued, then the totals and the error word come back together
@@ -934,11 +1125,15 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
       bool bytes_key = false;
       for (int c = 0; c < f.n_key; c++) bytes_key |= f.key_types[c] == CRGPU_BYTES && f.key_out[c] >= 0;
       ProfScope prof("kv_decode");
-      if (bytes_key)
-        hipLaunchKernelGGL(kv_decode_kernel<1>, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
+      if (bytes_key && fam_rows)
+        hipLaunchKernelGGL((kv_decode_kernel<1, true>), dim3(kv_grid(nkv, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), nkv, f, o,
+                           d->err.as<KvError>());
+      else if (bytes_key)
+        hipLaunchKernelGGL((kv_decode_kernel<1, false>), dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o,
                            d->err.as<KvError>());
       else
-        hipLaunchKernelGGL(kv_copy_bytes_kernel, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev, d->rec_off.as<int64_t>(), n, f, o);
+        hipLaunchKernelGGL(kv_copy_bytes_kernel, dim3(kv_grid(n, 256)), dim3(256), 0, st, repr_dev,
+                           fam_rows ? d->row_first.as<int64_t>() : d->rec_off.as<int64_t>(), n, f, o);
       CRGPU_HIP(hipGetLastError());
     }
     {  // validity bytes -> bitmaps, all output columns in ONE launch (a launch per column was ~16 per call)

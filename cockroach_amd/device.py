@@ -619,12 +619,16 @@ class Distinct:
 class Decoder:
     """crgpu_decoder handle: KV batch responses (device bytes) -> columns (cFetcher for one-KV-per-row indexes)."""
 
-    def __init__(self, key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_types, val_out, out_types):
+    def __init__(self, key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_types, val_out, out_types,
+                 max_keys_per_row=0, max_family_id=0, family_defaults=()):
+        """family_defaults: [(family id, default column id)] (IndexFetchSpec.FamilyDefaultColumns)."""
+        fam = list(family_defaults)
         self._keep = (_i32arr(key_types), _i32arr(key_dirs), _i32arr(key_out), _i32arr(val_col_ids), _i32arr(val_types),
-                      _i32arr(val_out), _i32arr(out_types))
+                      _i32arr(val_out), _i32arr(out_types), _i32arr([f for f, _ in fam]), _i32arr([c for _, c in fam]))
         k = self._keep
         spec = _lib.FetchSpec(key_prefix_len, len(list(key_types)), k[0], k[1], k[2], len(list(val_col_ids)),
-                              len(list(out_types)), k[3], k[4], k[5], k[6])
+                              len(list(out_types)), k[3], k[4], k[5], k[6], max_keys_per_row, max_family_id, len(fam), 0,
+                              k[7], k[8])
         self.h = C.c_void_p()
         _lib.check(_lib.load().crgpu_dev_decoder_create(C.byref(spec), C.byref(self.h)))
 

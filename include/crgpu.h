@@ -459,14 +459,18 @@ crgpu_status crgpu_dev_arrow_write(crgpu_arrow *h, const crgpu_dcol *cols, int64
                                    int64_t *msg_len_out);
 void crgpu_dev_arrow_destroy(crgpu_arrow *h);
 
-/* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for indexes that store one KV per
- * row (MaxKeysPerRow == 1 fast path, sql/colfetcher/cfetcher.go:758-1093,937-941) together with
- * colencoding.DecodeKeyValsToCols (colencoding/key_encoding.go:43), processValueBytes
- * (cfetcher.go:1313), colencoding.DecodeTableValueToCol (value_encoding.go:24) and fillNulls
- * (cfetcher.go:1401).  The spec is the subset of fetchpb.IndexFetchSpec the decode needs
- * (sql/catalog/fetchpb/index_fetch.proto:112: KeyPrefixLength, key columns with direction,
- * fetched columns by column id).  Types: crgpu_type; other families (DECIMAL, TIMESTAMP, ...)
- * stay on the CPU fetcher; such columns may still be PRESENT in the rows, they are skipped. */
+/* ---- KV fetch decode: replaces colfetcher.cFetcher.NextBatch for primary indexes
+ * (sql/colfetcher/cfetcher.go:758-1093: one KV per row -- the MaxKeysPerRow == 1 fast path :937-941 -- and rows of
+ * several column families, stateFetchNextKVWithUnfinishedRow :946-1020) together with
+ * colencoding.DecodeKeyValsToCols (colencoding/key_encoding.go:43), processValue (cfetcher.go:1136),
+ * processValueBytes (:1313) with colencoding.DecodeTableValueToCol (value_encoding.go:24), processValueSingle (:1280)
+ * with colencoding.UnmarshalColumnValueToCol (key_encoding.go:226-297: INT / FLOAT / BYTES single-column families),
+ * getCurrentColumnFamilyID (:1447), fillNulls (:1401) and the MVCC extended value header
+ * (roachpb/data.go:288-289,336-338,436-489), which is skipped.  The spec is the subset of fetchpb.IndexFetchSpec
+ * the decode needs (sql/catalog/fetchpb/index_fetch.proto:57-127: KeyPrefixLength, key columns with direction,
+ * fetched columns by column id, MaxKeysPerRow, MaxFamilyID, FamilyDefaultColumns).  Types: crgpu_type; other
+ * families (DECIMAL, TIMESTAMP, ...) stay on the CPU fetcher; such columns may still be PRESENT in the rows, they
+ * are skipped.  Secondary-index value forms (cfetcher.go:1218-1268) stay on the CPU fetcher. */
 typedef struct crgpu_fetch_spec {
   int32_t key_prefix_len;  /* IndexFetchSpec.KeyPrefixLength: tenant/table/index prefix bytes */
   int32_t n_key_cols;      /* index key columns, in key order (<= 8) */
@@ -479,13 +483,21 @@ typedef struct crgpu_fetch_spec {
   const int32_t *val_types;
   const int32_t *val_out;
   const int32_t *out_types; /* crgpu_type per output column */
+  /* Column families.  All zero / NULL: the index stores one KV per row in family 0. */
+  int32_t max_keys_per_row;   /* IndexFetchSpec.MaxKeysPerRow; > 1: consecutive KVs that share the row prefix are ONE row */
+  int32_t max_family_id;      /* IndexFetchSpec.MaxFamilyID; != 0: the family id is read from the key (keys.MakeFamilyKey) */
+  int32_t n_family_defaults;  /* IndexFetchSpec.FamilyDefaultColumns (<= 16) */
+  int32_t _pad;
+  const int32_t *family_ids;             /* FamilyDefaultColumn.FamilyID */
+  const int32_t *family_default_col_ids; /* FamilyDefaultColumn.DefaultColumnID: a non-TUPLE value of that family is this column's datum */
 } crgpu_fetch_spec;
 
 typedef struct crgpu_decoder crgpu_decoder;
 crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *spec, crgpu_decoder **out);
 /* repr_dev: concatenated MVCCScan batch responses (storage/enginepb/decode.go:77-128) in device
  * memory, 16-byte aligned and followed by >= 16 readable bytes; batch b spans [batch_offsets_host[b], batch_offsets_host[b+1]).
- * out: one row per KV in scan order, one column per output ordinal; columns requested but
+ * out: one row per KV (per group of KVs sharing a row prefix when max_keys_per_row > 1; a call must hold whole rows,
+ * as scans with WholeRowsOfSize deliver them) in scan order, one column per output ordinal; columns requested but
  * absent from a row are NULL.  Malformed input => CRGPU_ERR_INVALID naming the first bad row. */
 crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
                                  int64_t n_batches, crgpu_dev_result *out);

@@ -2,7 +2,8 @@
  * crdb_kv.c -- TEST INFRASTRUCTURE ONLY (see crdb_oracle.h).
  *
  * CPU restatement of the KV -> column decode path of the reference's cFetcher
- * for single-family tables (one KV per row), plus the matching ENCODER so that
+ * for primary indexes -- one KV per row, or several column families per row with TUPLE and
+ * single-column ("legacy") values and the MVCC extended value header --, plus the matching ENCODER so that
  * decode parity can be pinned by round trips (the reference holds no KV byte
  * fixtures for whole rows).  The primitive codecs are
  * pinned by the literal vectors of pkg/util/encoding/encoding_test.go:280-324,
@@ -22,8 +23,12 @@
  *   pkg/keys/keys.go                MakeFamilyKey :950-961 (family 0 => one byte 0x88)
  *   pkg/sql/colencoding             DecodeKeyValsToCols key_encoding.go:43, decodeTableKeyToCol :87,
  *                                   DecodeTableValueToCol value_encoding.go:24
- *   pkg/sql/colfetcher/cfetcher.go  NextBatch :758 (MaxKeysPerRow == 1 path :937), processValue :1136,
- *                                   processValueBytes :1313, fillNulls :1401
+ *   pkg/sql/colfetcher/cfetcher.go  NextBatch :758 (MaxKeysPerRow == 1 path :937, unfinished rows :946-1020), processValue :1136,
+ *                                   processValueSingle :1280, processValueBytes :1313, fillNulls :1401,
+ *                                   getCurrentColumnFamilyID :1447
+ *   pkg/sql/colencoding             UnmarshalColumnValueToCol key_encoding.go:226
+ *   pkg/roachpb/data.go             extended encoding :288-289,336-338,436-489; GetBytes/GetFloat/GetBool/GetInt :689-790
+ *   pkg/sql/rowenc/index_encoding.go EncodePrimaryIndex :1169-1265 (what the encoder writes per family)
  */
 #include <math.h>
 #include <stdint.h>
@@ -304,22 +309,56 @@ static int64_t get_int(const ora_col *c, int64_t i) {
   }
 }
 
-/* Encode n rows as MVCCScan batch responses (decode.go:77-103 framing):
- *   key   = uvarint(table) uvarint(index) keycols... 0x88 | 0x00 wall[8] [logical[4]] (len+1)
- *   value = checksum[4] 0x0A {tag data}*   (NULL columns are omitted; explicit_null_every k > 0
- *           writes every k-th NULL as an explicit Null-typed entry, which is also legal input)
- * A new batch starts when the current one reaches max_batch_bytes.  Output: malloc'd bytes,
+/* Column families (descpb.ColumnFamilyDescriptor; fetchpb.IndexFetchSpec.{MaxKeysPerRow, MaxFamilyID,
+ * FamilyDefaultColumns}, index_fetch.proto:112-190).  NULL where a function takes one = a table with the single family 0. */
+typedef struct ora_kv_families {
+  int32_t n_families;             /* families in ID order; family_ids[0] == 0 (the sentinel family always exists) */
+  int32_t mvcc_header_every;      /* ENCODER: every k-th KV's value carries an MVCC extended-encoding header (0: never) */
+  const int32_t *family_ids;
+  const int32_t *default_col_ids; /* DefaultColumnID per family (0: none) */
+  const int32_t *val_family;      /* ENCODER: per value column of the table, index into family_ids */
+} ora_kv_families;
+
+static void put_value_header(bytebuf *val, int64_t salt, int tag, int ext_header) {
+  /* roachpb.Value.RawBytes: [extended prelude: BE32 header length, 0x65, header bytes] checksum[4] tag[1] (data.go:284-289,
+   * 316, 479-481).  The header bytes stand for a marshalled enginepb.MVCCValueHeader: the decoder skips them by length. */
+  if (ext_header) {
+    uint32_t hl = 3 + (uint32_t)(salt % 5);
+    bb_reserve(val, 5 + hl);
+    val->p[val->n++] = (uint8_t)(hl >> 24); val->p[val->n++] = (uint8_t)(hl >> 16); val->p[val->n++] = (uint8_t)(hl >> 8); val->p[val->n++] = (uint8_t)hl;
+    val->p[val->n++] = 101; /* ValueType_MVCC_EXTENDED_ENCODING_SENTINEL */
+    for (uint32_t i = 0; i < hl; i++) val->p[val->n++] = (uint8_t)(0x0a + i * 7 + (uint32_t)salt); /* arbitrary */
+  }
+  bb_reserve(val, 8);
+  uint32_t ck = (uint32_t)((uint64_t)salt * 2654435761u + 12345u); /* not verified by scans; must be skipped */
+  val->p[val->n++] = (uint8_t)(ck >> 24); val->p[val->n++] = (uint8_t)(ck >> 16); val->p[val->n++] = (uint8_t)(ck >> 8); val->p[val->n++] = (uint8_t)ck;
+  val->p[val->n++] = (uint8_t)tag;
+}
+
+/* Encode n rows as MVCCScan batch responses (decode.go:77-103 framing), the way rowenc.EncodePrimaryIndex writes a row
+ * (rowenc/index_encoding.go:1169-1265): one KV per column family in family-ID order,
+ *   key   = uvarint(table) uvarint(index) keycols... familysuffix | 0x00 wall[8] [logical[4]] (len+1)
+ *           familysuffix = 0x88 for family 0, else uvarint(id) uvarint(length of that encoding) (keys.go:950-961)
+ *   value = family 0 and families of several columns: checksum[4] 0x0A {tag data}* -- column ids as deltas from the previous
+ *           column OF THIS VALUE; NULL columns are omitted (explicit_null_every k > 0 writes every k-th NULL as an explicit
+ *           Null-typed entry, which is also legal input); a family != 0 whose tuple is empty writes no KV (:1247);
+ *           a family != 0 whose ONE column is its DefaultColumnID: valueside.MarshalLegacy -- checksum[4] tag data with
+ *           tag INT (stdlib varint; BOOL as 0/1), FLOAT (8 bytes big-endian) or BYTES (the raw bytes); no KV when NULL (:1203-1227).
+ * A new batch starts at a ROW boundary once the current one reaches max_batch_bytes.  Output: malloc'd bytes,
  * batch_offsets[nbatches+1]. */
-int ora_kv_encode(const ora_kv_table *t, const ora_col *key_cols, const ora_col *val_cols, int64_t n,
-                  int64_t max_batch_bytes, int32_t explicit_null_every, uint8_t **out, int64_t *out_len,
-                  int64_t **batch_offsets, int64_t *nbatches) {
+int ora_kv_encode2(const ora_kv_table *t, const ora_kv_families *fam, const ora_col *key_cols, const ora_col *val_cols, int64_t n,
+                   int64_t max_batch_bytes, int32_t explicit_null_every, uint8_t **out, int64_t *out_len,
+                   int64_t **batch_offsets, int64_t *nbatches) {
   bytebuf bb = {0, 0, 0};
   int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 2));
-  int64_t nb = 0, batch_start = 0, nulls_seen = 0;
+  int64_t nb = 0, batch_start = 0, nulls_seen = 0, kv_seq = 0;
   offs[0] = 0;
-  bytebuf key = {0, 0, 0}, val = {0, 0, 0};
+  bytebuf key = {0, 0, 0}, val = {0, 0, 0}, rowbuf = {0, 0, 0};
+  const int32_t zero = 0;
+  const int nfam = fam ? fam->n_families : 1;
   for (int64_t r = 0; r < n; r++) {
-    key.n = val.n = 0;
+    key.n = 0;
+    rowbuf.n = 0;
     bb_reserve(&key, 32);
     key.n += ora_enc_uvarint_asc(key.p + key.n, (uint64_t)t->table_id);
     key.n += ora_enc_uvarint_asc(key.p + key.n, (uint64_t)t->index_id);
@@ -345,71 +384,121 @@ int ora_kv_encode(const ora_kv_table *t, const ora_col *key_cols, const ora_col 
           key.n += desc ? ora_enc_varint_desc(key.p + key.n, get_int(col, r)) : ora_enc_varint_asc(key.p + key.n, get_int(col, r));
       }
     }
-    bb_reserve(&key, 16);
-    key.p[key.n++] = (uint8_t)intZero; /* family 0 (keys.go:950-961) */
-    key.p[key.n++] = 0x00;             /* MVCC sentinel */
-    put_be64(key.p + key.n, (uint64_t)(1600000000000000000ll + r)); key.n += 8;
-    if (r % 3 != 0) { /* with a logical component: 12-byte timestamp */
-      uint32_t lg = (uint32_t)(r % 1000);
-      key.p[key.n++] = (uint8_t)(lg >> 24); key.p[key.n++] = (uint8_t)(lg >> 16); key.p[key.n++] = (uint8_t)(lg >> 8); key.p[key.n++] = (uint8_t)lg;
-      key.p[key.n++] = 13;
-    } else key.p[key.n++] = 9;
-
-    bb_reserve(&val, 8);
-    uint32_t ck = (uint32_t)(r * 2654435761u + 12345u); /* not verified by scans; must be skipped */
-    val.p[val.n++] = (uint8_t)(ck >> 24); val.p[val.n++] = (uint8_t)(ck >> 16); val.p[val.n++] = (uint8_t)(ck >> 8); val.p[val.n++] = (uint8_t)ck;
-    val.p[val.n++] = ValueType_TUPLE;
-    int32_t last_id = 0;
-    for (int c = 0; c < t->n_val_cols; c++) {
-      const ora_col *col = &val_cols[c];
-      const int32_t id = t->val_col_ids[c];
-      if (is_null(col, r)) {
-        nulls_seen++;
-        if (explicit_null_every > 0 && nulls_seen % explicit_null_every == 0) {
-          bb_reserve(&val, 12);
-          val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Null);
+    const int64_t row_key_len = key.n;
+    for (int fi = 0; fi < nfam; fi++) {
+      const int32_t fam_id = fam ? fam->family_ids[fi] : 0;
+      const int32_t def_col = fam ? fam->default_col_ids[fi] : 0;
+      int ncols_in_fam = 0, only = -1;
+      for (int c = 0; c < t->n_val_cols; c++)
+        if ((fam ? fam->val_family[c] : zero) == fi) { ncols_in_fam++; only = c; }
+      const int ext = fam && fam->mvcc_header_every > 0 && kv_seq % fam->mvcc_header_every == 0;
+      val.n = 0;
+      if (fam_id != 0 && ncols_in_fam == 1 && t->val_col_ids[only] == def_col) { /* legacy single-column value */
+        const ora_col *col = &val_cols[only];
+        if (is_null(col, r)) continue; /* no KV */
+        switch (t->val_types[only]) {
+          case ORA_FLOAT64: {
+            put_value_header(&val, r * 7 + fi, 2 /* FLOAT */, ext);
+            uint64_t u; memcpy(&u, (const double *)col->data + r, 8);
+            bb_reserve(&val, 8); put_be64(val.p + val.n, u); val.n += 8;
+            break;
+          }
+          case ORA_BYTES: {
+            uint32_t a = col->offsets[r], e = col->offsets[r + 1];
+            put_value_header(&val, r * 7 + fi, 3 /* BYTES */, ext);
+            bb_reserve(&val, (int64_t)(e - a) + 1);
+            memcpy(val.p + val.n, (const uint8_t *)col->data + a, e - a); val.n += e - a;
+            break;
+          }
+          default: /* ints, dates, bool: Value.SetInt / SetBool (data.go) */
+            put_value_header(&val, r * 7 + fi, 1 /* INT */, ext);
+            bb_reserve(&val, 12);
+            val.n += ora_enc_stdlib_varint(val.p + val.n, get_int(col, r));
+        }
+      } else {
+        put_value_header(&val, r * 7 + fi, ValueType_TUPLE, ext);
+        const int64_t hdr = val.n;
+        int32_t last_id = 0;
+        for (int c = 0; c < t->n_val_cols; c++) {
+          if ((fam ? fam->val_family[c] : zero) != fi) continue;
+          const ora_col *col = &val_cols[c];
+          const int32_t id = t->val_col_ids[c];
+          if (is_null(col, r)) {
+            nulls_seen++;
+            if (explicit_null_every > 0 && nulls_seen % explicit_null_every == 0) {
+              bb_reserve(&val, 12);
+              val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Null);
+              last_id = id;
+            }
+            continue;
+          }
+          bb_reserve(&val, 32);
+          switch (t->val_types[c]) {
+            case ORA_BOOL:
+              val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), get_int(col, r) ? T_True : T_False);
+              break;
+            case ORA_FLOAT64: {
+              val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Float);
+              uint64_t u; memcpy(&u, (const double *)col->data + r, 8);
+              put_be64(val.p + val.n, u); val.n += 8;
+              break;
+            }
+            case ORA_BYTES: {
+              uint32_t a = col->offsets[r], e = col->offsets[r + 1];
+              val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Bytes);
+              bb_reserve(&val, (int64_t)(e - a) + 12);
+              val.n += ora_enc_nonsorting_uvarint(val.p + val.n, e - a);
+              memcpy(val.p + val.n, (const uint8_t *)col->data + a, e - a); val.n += e - a;
+              break;
+            }
+            default:
+              val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Int);
+              val.n += ora_enc_stdlib_varint(val.p + val.n, get_int(col, r));
+          }
           last_id = id;
         }
-        continue;
+        if (fam_id != 0 && val.n == hdr) continue; /* empty tuple of a later family: no KV (:1247) */
       }
-      bb_reserve(&val, 32);
-      switch (t->val_types[c]) {
-        case ORA_BOOL:
-          val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), get_int(col, r) ? T_True : T_False);
-          break;
-        case ORA_FLOAT64: {
-          val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Float);
-          uint64_t u; memcpy(&u, (const double *)col->data + r, 8);
-          put_be64(val.p + val.n, u); val.n += 8;
-          break;
-        }
-        case ORA_BYTES: {
-          uint32_t a = col->offsets[r], e = col->offsets[r + 1];
-          val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Bytes);
-          bb_reserve(&val, (int64_t)(e - a) + 12);
-          val.n += ora_enc_nonsorting_uvarint(val.p + val.n, e - a);
-          memcpy(val.p + val.n, (const uint8_t *)col->data + a, e - a); val.n += e - a;
-          break;
-        }
-        default:
-          val.n += ora_enc_value_tag(val.p + val.n, (uint32_t)(id - last_id), T_Int);
-          val.n += ora_enc_stdlib_varint(val.p + val.n, get_int(col, r));
+      /* the KV's key: row key + family suffix + MVCC timestamp */
+      key.n = row_key_len;
+      bb_reserve(&key, 32);
+      if (fam_id == 0) key.p[key.n++] = (uint8_t)intZero;
+      else {
+        int fl = ora_enc_uvarint_asc(key.p + key.n, (uint64_t)fam_id);
+        key.n += fl;
+        key.n += ora_enc_uvarint_asc(key.p + key.n, (uint64_t)fl);
       }
-      last_id = id;
+      key.p[key.n++] = 0x00; /* MVCC sentinel */
+      put_be64(key.p + key.n, (uint64_t)(1600000000000000000ll + r)); key.n += 8;
+      if (r % 3 != 0) { /* with a logical component: 12-byte timestamp */
+        uint32_t lg = (uint32_t)(r % 1000);
+        key.p[key.n++] = (uint8_t)(lg >> 24); key.p[key.n++] = (uint8_t)(lg >> 16); key.p[key.n++] = (uint8_t)(lg >> 8); key.p[key.n++] = (uint8_t)lg;
+        key.p[key.n++] = 13;
+      } else key.p[key.n++] = 9;
+      const int64_t rec = 8 + key.n + val.n;
+      bb_reserve(&rowbuf, rec);
+      uint32_t vl = (uint32_t)val.n, kl = (uint32_t)key.n;
+      memcpy(rowbuf.p + rowbuf.n, &vl, 4); memcpy(rowbuf.p + rowbuf.n + 4, &kl, 4); /* little-endian host */
+      memcpy(rowbuf.p + rowbuf.n + 8, key.p, (size_t)key.n);
+      memcpy(rowbuf.p + rowbuf.n + 8 + key.n, val.p, (size_t)val.n);
+      rowbuf.n += rec;
+      kv_seq++;
     }
-    const int64_t rec = 8 + key.n + val.n;
-    if (bb.n > batch_start && bb.n - batch_start + rec > max_batch_bytes) { offs[++nb] = bb.n; batch_start = bb.n; }
-    bb_reserve(&bb, rec);
-    uint32_t vl = (uint32_t)val.n, kl = (uint32_t)key.n;
-    memcpy(bb.p + bb.n, &vl, 4); memcpy(bb.p + bb.n + 4, &kl, 4); /* little-endian host */
-    memcpy(bb.p + bb.n + 8, key.p, (size_t)key.n);
-    memcpy(bb.p + bb.n + 8 + key.n, val.p, (size_t)val.n);
-    bb.n += rec;
+    /* rows stay whole inside a batch (kvpb.ScanOptions.WholeRowsOfSize for multi-family indexes) */
+    if (bb.n > batch_start && bb.n - batch_start + rowbuf.n > max_batch_bytes) { offs[++nb] = bb.n; batch_start = bb.n; }
+    bb_reserve(&bb, rowbuf.n);
+    memcpy(bb.p + bb.n, rowbuf.p, (size_t)rowbuf.n);
+    bb.n += rowbuf.n;
   }
   if (bb.n > batch_start || nb == 0) offs[++nb] = bb.n;
-  free(key.p); free(val.p);
+  free(key.p); free(val.p); free(rowbuf.p);
   *out = bb.p; *out_len = bb.n; *batch_offsets = offs; *nbatches = nb;
   return 0;
+}
+int ora_kv_encode(const ora_kv_table *t, const ora_col *key_cols, const ora_col *val_cols, int64_t n,
+                  int64_t max_batch_bytes, int32_t explicit_null_every, uint8_t **out, int64_t *out_len,
+                  int64_t **batch_offsets, int64_t *nbatches) {
+  return ora_kv_encode2(t, NULL, key_cols, val_cols, n, max_batch_bytes, explicit_null_every, out, out_len, batch_offsets, nbatches);
 }
 void ora_kv_free(void *p) { free(p); }
 
@@ -453,10 +542,148 @@ static uint8_t *kc_bytes_room(kvcol *c, int64_t len) {
   return c->buf + c->buflen;
 }
 
-/* Decode batch responses into columns.  Returns 0, or a negative code:
- * -1 truncated batch, -2 bad MVCC key, -3 key decode error, -4 value is not a TUPLE, -5 value decode error. */
-int ora_kv_decode(const ora_kv_fetch *f, const int32_t *out_types, const uint8_t *repr, const int64_t *batch_offsets,
-                  int64_t nbatches, ora_kv_result **res) {
+/* processValueBytes (cfetcher.go:1313-1399) over the TUPLE payload of one KV; returns 0 or -5 */
+static int process_value_bytes(const ora_kv_fetch *f, ora_kv_result *R, uint8_t *seen, int64_t row, const uint8_t *vb, int64_t vrem) {
+  int32_t last_id = 0;
+  int idx = 0, remaining = 0;
+  for (int c = 0; c < f->n_val_cols; c++) remaining += !seen[f->val_out[c]]; /* remainingValueColsByIdx */
+  while (vrem > 0 && remaining > 0) { /* :1342-1394 */
+    uint32_t delta; int typ;
+    int doff = dec_value_tag(vb, vrem, &delta, &typ);
+    if (doff < 0) return -5;
+    int32_t id = last_id + (int32_t)delta;
+    last_id = id;
+    int vec = -1;
+    for (; idx < f->n_val_cols; idx++) {
+      if (f->val_col_ids[idx] == id) { vec = idx++; break; }
+      if (f->val_col_ids[idx] > id) break;
+    }
+    if (vec < 0) { /* not requested: skip (:1365-1373) */
+      int64_t l = peek_value_len(vb, vrem, doff, typ);
+      if (l < 0 || l > vrem) return -5;
+      vb += l, vrem -= l;
+      continue;
+    }
+    kvcol *oc = &R->cols[f->val_out[vec]];
+    if (!seen[f->val_out[vec]]) remaining--;
+    seen[f->val_out[vec]] = 1;
+    if (typ == T_Null) { /* DecodeTableValueToCol value_encoding.go:35-38 */
+      kc_set_null(oc, row);
+      vb += doff, vrem -= doff;
+      continue;
+    }
+    const uint8_t *d = vb + doff;
+    int64_t drem = vrem - doff, used = 0;
+    switch (f->val_types[vec]) {
+      case ORA_BOOL:
+        if (typ != T_True && typ != T_False) return -5;
+        kc_set_fixed(oc, row, typ == T_True, 0);
+        break;
+      case ORA_FLOAT64: {
+        if (drem < 8) return -5;
+        uint64_t u = get_be64(d); double x; memcpy(&x, &u, 8);
+        kc_set_fixed(oc, row, 0, x); used = 8;
+        break;
+      }
+      case ORA_BYTES: {
+        uint64_t l; int n = ora_dec_nonsorting_uvarint(d, drem, &l);
+        if (n < 0 || (int64_t)l > drem - n) return -5;
+        uint8_t *dst = kc_bytes_room(oc, (int64_t)l);
+        memcpy(dst, d + n, (size_t)l);
+        oc->buflen += (int64_t)l; oc->off[row + 1] = (uint32_t)oc->buflen;
+        used = n + (int64_t)l;
+        break;
+      }
+      default: {
+        int64_t v; int n = ora_dec_stdlib_varint(d, drem, &v);
+        if (n < 0) return -5;
+        kc_set_fixed(oc, row, v, 0); used = n;
+      }
+    }
+    vb += doff + used, vrem -= doff + used;
+  }
+  return 0;
+}
+
+/* colencoding.UnmarshalColumnValueToCol (key_encoding.go:226-297) through roachpb.Value.GetInt / GetBool / GetFloat /
+ * GetBytes (data.go:689-790): `tag` and `data` are the simple value's tag byte and data bytes.  Returns 0 or -5. */
+static int unmarshal_single(kvcol *oc, int64_t row, int tag, const uint8_t *data, int64_t dlen) {
+  switch (oc->type) {
+    case ORA_BOOL: {
+      int64_t v;
+      if (tag != 1 /* INT */ || ora_dec_stdlib_varint(data, dlen, &v) <= 0 || v > 1 || v < 0) return -5;
+      kc_set_fixed(oc, row, v, 0);
+      return 0;
+    }
+    case ORA_FLOAT64: {
+      if (tag != 2 /* FLOAT */ || dlen != 8) return -5;
+      uint64_t u = get_be64(data); double x; memcpy(&x, &u, 8);
+      kc_set_fixed(oc, row, 0, x);
+      return 0;
+    }
+    case ORA_BYTES: {
+      if (tag != 3 /* BYTES */) return -5;
+      uint8_t *dst = kc_bytes_room(oc, dlen);
+      memcpy(dst, data, (size_t)dlen);
+      oc->buflen += dlen; oc->off[row + 1] = (uint32_t)oc->buflen;
+      return 0;
+    }
+    default: {
+      int64_t v;
+      if (tag != 1 /* INT */ || ora_dec_stdlib_varint(data, dlen, &v) <= 0) return -5;
+      kc_set_fixed(oc, row, v, 0);
+      return 0;
+    }
+  }
+}
+
+/* cFetcher.processValue (cfetcher.go:1136-1275, the primary-index branch :1168-1217) for one KV of family `family_id`.
+ * Returns 0, -4 ("single entry value with no default column", :1207-1212) or -5. */
+static int process_value(const ora_kv_fetch *f, const ora_kv_families *fam, ora_kv_result *R, uint8_t *seen, int64_t row,
+                         int32_t family_id, const uint8_t *val, int64_t vl) {
+  if (f->n_out == 0) return 0; /* :1162-1165 */
+  /* Value.GetTag / dataBytes with the MVCC extended encoding (data.go:336-338, 436-448, 479-489):
+   * [BE32 header length][0x65][header]checksum[4] tag[1] data */
+  int64_t simple = 0; /* where the simple value (checksum, tag, data) starts */
+  int extended = 0;
+  if (vl > 5 && val[4] == 101) {
+    extended = 1;
+    simple = 5 + (int64_t)(((uint32_t)val[0] << 24) | ((uint32_t)val[1] << 16) | ((uint32_t)val[2] << 8) | val[3]);
+  }
+  int tag = 0; /* ValueType_UNKNOWN */
+  if (!extended) { if (vl > 4) tag = val[4]; }
+  else if (vl > simple + 4) tag = val[simple + 4];
+  const uint8_t *data = val + simple + 5;
+  const int64_t dlen = vl - simple - 5;
+  if (tag == ValueType_TUPLE) return process_value_bytes(f, R, seen, row, data, dlen);
+  if (family_id == 0) return 0; /* the row sentinel of the pre-family format: no value expected (:1192-1196) */
+  int32_t def_col = 0;
+  int found = 0;
+  for (int i = 0; fam && i < fam->n_families; i++)
+    if (fam->family_ids[i] == family_id && fam->default_col_ids[i] != 0) { def_col = fam->default_col_ids[i]; found = 1; break; }
+  if (!found) return -4;
+  int vec = -1; /* orderedColIdxMap.Get(DefaultColumnID): -1 when the column is not fetched */
+  for (int c = 0; c < f->n_val_cols; c++)
+    if (f->val_col_ids[c] == def_col) vec = c;
+  if (vec < 0) return 0; /* processValueSingle :1285-1289 */
+  /* Value.IsPresent (data.go:396-411) */
+  if (vl == 0 || (extended && vl <= simple)) return 0;
+  if (dlen < 0) return -5;
+  const int rc = unmarshal_single(&R->cols[f->val_out[vec]], row, tag, data, dlen);
+  if (rc == 0) seen[f->val_out[vec]] = 1;
+  return rc;
+}
+
+/* Decode batch responses into columns: cFetcher.NextBatch's state machine (cfetcher.go:758-1093) over the concatenated
+ * KVs of all batches.  stateDecodeFirstKVOfRow (:806-944): the key columns are decoded, the bytes up to their end are
+ * the row prefix, the KV's value is processed; with MaxKeysPerRow == 1 the row is finished.  Otherwise
+ * stateFetchNextKVWithUnfinishedRow (:946-1020): a KV whose key does not start with the row prefix belongs to the next
+ * row; one that does contributes its family's columns, and the row's last possible family (MaxFamilyID) ends the row.
+ * stateFinalizeRow: fillNulls (:1401-1427).
+ * Returns 0, or a negative code: -1 truncated batch, -2 bad MVCC key, -3 key decode error, -4 a single-column value
+ * of a family without default column, -5 value decode error. */
+int ora_kv_decode2(const ora_kv_fetch *f, const ora_kv_families *fam, const int32_t *out_types, const uint8_t *repr,
+                   const int64_t *batch_offsets, int64_t nbatches, ora_kv_result **res) {
   ora_kv_result *R = (ora_kv_result *)calloc(1, sizeof(*R));
   R->ncols = f->n_out;
   R->cols = (kvcol *)calloc((size_t)(f->n_out > 0 ? f->n_out : 1), sizeof(kvcol));
@@ -464,6 +691,18 @@ int ora_kv_decode(const ora_kv_fetch *f, const int32_t *out_types, const uint8_t
   int64_t row = 0;
   int rc = 0;
   uint8_t *seen = (uint8_t *)calloc((size_t)(f->n_out > 0 ? f->n_out : 1), 1);
+  const int max_keys_per_row = fam ? fam->n_families : 1;
+  const int32_t max_family_id = fam && fam->n_families > 0 ? fam->family_ids[fam->n_families - 1] : 0;
+  int in_row = 0;                   /* stateFetchNextKVWithUnfinishedRow */
+  const uint8_t *row_prefix = NULL; /* lastRowPrefix, from KeyPrefixLength on */
+  int64_t row_prefix_len = 0;
+#define FINALIZE_ROW()                                               \
+  do {                                                               \
+    for (int c_ = 0; c_ < f->n_out; c_++)                            \
+      if (!seen[c_]) kc_set_null(&R->cols[c_], row);                 \
+    row++;                                                           \
+    in_row = 0;                                                      \
+  } while (0)
   for (int64_t bi = 0; bi < nbatches && rc == 0; bi++) {
     const uint8_t *p = repr + batch_offsets[bi];
     int64_t rem = batch_offsets[bi + 1] - batch_offsets[bi];
@@ -481,132 +720,91 @@ int ora_kv_decode(const ora_kv_fetch *f, const int32_t *out_types, const uint8_t
       const uint8_t *key = mk + f->key_prefix_len;
       int64_t klen = key_end - f->key_prefix_len;
       if (klen < 0) { rc = -3; break; }
-      for (int c = 0; c < f->n_out; c++) { kc_reserve(&R->cols[c], row + 1); seen[c] = 0; if (R->cols[c].type == ORA_BYTES) R->cols[c].off[row + 1] = (uint32_t)R->cols[c].buflen; }
-      /* DecodeKeyValsToCols key_encoding.go:43-81 */
-      for (int c = 0; c < f->n_key_cols && rc == 0; c++) {
-        const int desc = f->key_dirs[c];
-        const int oc = f->key_out[c];
-        if (klen <= 0) { rc = -3; break; }
-        if (key[0] == (desc ? encodedNullDesc : encodedNull)) { /* DecodeIfNull :101 */
-          if (oc >= 0) { kc_set_null(&R->cols[oc], row); seen[oc] = 1; }
-          key++, klen--;
-          continue;
-        }
-        int64_t n;
-        switch (f->key_types[c]) {
-          case ORA_FLOAT64: {
-            double d;
-            n = desc ? ora_dec_float_desc(key, klen, &d) : ora_dec_float_asc(key, klen, &d);
-            if (n < 0) { rc = -3; break; }
-            if (oc >= 0) kc_set_fixed(&R->cols[oc], row, 0, d);
-            break;
+      if (in_row && !(klen >= row_prefix_len && memcmp(key, row_prefix, (size_t)row_prefix_len) == 0))
+        FINALIZE_ROW(); /* the KV is from a different row (:975-981) */
+      int32_t family_id = 0;
+      if (!in_row) { /* stateDecodeFirstKVOfRow */
+        for (int c = 0; c < f->n_out; c++) { kc_reserve(&R->cols[c], row + 1); seen[c] = 0; if (R->cols[c].type == ORA_BYTES) R->cols[c].off[row + 1] = (uint32_t)R->cols[c].buflen; }
+        const uint8_t *key0 = key;
+        /* DecodeKeyValsToCols key_encoding.go:43-81 */
+        for (int c = 0; c < f->n_key_cols && rc == 0; c++) {
+          const int desc = f->key_dirs[c];
+          const int oc = f->key_out[c];
+          if (klen <= 0) { rc = -3; break; }
+          if (key[0] == (desc ? encodedNullDesc : encodedNull)) { /* DecodeIfNull :101 */
+            if (oc >= 0) { kc_set_null(&R->cols[oc], row); seen[oc] = 1; }
+            key++, klen--;
+            continue;
           }
-          case ORA_BYTES: {
-            int64_t dl;
-            n = ora_dec_bytes(key, klen, desc, NULL, &dl);
-            if (n < 0) { rc = -3; break; }
-            if (oc >= 0) {
-              uint8_t *dst = kc_bytes_room(&R->cols[oc], dl);
-              ora_dec_bytes(key, klen, desc, dst, &dl);
-              R->cols[oc].buflen += dl;
-              R->cols[oc].off[row + 1] = (uint32_t)R->cols[oc].buflen;
+          int64_t n;
+          switch (f->key_types[c]) {
+            case ORA_FLOAT64: {
+              double d;
+              n = desc ? ora_dec_float_desc(key, klen, &d) : ora_dec_float_asc(key, klen, &d);
+              if (n < 0) { rc = -3; break; }
+              if (oc >= 0) kc_set_fixed(&R->cols[oc], row, 0, d);
+              break;
             }
-            break;
-          }
-          default: {
-            int64_t v;
-            n = desc ? ora_dec_varint_desc(key, klen, &v) : ora_dec_varint_asc(key, klen, &v);
-            if (n < 0) { rc = -3; break; }
-            if (oc >= 0) kc_set_fixed(&R->cols[oc], row, v, 0);
-          }
-        }
-        if (rc) break;
-        if (oc >= 0) seen[oc] = 1;
-        key += n, klen -= n;
-      }
-      if (rc) break;
-      /* processValue cfetcher.go:1167-1190: RawBytes = checksum[4] tag[1] payload */
-      if (f->n_val_cols > 0) {
-        if (vl < 5) {
-          if (vl != 0) { rc = -4; break; }
-        } else {
-          if (val[4] != ValueType_TUPLE) { rc = -4; break; }
-          const uint8_t *vb = val + 5;
-          int64_t vrem = (int64_t)vl - 5;
-          int32_t last_id = 0;
-          int idx = 0, remaining = f->n_val_cols;
-          while (vrem > 0 && remaining > 0) { /* processValueBytes :1342-1394 */
-            uint32_t delta; int typ;
-            int doff = dec_value_tag(vb, vrem, &delta, &typ);
-            if (doff < 0) { rc = -5; break; }
-            int32_t id = last_id + (int32_t)delta;
-            last_id = id;
-            int vec = -1;
-            for (; idx < f->n_val_cols; idx++) {
-              if (f->val_col_ids[idx] == id) { vec = idx++; break; }
-              if (f->val_col_ids[idx] > id) break;
-            }
-            if (vec < 0) { /* not requested: skip (:1365-1373) */
-              int64_t l = peek_value_len(vb, vrem, doff, typ);
-              if (l < 0 || l > vrem) { rc = -5; break; }
-              vb += l, vrem -= l;
-              continue;
-            }
-            kvcol *oc = &R->cols[f->val_out[vec]];
-            seen[f->val_out[vec]] = 1;
-            remaining--;
-            if (typ == T_Null) { /* DecodeTableValueToCol value_encoding.go:35-38 */
-              kc_set_null(oc, row);
-              vb += doff, vrem -= doff;
-              continue;
-            }
-            const uint8_t *d = vb + doff;
-            int64_t drem = vrem - doff, used = 0;
-            switch (f->val_types[vec]) {
-              case ORA_BOOL:
-                if (typ != T_True && typ != T_False) { rc = -5; break; }
-                kc_set_fixed(oc, row, typ == T_True, 0);
-                break;
-              case ORA_FLOAT64: {
-                if (drem < 8) { rc = -5; break; }
-                uint64_t u = get_be64(d); double x; memcpy(&x, &u, 8);
-                kc_set_fixed(oc, row, 0, x); used = 8;
-                break;
+            case ORA_BYTES: {
+              int64_t dl;
+              n = ora_dec_bytes(key, klen, desc, NULL, &dl);
+              if (n < 0) { rc = -3; break; }
+              if (oc >= 0) {
+                uint8_t *dst = kc_bytes_room(&R->cols[oc], dl);
+                ora_dec_bytes(key, klen, desc, dst, &dl);
+                R->cols[oc].buflen += dl;
+                R->cols[oc].off[row + 1] = (uint32_t)R->cols[oc].buflen;
               }
-              case ORA_BYTES: {
-                uint64_t l; int n = ora_dec_nonsorting_uvarint(d, drem, &l);
-                if (n < 0 || (int64_t)l > drem - n) { rc = -5; break; }
-                uint8_t *dst = kc_bytes_room(oc, (int64_t)l);
-                memcpy(dst, d + n, (size_t)l);
-                oc->buflen += (int64_t)l; oc->off[row + 1] = (uint32_t)oc->buflen;
-                used = n + (int64_t)l;
-                break;
-              }
-              default: {
-                int64_t v; int n = ora_dec_stdlib_varint(d, drem, &v);
-                if (n < 0) { rc = -5; break; }
-                kc_set_fixed(oc, row, v, 0); used = n;
-              }
+              break;
             }
-            if (rc) break;
-            vb += doff + used, vrem -= doff + used;
+            default: {
+              int64_t v;
+              n = desc ? ora_dec_varint_desc(key, klen, &v) : ora_dec_varint_asc(key, klen, &v);
+              if (n < 0) { rc = -3; break; }
+              if (oc >= 0) kc_set_fixed(&R->cols[oc], row, v, 0);
+            }
           }
           if (rc) break;
+          if (oc >= 0) seen[oc] = 1;
+          key += n, klen -= n;
         }
+        if (rc) break;
+        row_prefix = key0; /* :857-858 */
+        row_prefix_len = key - key0;
+        if (max_family_id != 0) { /* getCurrentColumnFamilyID :1447-1467 */
+          uint64_t id;
+          if (ora_dec_uvarint_asc(key, klen, &id) < 0) { rc = -3; break; }
+          family_id = (int32_t)id;
+        }
+        rc = process_value(f, fam, R, seen, row, family_id, val, vl);
+        if (rc) break;
+        if (max_keys_per_row == 1) FINALIZE_ROW(); /* :937-941 */
+        else in_row = 1;
+      } else { /* another KV of the unfinished row (:983-1020) */
+        if (max_family_id != 0) {
+          uint64_t id;
+          if (ora_dec_uvarint_asc(key + row_prefix_len, klen - row_prefix_len, &id) < 0) { rc = -3; break; }
+          family_id = (int32_t)id;
+        }
+        rc = process_value(f, fam, R, seen, row, family_id, val, vl);
+        if (rc) break;
+        if (family_id == max_family_id) FINALIZE_ROW(); /* :1013-1016 */
       }
-      /* fillNulls cfetcher.go:1401-1427 */
-      for (int c = 0; c < f->n_out; c++)
-        if (!seen[c]) kc_set_null(&R->cols[c], row);
-      row++;
       p += 8 + (int64_t)kl + vl;
       rem -= 8 + (int64_t)kl + vl;
     }
   }
+  if (rc == 0 && in_row) FINALIZE_ROW(); /* no more KVs: the last row is complete (:953-968) */
+#undef FINALIZE_ROW
   free(seen);
   R->nrows = row;
   for (int c = 0; c < f->n_out; c++) R->cols[c].n = row;
   *res = R;
   return rc;
+}
+int ora_kv_decode(const ora_kv_fetch *f, const int32_t *out_types, const uint8_t *repr, const int64_t *batch_offsets,
+                  int64_t nbatches, ora_kv_result **res) {
+  return ora_kv_decode2(f, NULL, out_types, repr, batch_offsets, nbatches, res);
 }
 int32_t ora_kv_result_ncols(const ora_kv_result *r) { return r->ncols; }
 int64_t ora_kv_result_nrows(const ora_kv_result *r) { return r->nrows; }

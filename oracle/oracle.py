@@ -298,8 +298,29 @@ class OraKvFetch(C.Structure):
                 ("val_col_ids", C.c_void_p), ("val_types", C.c_void_p), ("val_out", C.c_void_p)]
 
 
+class OraKvFamilies(C.Structure):
+    _fields_ = [("n_families", C.c_int32), ("mvcc_header_every", C.c_int32), ("family_ids", C.c_void_p),
+                ("default_col_ids", C.c_void_p), ("val_family", C.c_void_p)]
+
+
 def _i32arr(xs):
     return np.ascontiguousarray(np.asarray(list(xs), dtype=np.int32))
+
+
+class KvFamilies:
+    """Column families of a table (descpb.ColumnFamilyDescriptor): family ids in increasing order starting with 0, the
+    DefaultColumnID of each (0: none) and, for the encoder, the family (an index into family_ids) of every value column.
+    mvcc_header_every k > 0: the encoder gives every k-th KV's value an MVCC extended-encoding header."""
+
+    def __init__(self, family_ids, default_col_ids, val_family=None, mvcc_header_every=0):
+        self.family_ids, self.default_col_ids = list(family_ids), list(default_col_ids)
+        self.val_family = list(val_family) if val_family is not None else []
+        self.mvcc_header_every = mvcc_header_every
+
+    def struct(self):
+        keep = [_i32arr(self.family_ids), _i32arr(self.default_col_ids), _i32arr(self.val_family or [0])]
+        return OraKvFamilies(len(self.family_ids), self.mvcc_header_every, keep[0].ctypes.data, keep[1].ctypes.data,
+                             keep[2].ctypes.data), keep
 
 
 def _kv_setup():
@@ -334,6 +355,11 @@ def _kv_setup():
     L.ora_kv_encode.restype = C.c_int
     L.ora_kv_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.ora_kv_encode2.restype = C.c_int
+    L.ora_kv_encode2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.ora_kv_decode2.restype = C.c_int
+    L.ora_kv_decode2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     L.ora_kv_free.argtypes = [C.c_void_p]
     L.ora_kv_decode.restype = C.c_int
     L.ora_kv_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
@@ -390,8 +416,9 @@ class KvTable:
         return len(kv_enc("uvarint_asc", self.table_id)) + len(kv_enc("uvarint_asc", self.index_id))
 
 
-def kv_encode(table: KvTable, key_vecs, val_vecs, max_batch_bytes=10 << 20, explicit_null_every=0):
-    """Rows -> (uint8 array of concatenated MVCCScan batch responses, int64 batch offsets[nbatches+1])."""
+def kv_encode(table: KvTable, key_vecs, val_vecs, max_batch_bytes=10 << 20, explicit_null_every=0, families=None):
+    """Rows -> (uint8 array of concatenated MVCCScan batch responses, int64 batch offsets[nbatches+1]).
+    families: a KvFamilies (one KV per family and row, rowenc.EncodePrimaryIndex); None: the single family 0."""
     L = _kv_setup()
     n = len(key_vecs[0]) if key_vecs else len(val_vecs[0])
     keep = [_i32arr(table.key_types), _i32arr(table.key_dirs), _i32arr(table.val_col_ids), _i32arr(table.val_types)]
@@ -400,8 +427,9 @@ def kv_encode(table: KvTable, key_vecs, val_vecs, max_batch_bytes=10 << 20, expl
     kc, _k1 = make_cols(key_vecs)
     vc, _k2 = make_cols(val_vecs)
     out, out_len, offs, nb = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
-    rc = L.ora_kv_encode(C.byref(t), kc, vc, n, max_batch_bytes, explicit_null_every, C.byref(out), C.byref(out_len),
-                         C.byref(offs), C.byref(nb))
+    fs, _fkeep = families.struct() if families is not None else (None, None)
+    rc = L.ora_kv_encode2(C.byref(t), C.byref(fs) if fs is not None else None, kc, vc, n, max_batch_bytes, explicit_null_every,
+                          C.byref(out), C.byref(out_len), C.byref(offs), C.byref(nb))
     assert rc == 0
     data = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(out_len.value, 1),))[:out_len.value].copy()
     offsets = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_int64)), shape=(nb.value + 1,)).copy()
@@ -416,8 +444,10 @@ class KvDecodeError(Exception):
         self.code = code
 
 
-def kv_decode(key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_types, val_out, out_types, data, offsets):
-    """cFetcher-style decode of batch responses -> list[Vec] (one per output ordinal)."""
+def kv_decode(key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_types, val_out, out_types, data, offsets,
+              families=None):
+    """cFetcher-style decode of batch responses -> list[Vec] (one per output ordinal).  families: a KvFamilies for
+    tables with several column families (rows of several KVs); None: the single family 0."""
     L = _kv_setup()
     keep = [_i32arr(key_types), _i32arr(key_dirs), _i32arr(key_out), _i32arr(val_col_ids), _i32arr(val_types),
             _i32arr(val_out), _i32arr(out_types)]
@@ -426,8 +456,9 @@ def kv_decode(key_prefix_len, key_types, key_dirs, key_out, val_col_ids, val_typ
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     res = C.c_void_p()
-    rc = L.ora_kv_decode(C.byref(f), keep[6].ctypes.data, data.ctypes.data if data.size else None, offsets.ctypes.data,
-                         len(offsets) - 1, C.byref(res))
+    fs, _fkeep = families.struct() if families is not None else (None, None)
+    rc = L.ora_kv_decode2(C.byref(f), C.byref(fs) if fs is not None else None, keep[6].ctypes.data,
+                          data.ctypes.data if data.size else None, offsets.ctypes.data, len(offsets) - 1, C.byref(res))
     if rc != 0:
         L.ora_kv_result_free(res)
         raise KvDecodeError(rc)

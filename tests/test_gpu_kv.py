@@ -15,8 +15,13 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def gpu_decode(prefix_len, kt, kd, ko, ids, vt, vo, out_types, data, offs):
-    d = dev.Decoder(prefix_len, kt, kd, ko, ids, vt, vo, out_types)
+def gpu_decode(prefix_len, kt, kd, ko, ids, vt, vo, out_types, data, offs, families=None):
+    """families: an oracle.KvFamilies -> IndexFetchSpec.MaxKeysPerRow / MaxFamilyID / FamilyDefaultColumns."""
+    kw = {}
+    if families is not None:
+        kw = dict(max_keys_per_row=len(families.family_ids), max_family_id=families.family_ids[-1],
+                  family_defaults=[(f, c) for f, c in zip(families.family_ids, families.default_col_ids) if c != 0])
+    d = dev.Decoder(prefix_len, kt, kd, ko, ids, vt, vo, out_types, **kw)
     pad = (-len(data)) % 16
     buf = dev.DeviceBuffer.from_numpy(np.concatenate([data, np.zeros(pad + 16, np.uint8)]))
     try:
@@ -104,10 +109,15 @@ def test_decode_errors_and_empty(oracle):
     assert e.value.code == _lib.ERR_INVALID and "truncated" in str(e.value)
     bad = data.copy()
     rec0_key_len = int.from_bytes(bytes(bad[4:8]), "little")
-    bad[8 + rec0_key_len + 4] = 3  # BYTES-tagged value where a TUPLE is expected
+    bad[8 + rec0_key_len + 4] = 3  # a BYTES-tagged value in family 0: the pre-family row sentinel, no value expected
+    out = gpu_decode(*args, bad, offs)  # (cfetcher.go:1192-1196): the column is NULL, as in the oracle
+    H.assert_vecs_equal(out, oracle.kv_decode(*args, bad, offs), "sentinel value")
+    assert out[1].to_values()[:3] == [None, 1, 2]
+    bad[8 + rec0_key_len + 5] = 0xff  # a TUPLE whose first tag never ends
+    bad[8 + rec0_key_len + 4] = 10
     with pytest.raises(_lib.CrgpuError) as e:
         gpu_decode(*args, bad, offs)
-    assert "TUPLE" in str(e.value) and "row 0" in str(e.value)
+    assert "value column decode error" in str(e.value) and "row 0" in str(e.value)
     with pytest.raises(_lib.CrgpuError):  # value column ids must increase
         dev.Decoder(2, [cd.INT64], [0], [0], [5, 3], [cd.INT64, cd.INT64], [1, 2], [cd.INT64] * 3)
 
@@ -169,3 +179,79 @@ def test_decode_one_large_batch_many_segments(oracle, walk_twice, monkeypatch):
     assert len(offs) == 2 and len(data) > 100 * 32 * 1024
     spec = (t.prefix_len(), kt, kd, [0, 1], ids, vt, [2, 3, 4], kt + vt)
     H.assert_vecs_equal(gpu_decode(*spec, data, offs), oracle.kv_decode(*spec, data, offs), "one batch, many segments")
+
+
+# ---------------------------------------------------------------- rows of several KVs: column families
+def test_decode_reference_kv_dump_with_families(oracle):
+    """docs/tech-notes/encoding.md:169-235 (tests/golden/encoding_vectors.json: kv_families_dump): two families, the second
+    one a single-column family whose KVs carry a BYTES-tagged value and are missing where the column is NULL."""
+    from tests.test_oracle_kv import _family_key, _record
+    with open(os.path.join(H.GOLDEN, "encoding_vectors.json")) as f:
+        dump = json.load(f)["kv_families_dump"]
+    data = b""
+    for kv in dump["kvs"]:
+        data += _record(_family_key(oracle, dump["table_id"], dump["index_id"], kv["id"], kv["family"]), bytes.fromhex(kv["value"]))
+    arr = np.frombuffer(data, dtype=np.uint8)
+    fam = oracle.KvFamilies([0, 1], [0, 2])
+    out = gpu_decode(2, [cd.INT64], [0], [0], [2], [cd.BYTES], [1], [cd.INT64, cd.BYTES], arr, [0, len(arr)], families=fam)
+    assert out[0].to_values() == [1, 2, 3, 4, 5]
+    assert out[1].to_values() == [None if o is None else o.encode() for o in dump["owner"]]
+
+
+@pytest.mark.parametrize("layout", ["tuple+singles", "two tuples", "sparse ids"])
+@pytest.mark.parametrize("mvcc_header_every,batch_bytes", [(0, 4 << 10), (3, 1 << 20)])
+def test_decode_families_matches_oracle(oracle, layout, mvcc_header_every, batch_bytes):
+    """Seeded tables with 2-4 column families (TUPLE families, INT / FLOAT / BYTES / BOOL single-column families, family
+    ids of one and several bytes), NULLs that suppress whole KVs, values behind MVCC extended headers: bit-exact against
+    the oracle's cFetcher state machine, all columns and a projection (a BYTES key column: the re-parsing BYTES pass)."""
+    from tests.test_oracle_kv import FAM_LAYOUTS
+    fam_ids, defaults, val_family = FAM_LAYOUTS[layout]
+    rng = np.random.default_rng(len(layout) * 3 + mvcc_header_every)
+    n = 30_000
+    kt, dirs = [cd.INT64, cd.BYTES], [0, 1]
+    vt = [cd.INT64, cd.FLOAT64, cd.BYTES, cd.BOOL, cd.INT16, cd.BYTES]
+    ids = [5, 6, 9, 10, 40, 300]
+    keys, vals = H.kv_random_rows(rng, n, kt, vt)
+    keys[0] = cd.Vec.from_numpy(cd.INT64, rng.permutation(n * 3)[:n].astype(np.int64) - n)
+    t = oracle.KvTable(106, 1, kt, dirs, ids, vt)
+    fam = oracle.KvFamilies(fam_ids, defaults, val_family, mvcc_header_every)
+    data, offs = oracle.kv_encode(t, keys, vals, max_batch_bytes=batch_bytes, explicit_null_every=3, families=fam)
+    full = (t.prefix_len(), kt, dirs, [0, 1], ids, vt, [2, 3, 4, 5, 6, 7], kt + vt)
+    got = gpu_decode(*full, data, offs, families=fam)
+    H.assert_vecs_equal(got, oracle.kv_decode(*full, data, offs, families=fam), "all columns")
+    H.assert_vecs_equal(got, [H.kv_key_canonical(k) for k in keys] + vals, "all columns vs source rows")
+    proj = (t.prefix_len(), kt, dirs, [-1, -1], [6, 10, 300], [vt[1], vt[3], vt[5]], [0, 2, 1], [cd.FLOAT64, cd.BYTES, cd.BOOL])
+    got = gpu_decode(*proj, data, offs, families=fam)  # no BYTES key column fetched: the copy pass
+    H.assert_vecs_equal(got, oracle.kv_decode(*proj, data, offs, families=fam), "projection")
+    H.assert_vecs_equal(got, [vals[1], vals[5], vals[3]], "projection vs source rows")
+
+
+def test_decode_families_errors(oracle):
+    """A single-column value of a family that has no default column is an error ("single entry value with no default
+    column", cfetcher.go:1207-1212); a wrong tag for the column's type too (Value.GetInt, data.go:781-790)."""
+    t = oracle.KvTable(60, 1, [cd.INT64], [0], [2, 3], [cd.INT64, cd.INT64])
+    k = cd.Vec.from_numpy(cd.INT64, np.arange(40, dtype=np.int64))
+    fam = oracle.KvFamilies([0, 1], [0, 3], [0, 1])
+    data, offs = oracle.kv_encode(t, [k], [k, k], families=fam)
+    args = (t.prefix_len(), [cd.INT64], [0], [0], [2, 3], [cd.INT64, cd.INT64], [1, 2], [cd.INT64] * 3)
+    H.assert_vecs_equal(gpu_decode(*args, data, offs, families=fam), [k, k, k], "two families")
+    nodefault = oracle.KvFamilies([0, 1], [0, 0], [0, 1])
+    with pytest.raises(_lib.CrgpuError) as e:
+        gpu_decode(*args, data, offs, families=nodefault)
+    assert "no default column" in str(e.value) and "row 0" in str(e.value)
+    with pytest.raises(oracle.KvDecodeError) as eo:
+        oracle.kv_decode(*args, data, offs, families=nodefault)
+    assert eo.value.code == -4
+    bad = data.copy()
+    kl0 = int.from_bytes(bytes(bad[4:8]), "little")
+    vl0 = int.from_bytes(bytes(bad[0:4]), "little")
+    rec1 = 8 + kl0 + vl0
+    kl1 = int.from_bytes(bytes(bad[rec1 + 4:rec1 + 8]), "little")
+    assert bad[rec1 + 8 + kl1 + 4] == 1  # INT-tagged single value of family 1
+    bad[rec1 + 8 + kl1 + 4] = 2          # ... now FLOAT-tagged: not what an INT column takes
+    with pytest.raises(_lib.CrgpuError) as e:
+        gpu_decode(*args, bad, offs, families=fam)
+    assert "value column decode error" in str(e.value)
+    with pytest.raises(oracle.KvDecodeError) as eo:
+        oracle.kv_decode(*args, bad, offs, families=fam)
+    assert eo.value.code == -5

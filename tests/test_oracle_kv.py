@@ -115,7 +115,63 @@ def test_decode_errors(oracle):
     assert e.value.code == -1
     bad = data.copy()
     rec0_key_len = int.from_bytes(bytes(bad[4:8]), "little")
-    bad[8 + rec0_key_len + 4] = 3  # value tag BYTES instead of TUPLE
-    with pytest.raises(oracle.KvDecodeError) as e:
-        oracle.kv_decode(*args, bad, offs)
-    assert e.value.code == -4
+    bad[8 + rec0_key_len + 4] = 3  # value tag BYTES instead of TUPLE in family 0: the row sentinel of the pre-family
+    out = oracle.kv_decode(*args, bad, offs)  # format, "a value is not expected" (cfetcher.go:1192-1196): the column is NULL
+    assert out[1].to_values() == [None, 1, 2, 3, 4] and out[0].to_values() == [0, 1, 2, 3, 4]
+
+
+def _family_key(oracle, table_id, index_id, pk, family):
+    key = oracle.kv_enc("uvarint_asc", table_id) + oracle.kv_enc("uvarint_asc", index_id) + oracle.kv_enc("varint_asc", pk)
+    if family == 0:
+        return key + b"\x88"  # keys.MakeFamilyKey: family 0 has no length suffix
+    fam = oracle.kv_enc("uvarint_asc", family)
+    return key + fam + oracle.kv_enc("uvarint_asc", len(fam))
+
+
+def test_decode_reference_kv_dump_with_families(oracle):
+    """docs/tech-notes/encoding.md:169-235: accounts(id, owner, balance) with FAMILY f0 (id, balance), FAMILY f1 (owner).
+    f1 holds one column that is its DefaultColumnID: its KVs carry a BYTES-tagged single value, and rows whose owner is
+    NULL have no f1 KV at all.  balance (DECIMAL, column 3) sits in f0's TUPLE and is skipped by its encoded length."""
+    dump = VEC["kv_families_dump"]
+    data = b""
+    for kv in dump["kvs"]:
+        data += _record(_family_key(oracle, dump["table_id"], dump["index_id"], kv["id"], kv["family"]), bytes.fromhex(kv["value"]))
+    arr = np.frombuffer(data, dtype=np.uint8)
+    fam = oracle.KvFamilies([0, 1], [0, 2])
+    out = oracle.kv_decode(2, [cd.INT64], [0], [0], [2], [cd.BYTES], [1], [cd.INT64, cd.BYTES], arr, [0, len(arr)], families=fam)
+    assert out[0].to_values() == [1, 2, 3, 4, 5]
+    assert out[1].to_values() == [None if o is None else o.encode() for o in dump["owner"]]
+
+
+FAM_LAYOUTS = {
+    # family ids, DefaultColumnID per family, family (index) of each of the six value columns 5, 6, 9, 10, 40, 300
+    "tuple+singles": ([0, 1, 4, 7], [0, 6, 40, 300], [0, 1, 0, 0, 2, 3]),   # three single-column families: FLOAT, INT16, BYTES
+    "two tuples": ([0, 3], [0, 0], [0, 1, 1, 0, 1, 0]),
+    "sparse ids": ([0, 130, 70000], [0, 10, 0], [0, 2, 2, 1, 0, 2]),          # family ids beyond one byte; BOOL single
+}
+
+
+@pytest.mark.parametrize("layout", sorted(FAM_LAYOUTS))
+@pytest.mark.parametrize("mvcc_header_every", [0, 3])
+def test_encode_decode_round_trip_families(oracle, layout, mvcc_header_every):
+    """Rows of several KVs: one per column family (rowenc.EncodePrimaryIndex), TUPLE values and single-column
+    ("legacy") values, KVs suppressed when all their columns are NULL, every third value behind an MVCC extended header."""
+    fam_ids, defaults, val_family = FAM_LAYOUTS[layout]
+    rng = np.random.default_rng(len(layout) + mvcc_header_every)
+    n = 4000
+    kt, dirs = [cd.INT64, cd.BYTES], [0, 1]
+    vt = [cd.INT64, cd.FLOAT64, cd.BYTES, cd.BOOL, cd.INT16, cd.BYTES]
+    ids = [5, 6, 9, 10, 40, 300]
+    keys, vals = H.kv_random_rows(rng, n, kt, vt)
+    keys[0] = cd.Vec.from_numpy(cd.INT64, rng.permutation(n * 3)[:n].astype(np.int64) - n)  # a primary key: unique, no NULLs
+    want_keys = [H.kv_key_canonical(k) for k in keys]
+    t = oracle.KvTable(106, 1, kt, dirs, ids, vt)
+    fam = oracle.KvFamilies(fam_ids, defaults, val_family, mvcc_header_every)
+    data, offs = oracle.kv_encode(t, keys, vals, max_batch_bytes=64 << 10, explicit_null_every=3, families=fam)
+    one, _ = oracle.kv_encode(t, keys, vals, max_batch_bytes=64 << 10, explicit_null_every=3)
+    assert len(offs) > 3 and len(data) > len(one)  # more KVs than rows
+    out = oracle.kv_decode(t.prefix_len(), kt, dirs, [0, 1], ids, vt, [2, 3, 4, 5, 6, 7], kt + vt, data, offs, families=fam)
+    H.assert_vecs_equal(out, want_keys + vals, "all columns")
+    out = oracle.kv_decode(t.prefix_len(), kt, dirs, [-1, 1], [6, 300], [vt[1], vt[5]], [0, 2], [cd.FLOAT64, cd.BYTES, cd.BYTES],
+                           data, offs, families=fam)
+    H.assert_vecs_equal(out, [vals[1], want_keys[1], vals[5]], "projection")
