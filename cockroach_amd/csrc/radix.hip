@@ -2002,7 +2002,7 @@ crgpu_status radix_probe(RadixTable &t, int jt, const RadixSrc &src_in, int64_t 
   const bool keeps_unmatched = jt == CRGPU_LEFT_OUTER || jt == CRGPU_LEFT_ANTI;
   if (partitioned) {
     // large probes skip the histogram pass (fixed-capacity cells); skewed keys and perfect-hash tables take the classic form
-    static const bool cells_on = env_flag_default_on("CRGPU_RADIX_CELLS");
+    const bool cells_on = env_flag_default_on("CRGPU_RADIX_CELLS");  // (read per probe: tests switch it)
     bool cells = false;
     if (cells_on && !t.chd && !t.cells_failed && n >= (int64_t(1) << 22) && n <= (int64_t(1) << 30)) {
       CRGPU_TRY(radix_partition_cells(t, src, n, &cells));

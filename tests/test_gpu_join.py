@@ -340,6 +340,56 @@ def test_join_direct_addressed_tables_at_real_thresholds(oracle, jt):
         assert np.array_equal(res[2].present()[order], hit) and np.array_equal(res[2].data[order][bp], pk[hit])
 
 
+@pytest.mark.parametrize("tables", ["hashed", "dense"])
+@pytest.mark.parametrize("skew", ["zipf", "burst"])
+def test_join_probe_cells_fall_back_to_histogram(monkeypatch, tables, skew):
+    """The probe side is scattered into fixed-capacity (partition, chunk) cells without a histogram pass; skewed keys
+    must take the histogram form instead.  zipf: the 65536-row sample sees the hot partitions and the cells are not
+    tried; burst: a key repeated 3000 times inside one 2^20-row chunk is invisible to the sample, overflows its cell,
+    the pass raises its flag and the probe is partitioned again with the histogram (radix.hip: radix_partition_cells ->
+    cells_failed).  Real thresholds (2^22 build rows), results against numpy row by row."""
+    from cockroach_amd import device as dev
+    if tables == "hashed":
+        monkeypatch.setenv("CRGPU_JOIN_DIRECT", "0")
+    rng = np.random.default_rng(5)
+    nb, npr = 1 << 22, (1 << 22) + (1 << 21)
+    bk = rng.permutation(nb).astype(np.int64)
+    bv = bk * 7 - 3
+    if skew == "zipf":
+        r = np.exp(rng.random(npr) * np.log(nb)).astype(np.int64).clip(1, nb - 1)
+        pk = (r * 0x9E3779B1) % nb
+    else:
+        pk = rng.integers(0, nb, size=npr, dtype=np.int64)
+        pk[(1 << 20) + 1000:(1 << 20) + 4000] = 123_457
+    pw = np.arange(npr, dtype=np.int64)
+    j = dev.Join(0, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], True, out_cols=[1, 3])
+    j.build([dev.upload(cd.Vec.from_numpy(cd.INT64, bk)), dev.upload(cd.Vec.from_numpy(cd.INT64, bv))], nb)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    pcols = [dev.upload(cd.Vec.from_numpy(cd.INT64, pk)), dev.upload(cd.Vec.from_numpy(cd.INT64, pw))]
+    for chunk in range(2):  # the second chunk goes straight to the histogram form (cells_failed is remembered)
+        res = j.probe(pcols, npr)
+        assert dev.prof_get("radix_probe_hist")[1] == chunk + 1, "expected the histogram form of the probe-side partition"
+        w_out, v_out = (o.data for o in dev.result_to_vecs(res))
+        assert res.n == npr
+        order = np.argsort(w_out, kind="stable")
+        assert np.array_equal(w_out[order], pw) and np.array_equal(v_out[order], pk * 7 - 3)
+    scatters = dev.prof_get("radix_probe_scatter")[1]
+    assert scatters == (3 if skew == "burst" else 2), "burst: the cells pass ran once and was thrown away"
+    dev.prof_enable(False)
+    j.close()
+    # and with the cells switched off through the environment (read per probe) the histogram form runs without a first try
+    monkeypatch.setenv("CRGPU_RADIX_CELLS", "0")
+    j = dev.Join(0, [cd.INT64, cd.INT64], [cd.INT64, cd.INT64], [0], [0], True, out_cols=[1, 3])
+    j.build([dev.upload(cd.Vec.from_numpy(cd.INT64, bk)), dev.upload(cd.Vec.from_numpy(cd.INT64, bv))], nb)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    res = j.probe(pcols, npr)
+    assert dev.prof_get("radix_probe_hist")[1] == 1 and dev.prof_get("radix_probe_scatter")[1] == 1 and res.n == npr
+    dev.prof_enable(False)
+    j.close()
+
+
 def test_join_radix_duplicate_build_keys_fall_back(oracle, radix_env):
     """A build side that is not unique (declared key or not) may overflow a sub-partition
     of the radix table; the joiner must then fall back to the classic table, not lose rows."""
