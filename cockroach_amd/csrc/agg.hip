@@ -432,6 +432,28 @@ __device__ __forceinline__ void pack_rows(const KeyCols &keys, const PackSpec &p
     }
   }
 }
+// A load at a 32-bit byte offset from a wave-uniform base: the scalar-base + 32-bit-vector-offset form of global_load,
+// one VGPR per address and no 64-bit address arithmetic (the offset of row r is shared by every column of one width).
+template <typename T>
+__device__ __forceinline__ T ld_at(const void *base, uint32_t byte_off) {
+  return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
+// Bounds-checked buffer loads: a column that is absent (a slot without an operand, a FILTER without a validity bitmap)
+// gets a descriptor of zero records -- its loads return 0 and touch no memory -- so the load sequence of a kernel is
+// the same straight-line code whatever the plan is.  (A load behind a wave-uniform branch would do as well for the
+// memory system, but its result merges with the other path's value at the join, and the compiler waits for the data
+// right there: every such branch ends the run of loads in flight.)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p != nullptr ? bytes : 0u, 0x00020000);
+}
+__device__ __forceinline__ unsigned long long buf_ld8(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(byte_off), 0, 0);
+  return (static_cast<unsigned long long>(v.y) << 32) | v.x;
+}
+__device__ __forceinline__ uint32_t buf_ld1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b8(r, static_cast<int>(byte_off), 0, 0);
+}
 __device__ __forceinline__ uint32_t pk_hash(unsigned long long k0, unsigned long long k1) {
 #ifdef CRGPU_PK_HASH_FMIX
   return static_cast<uint32_t>(fmix64(k0 ^ (k1 * 0x9FB21C651E98DF25ull)) >> 20);
@@ -1091,7 +1113,7 @@ struct SfIn {
   const double *y, *z;  // computed FLOAT64 inputs: value = op2(op1(x, y), z)
   int8_t op1, op2, type;
   int8_t p_sum, p_hi, p_min, p_max;  // planes of the partial table (-1: nobody needs that accumulation of this input)
-  int8_t _pad;
+  int8_t chain;  // agg_sf8_kernel: x is the value of the previous slot (no load)
 };
 struct SfOp {
   int8_t kind, in;  // in: index of the distinct input
@@ -1113,36 +1135,120 @@ struct SfArgs {
   const unsigned long long *meta;
   uint32_t mask, G, R, C;
   uint32_t nplanes, _pad;
+  uint32_t row_base, _pad2;  // agg_sf8_kernel: the launch covers rows [row_base, row_base + m) of the chunk
   unsigned long long plane_init[kSfMaxPlanes];
   uint32_t *miss_list;
   unsigned int *counters;
 };
 static_assert(sizeof(SfArgs) <= 4096, "kernel arguments are limited to 4 KiB");
 
-template <int NIN>
-__global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
-  extern __shared__ unsigned long long lds_words[];
-  const uint32_t plane = (a.G + 1) * a.R;  // G groups + the trash group, R replicas each
-  unsigned long long *cnt = lds_words;     // plane 0: rows; planes 1..: [nplanes][plane]
-  unsigned long long *t_k0 = lds_words + static_cast<size_t>(a.nplanes) * plane;
-  unsigned long long *t_k1 = t_k0 + a.C;
-  uint32_t *t_gid = reinterpret_cast<uint32_t *>(a.pack.two_words ? t_k1 + a.C : t_k1);
-  const KeyStore &store = a.store;
-  for (uint32_t i = threadIdx.x; i < a.C; i += blockDim.x) t_gid[i] = kGidDefer;
+// LDS layout of the sum-family kernels: planes [nplanes][(G + 1) * R] of 64-bit words (plane 0: rows), then the key table.
+struct SfLds {
+  unsigned long long *cnt, *t_k0, *t_k1;
+  uint32_t *t_gid;
+  uint32_t plane;
+};
+__device__ __forceinline__ SfLds sf_prologue(const SfArgs &a, unsigned long long *lds_words) {
+  SfLds L;
+  L.plane = (a.G + 1) * a.R;  // G groups + the trash group, R replicas each
+  L.cnt = lds_words;
+  L.t_k0 = lds_words + static_cast<size_t>(a.nplanes) * L.plane;
+  L.t_k1 = L.t_k0 + a.C;
+  L.t_gid = reinterpret_cast<uint32_t *>(a.pack.two_words ? L.t_k1 + a.C : L.t_k1);
+  for (uint32_t i = threadIdx.x; i < a.C; i += blockDim.x) L.t_gid[i] = kGidDefer;
   for (uint32_t p = 0; p < a.nplanes; p++) {
     const unsigned long long init = a.plane_init[p];
-    for (uint32_t i = threadIdx.x; i < plane; i += blockDim.x) lds_words[static_cast<size_t>(p) * plane + i] = init;
+    for (uint32_t i = threadIdx.x; i < L.plane; i += blockDim.x) lds_words[static_cast<size_t>(p) * L.plane + i] = init;
   }
   __syncthreads();
   for (uint32_t g = threadIdx.x; g < a.G; g += blockDim.x) {
     unsigned long long k0, k1;
-    if (!pack_group(store, a.pack, g, k0, k1)) continue;
+    if (!pack_group(a.store, a.pack, g, k0, k1)) continue;
     uint32_t idx = pk_hash(k0, k1) & (a.C - 1);
-    while (atomicCAS(&t_gid[idx], kGidDefer, g) != kGidDefer) idx = (idx + 1) & (a.C - 1);
-    t_k0[idx] = k0;
-    if (a.pack.two_words) t_k1[idx] = k1;
+    while (atomicCAS(&L.t_gid[idx], kGidDefer, g) != kGidDefer) idx = (idx + 1) & (a.C - 1);
+    L.t_k0[idx] = k0;
+    if (a.pack.two_words) L.t_k1[idx] = k1;
   }
   __syncthreads();
+  return L;
+}
+__device__ __forceinline__ void sf_merge(const SfArgs &a, unsigned long long *lds_words, const unsigned long long *cnt, uint32_t plane) {
+  __syncthreads();
+  // merge: the aggregations are told apart only here
+  const uint32_t pairs = a.G * static_cast<uint32_t>(a.nops);
+  for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
+    const uint32_t f = t / a.G, g = t - f * a.G;
+    const SfOp &op = a.ops[f];
+    unsigned long long c = 0;
+    for (uint32_t r = 0; r < a.R; r++) c += cnt[g * a.R + r];
+    if (c == 0) continue;
+    const SfIn &e = a.in[op.in >= 0 ? op.in : 0];
+    switch (op.kind) {
+      case ACC_COUNT_ROWS:
+      case ACC_COUNT: atomicAdd(&op.w0[g], c); break;
+      case ACC_SUM_F64:
+      case ACC_AVG_F64: {
+        const unsigned long long *ps = lds_words + static_cast<size_t>(e.p_sum) * plane + g * a.R;
+        double sm = 0;
+        for (uint32_t r = 0; r < a.R; r++) sm += __longlong_as_double(static_cast<long long>(ps[r]));
+        unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[g]), sm);
+        if (op.kind == ACC_AVG_F64) atomicAdd(&op.w1[g], c);
+        else op.seen[g] = 1;
+        break;
+      }
+      case ACC_SUM_I128: {
+        const unsigned long long *pl = lds_words + static_cast<size_t>(e.p_sum) * plane + g * a.R;
+        const unsigned long long *ph = lds_words + static_cast<size_t>(e.p_hi) * plane + g * a.R;
+        unsigned long long lo = 0, hi = 0;
+        for (uint32_t r = 0; r < a.R; r++) {
+          const unsigned long long sl = lo + pl[r];
+          hi += ph[r] + (sl < lo ? 1ull : 0ull);
+          lo = sl;
+        }
+        add_i128(&op.w0[g], &op.w1[g], lo, hi);
+        op.seen[g] = 1;
+        break;
+      }
+      case ACC_MIN_I64:
+      case ACC_MAX_I64:
+      case ACC_BOOL_AND:
+      case ACC_BOOL_OR: {
+        const bool is_min = op.kind == ACC_MIN_I64 || op.kind == ACC_BOOL_AND;
+        const unsigned long long *pm = lds_words + static_cast<size_t>(is_min ? e.p_min : e.p_max) * plane + g * a.R;
+        long long m = static_cast<long long>(pm[0]);
+        for (uint32_t r = 1; r < a.R; r++) {
+          const long long x = static_cast<long long>(pm[r]);
+          m = is_min ? (x < m ? x : m) : (x > m ? x : m);
+        }
+        if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(&op.w0[g]), m);
+        else if (op.kind == ACC_MAX_I64) atomicMax(reinterpret_cast<long long *>(&op.w0[g]), m);
+        else if (op.kind == ACC_BOOL_AND) { if (m == 0) atomicAnd(&op.w0[g], 0ull); }
+        else { if (m != 0) atomicOr(&op.w0[g], 1ull); }
+        op.seen[g] = 1;
+        break;
+      }
+      default: {  // MIN / MAX over FLOAT64 (ordered words)
+        const bool is_min = op.kind == ACC_MIN_F64;
+        const unsigned long long *pm = lds_words + static_cast<size_t>(is_min ? e.p_min : e.p_max) * plane + g * a.R;
+        unsigned long long m = pm[0];
+        for (uint32_t r = 1; r < a.R; r++) m = is_min ? (pm[r] < m ? pm[r] : m) : (pm[r] > m ? pm[r] : m);
+        if (is_min) atomicMin(&op.w0[g], m);
+        else atomicMax(&op.w0[g], m);
+        op.seen[g] = 1;
+        break;
+      }
+    }
+  }
+}
+
+template <int NIN>
+__global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
+  extern __shared__ unsigned long long lds_words[];
+  const SfLds L = sf_prologue(a, lds_words);
+  const uint32_t plane = L.plane;
+  unsigned long long *cnt = L.cnt, *t_k0 = L.t_k0, *t_k1 = L.t_k1;
+  uint32_t *t_gid = L.t_gid;
+  const KeyStore &store = a.store;
   const uint32_t rep = threadIdx.x & (a.R - 1);
   const uint32_t trash = a.G * a.R + rep;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
@@ -1309,70 +1415,281 @@ __global__ __launch_bounds__(1024) void agg_sumfam_kernel(SfArgs a) {
       }
     }
   }
+  sf_merge(a, lds_words, cnt, plane);
+}
+
+// ------------------------------------------------------------------ the same pass, every load requested up front
+// agg_sumfam_kernel walks its inputs one after the other: a projected input waits for its operands before the next
+// input's loads are issued, then the FILTER column, then each key column (BYTES: offsets, then payload) -- about
+// eight dependent memory round trips per iteration, and the Q1 pass ran at 1.7 us per trip (3.2 TB/s).  This form
+// covers the common shape -- one or two NULL-free key columns, all BYTES (KB) or all 8 bytes wide; COUNT_ROWS, COUNT,
+// SUM and AVG over NULL-free FLOAT64 inputs -- with two trips per iteration:
+//   trip 1  key values / BYTES offsets, the FILTER column, every input and operand column
+//   trip 2  the BYTES payload of the keys
+// The inputs arrive as SLOTS (sf8_slots): a slot loads its x or takes the previous slot's value (`chain`), then
+// applies at most one operation with a loaded operand y -- price, price * (1 - disc), price * (1 - disc) * (1 + tax)
+// are three consecutive slots and four loads.  Absent columns are zero-record buffer descriptors (buf_rsrc); rows
+// are addressed by 32-bit byte offsets from wave-uniform bases: one address register per row and column width.
+static constexpr int kSf8Rows = 2;  // rows per thread and iteration
+__host__ __device__ constexpr uint32_t kSf8Planes(int nin) { return static_cast<uint32_t>((nin + 1) | 1); }  // count + one sum per slot, odd
+template <int NIN, int NK, bool KB>
+__global__ __launch_bounds__(1024) void agg_sf8_kernel(SfArgs a) {
+  // LDS: the partial table, interleaved -- word (g * R + rep) * NPL + p, p = 0 the row count, p = 1 + c the sum of slot c
+  // (NPL odd: lanes 56 bytes apart spread over the banks) -- so that the atomics of a row share ONE address register
+  // and differ in the instruction's immediate offset; then the key table as in sf_prologue.
+  extern __shared__ unsigned long long lds_words[];
+  constexpr uint32_t NPL = kSf8Planes(NIN);
+  const uint32_t cells = (a.G + 1) * a.R;  // G groups + the trash group, R replicas each
+  unsigned long long *t_k0 = lds_words + static_cast<size_t>(cells) * NPL;
+  unsigned long long *t_k1 = t_k0 + a.C;
+  uint32_t *t_gid = reinterpret_cast<uint32_t *>(a.pack.two_words ? t_k1 + a.C : t_k1);
+  for (uint32_t i = threadIdx.x; i < a.C; i += blockDim.x) t_gid[i] = kGidDefer;
+  for (uint32_t i = threadIdx.x; i < cells * NPL; i += blockDim.x) lds_words[i] = 0;
   __syncthreads();
-  // merge: the aggregations are told apart only here
+  for (uint32_t g = threadIdx.x; g < a.G; g += blockDim.x) {
+    unsigned long long k0, k1;
+    if (!pack_group(a.store, a.pack, g, k0, k1)) continue;
+    uint32_t idx = pk_hash(k0, k1) & (a.C - 1);
+    while (atomicCAS(&t_gid[idx], kGidDefer, g) != kGidDefer) idx = (idx + 1) & (a.C - 1);
+    t_k0[idx] = k0;
+    if (a.pack.two_words) t_k1[idx] = k1;
+  }
+  __syncthreads();
+  const uint32_t rep = threadIdx.x & (a.R - 1);
+  const uint32_t trash = a.G * a.R + rep;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  const int64_t mround = (a.m + 63) & ~int64_t(63);
+  // FILTER: an INT64 column compared with a constant (cf_kind 2) or a BOOL column (1), each with an optional bitmap;
+  // the comparison as three wave-uniform masks (which of <, ==, > pass)
+  const uint8_t *fvalid = a.cf_kind == 2 ? a.cf_sel.valid : (a.cf_kind == 1 ? a.cf_valid : nullptr);
+  const int cmp = a.cf_sel.cmp;
+  const bool want_lt = cmp == SEL_LT || cmp == SEL_LE || cmp == SEL_NE, want_eq = cmp == SEL_EQ || cmp == SEL_LE || cmp == SEL_GE,
+             want_gt = cmp == SEL_GT || cmp == SEL_GE || cmp == SEL_NE;
+  for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i0 < mround; i0 += stride * kSf8Rows) {
+    uint32_t row[kSf8Rows], off8[kSf8Rows];  // (a chunk has at most 2^28 rows)
+    bool ok[kSf8Rows], live[kSf8Rows];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) {
+      const int64_t i = i0 + k * stride;
+      live[k] = ok[k] = i < a.m;
+      row[k] = ok[k] ? static_cast<uint32_t>(i) : 0u;
+      off8[k] = row[k] << 3;
+    }
+    // ---- trip 1
+    unsigned long long kv[NK][kSf8Rows];
+    uint32_t a0[NK][kSf8Rows], len[NK][kSf8Rows];
+#pragma unroll
+    for (int c = 0; c < NK; c++) {
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) {
+        if (KB) {
+          a0[c][k] = ld_at<uint32_t>(a.keys.c[c].offsets, row[k] << 2);
+          len[c][k] = ld_at<uint32_t>(a.keys.c[c].offsets + 1, row[k] << 2);
+          kv[c][k] = 0;
+        } else {
+          kv[c][k] = ld_at<unsigned long long>(a.keys.c[c].data, off8[k]);
+          a0[c][k] = len[c][k] = 0;
+        }
+      }
+    }
+    // (a column that is absent leaves its registers undefined -- __builtin_nondeterministic_value -- so that the join
+    // behind the wave-uniform branch needs no copy of the loaded value: a copy there would wait for the load)
+    long long fx[kSf8Rows];
+    uint32_t fb[kSf8Rows], fvb[kSf8Rows];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) {
+      fx[k] = __builtin_nondeterministic_value(fx[k]);
+      fb[k] = __builtin_nondeterministic_value(fb[k]);
+      fvb[k] = __builtin_nondeterministic_value(fvb[k]);
+    }
+    if (a.cf_kind == 2) {
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) fx[k] = ld_at<long long>(a.cf_sel.data, off8[k]);
+    } else if (a.cf_kind == 1) {
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) fb[k] = ld_at<uint8_t>(a.cf_data, row[k]);
+    }
+    if (fvalid != nullptr) {
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) fvb[k] = ld_at<uint8_t>(fvalid, row[k] >> 3);
+    }
+    unsigned long long v[NIN][kSf8Rows];
+    double y[NIN][kSf8Rows];
+#pragma unroll
+    for (int c = 0; c < NIN; c++) {
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) {
+        v[c][k] = __builtin_nondeterministic_value(v[c][k]);
+        y[c][k] = __builtin_nondeterministic_value(y[c][k]);
+      }
+      if (c == 0 || !a.in[c].chain) {
+#pragma unroll
+        for (int k = 0; k < kSf8Rows; k++) v[c][k] = ld_at<unsigned long long>(a.in[c].x, off8[k]);
+      }
+      if (a.in[c].op1 >= 0) {
+#pragma unroll
+        for (int k = 0; k < kSf8Rows; k++) y[c][k] = ld_at<double>(a.in[c].y, off8[k]);
+      }
+    }
+    // ---- trip 2: the payload of BYTES keys, {length:4, up to 7 bytes} (pack_rows); byte j of every row is one
+    // unconditional load (rows shorter than j + 1 re-read their last byte, empty ones the offsets array)
+    if (KB) {
+#pragma unroll
+      for (int c = 0; c < NK; c++) {
+        const uint32_t bb = static_cast<uint32_t>(a.pack.c[c].bbytes);
+#pragma unroll
+        for (int k = 0; k < kSf8Rows; k++) {
+          len[c][k] -= a0[c][k];
+          if (len[c][k] > bb) ok[k] = false;
+        }
+      }
+      bool any_left = false;
+#pragma unroll
+      for (int c = 0; c < NK; c++) {
+#pragma unroll
+        for (int k = 0; k < kSf8Rows; k++) {
+          if (!ok[k]) len[c][k] = 0;  // (also the rows another column made unpackable, and the rows past the end)
+          kv[c][k] = len[c][k];
+          any_left |= len[c][k] > 0;
+        }
+      }
+      for (uint32_t j = 0; __any(any_left); j++) {
+        uint32_t b[NK][kSf8Rows];
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+#pragma unroll
+          for (int k = 0; k < kSf8Rows; k++) {
+            const uint32_t l = len[c][k];
+            const uint32_t at_data = a0[c][k] + (j < l ? j : l - 1);
+            b[c][k] = l ? ld_at<uint8_t>(a.keys.c[c].data, at_data) : ld_at<uint8_t>(a.keys.c[c].offsets, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every byte load is in flight before the first one is used
+        any_left = false;
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+#pragma unroll
+          for (int k = 0; k < kSf8Rows; k++) {
+            if (j < len[c][k]) kv[c][k] |= static_cast<unsigned long long>(b[c][k]) << (4 + 8 * j);
+            any_left |= j + 1 < len[c][k];
+          }
+        }
+      }
+    }
+    // ---- values, FILTER, packed key
+#pragma unroll
+    for (int c = 0; c < NIN; c++) {
+      const int op = a.in[c].op1;
+      if (c > 0 && a.in[c].chain) {
+#pragma unroll
+        for (int k = 0; k < kSf8Rows; k++) v[c][k] = v[c > 0 ? c - 1 : 0][k];
+      }
+      if (op >= 0) {
+#pragma unroll
+        for (int k = 0; k < kSf8Rows; k++)
+          v[c][k] = static_cast<unsigned long long>(__double_as_longlong(ex_apply(op, __longlong_as_double(static_cast<long long>(v[c][k])), y[c][k])));
+      }
+    }
+    bool pass[kSf8Rows];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) {
+      pass[k] = live[k];
+      if (fvalid != nullptr) pass[k] = pass[k] && ((fvb[k] >> (row[k] & 7)) & 1u) != 0;
+      if (a.cf_kind == 2) pass[k] = pass[k] && ((want_lt && fx[k] < a.cf_sel.cst) || (want_eq && fx[k] == a.cf_sel.cst) || (want_gt && fx[k] > a.cf_sel.cst));
+      else if (a.cf_kind == 1) pass[k] = pass[k] && fb[k] != 0;
+    }
+    unsigned long long k0[kSf8Rows], k1[kSf8Rows];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) k0[k] = k1[k] = 0;
+#pragma unroll
+    for (int c = 0; c < NK; c++) {
+      const PackCol &pc = a.pack.c[c];
+      const bool canon = !KB && a.keys.c[c].type == CRGPU_FLOAT64;
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) {
+        unsigned long long w = kv[c][k];
+        const double f = __longlong_as_double(static_cast<long long>(w));
+        if (canon) w = f != f ? 0x7FF8000000000000ull : (f == 0 ? 0ull : w);
+        if (pc.word) k1[k] |= w << pc.shift;
+        else k0[k] |= w << pc.shift;
+      }
+    }
+    uint32_t gid[kSf8Rows], idx[kSf8Rows], g0[kSf8Rows];
+    unsigned long long q0[kSf8Rows], q1[kSf8Rows];
+    bool need[kSf8Rows], more = false;
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) idx[k] = pk_hash(k0[k], k1[k]) & (a.C - 1);
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) g0[k] = t_gid[idx[k]];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) q0[k] = t_k0[idx[k]];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) q1[k] = a.pack.two_words ? t_k1[idx[k]] : k1[k];
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) {
+      const bool occupied = ok[k] && g0[k] != kGidDefer;
+      const bool hit = occupied && q0[k] == k0[k] && q1[k] == k1[k];
+      gid[k] = hit ? g0[k] : kGidDefer;
+      need[k] = occupied && !hit;
+      more |= need[k];
+    }
+    if (__any(more)) {
+#pragma unroll
+      for (int k = 0; k < kSf8Rows; k++) {
+        if (!need[k]) continue;
+        uint32_t ix = (idx[k] + 1) & (a.C - 1);
+        for (;;) {
+          const uint32_t g = t_gid[ix];
+          if (g == kGidDefer) break;
+          if (t_k0[ix] == k0[k] && (!a.pack.two_words || t_k1[ix] == k1[k])) {
+            gid[k] = g;
+            break;
+          }
+          ix = (ix + 1) & (a.C - 1);
+        }
+      }
+    }
+    // rows the LDS key table does not resolve (unpackable key, new group) go to the resolve pass through the miss list
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) {
+      const bool miss = live[k] && gid[k] == kGidDefer;
+      const uint64_t mm = __ballot(miss);
+      if (mm) {
+        const int lead = __ffsll(static_cast<long long>(mm)) - 1;
+        unsigned int base = 0;
+        if (lane_id() == static_cast<uint32_t>(lead)) base = atomicAdd(&a.counters[1], static_cast<unsigned int>(popc64(mm)));
+        base = __shfl(base, lead, 64);
+        if (miss) a.miss_list[base + rank_in_mask(mm)] = row[k] + a.row_base;
+      }
+    }
+    // rows that do not contribute update the trash group: straight-line code
+#pragma unroll
+    for (int k = 0; k < kSf8Rows; k++) {
+      const uint32_t at = ((pass[k] && gid[k] < a.G) ? gid[k] * a.R + rep : trash) * NPL;
+      atomicAdd(lds_words + at, 1ull);
+#pragma unroll
+      for (int c = 0; c < NIN; c++)
+        unsafeAtomicAdd(reinterpret_cast<double *>(lds_words + at + 1 + c), __longlong_as_double(static_cast<long long>(v[c][k])));
+    }
+  }
+  __syncthreads();
+  // merge: the aggregations are told apart only here (COUNT_ROWS / COUNT / AVG's count: plane 0; SUM / AVG: their slot's)
   const uint32_t pairs = a.G * static_cast<uint32_t>(a.nops);
   for (uint32_t t = threadIdx.x; t < pairs; t += blockDim.x) {
     const uint32_t f = t / a.G, g = t - f * a.G;
     const SfOp &op = a.ops[f];
+    const unsigned long long *w = lds_words + static_cast<size_t>(g) * a.R * NPL;
     unsigned long long c = 0;
-    for (uint32_t r = 0; r < a.R; r++) c += cnt[g * a.R + r];
+    for (uint32_t r = 0; r < a.R; r++) c += w[r * NPL];
     if (c == 0) continue;
-    const SfIn &e = a.in[op.in >= 0 ? op.in : 0];
-    switch (op.kind) {
-      case ACC_COUNT_ROWS:
-      case ACC_COUNT: atomicAdd(&op.w0[g], c); break;
-      case ACC_SUM_F64:
-      case ACC_AVG_F64: {
-        const unsigned long long *ps = lds_words + static_cast<size_t>(e.p_sum) * plane + g * a.R;
-        double sm = 0;
-        for (uint32_t r = 0; r < a.R; r++) sm += __longlong_as_double(static_cast<long long>(ps[r]));
-        unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[g]), sm);
-        if (op.kind == ACC_AVG_F64) atomicAdd(&op.w1[g], c);
-        else op.seen[g] = 1;
-        break;
-      }
-      case ACC_SUM_I128: {
-        const unsigned long long *pl = lds_words + static_cast<size_t>(e.p_sum) * plane + g * a.R;
-        const unsigned long long *ph = lds_words + static_cast<size_t>(e.p_hi) * plane + g * a.R;
-        unsigned long long lo = 0, hi = 0;
-        for (uint32_t r = 0; r < a.R; r++) {
-          const unsigned long long sl = lo + pl[r];
-          hi += ph[r] + (sl < lo ? 1ull : 0ull);
-          lo = sl;
-        }
-        add_i128(&op.w0[g], &op.w1[g], lo, hi);
-        op.seen[g] = 1;
-        break;
-      }
-      case ACC_MIN_I64:
-      case ACC_MAX_I64:
-      case ACC_BOOL_AND:
-      case ACC_BOOL_OR: {
-        const bool is_min = op.kind == ACC_MIN_I64 || op.kind == ACC_BOOL_AND;
-        const unsigned long long *pm = lds_words + static_cast<size_t>(is_min ? e.p_min : e.p_max) * plane + g * a.R;
-        long long m = static_cast<long long>(pm[0]);
-        for (uint32_t r = 1; r < a.R; r++) {
-          const long long x = static_cast<long long>(pm[r]);
-          m = is_min ? (x < m ? x : m) : (x > m ? x : m);
-        }
-        if (op.kind == ACC_MIN_I64) atomicMin(reinterpret_cast<long long *>(&op.w0[g]), m);
-        else if (op.kind == ACC_MAX_I64) atomicMax(reinterpret_cast<long long *>(&op.w0[g]), m);
-        else if (op.kind == ACC_BOOL_AND) { if (m == 0) atomicAnd(&op.w0[g], 0ull); }
-        else { if (m != 0) atomicOr(&op.w0[g], 1ull); }
-        op.seen[g] = 1;
-        break;
-      }
-      default: {  // MIN / MAX over FLOAT64 (ordered words)
-        const bool is_min = op.kind == ACC_MIN_F64;
-        const unsigned long long *pm = lds_words + static_cast<size_t>(is_min ? e.p_min : e.p_max) * plane + g * a.R;
-        unsigned long long m = pm[0];
-        for (uint32_t r = 1; r < a.R; r++) m = is_min ? (pm[r] < m ? pm[r] : m) : (pm[r] > m ? pm[r] : m);
-        if (is_min) atomicMin(&op.w0[g], m);
-        else atomicMax(&op.w0[g], m);
-        op.seen[g] = 1;
-        break;
-      }
+    if (op.kind == ACC_COUNT_ROWS || op.kind == ACC_COUNT) {
+      atomicAdd(&op.w0[g], c);
+    } else {
+      double sm = 0;
+      for (uint32_t r = 0; r < a.R; r++) sm += __longlong_as_double(static_cast<long long>(w[r * NPL + 1 + op.in]));
+      unsafeAtomicAdd(reinterpret_cast<double *>(&op.w0[g]), sm);
+      if (op.kind == ACC_AVG_F64) atomicAdd(&op.w1[g], c);
+      else op.seen[g] = 1;
     }
   }
 }
@@ -3313,6 +3630,98 @@ static void launch_sumfam_n(const SfArgs &args, dim3 grid, dim3 block, size_t ld
   }
   hipLaunchKernelGGL(agg_sumfam_kernel<NIN>, grid, block, lds, st, args);
 }
+template <int NIN, int NK, bool KB>
+static void launch_sf8_nk(const SfArgs &args, int blk, int wgs_per_cu, size_t lds, hipStream_t st) {
+  static DeviceOnce attr_set;  // per instantiation
+  if (attr_set.need()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_sf8_kernel<NIN, NK, KB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(kLdsMax));
+    attr_set.mark();
+  }
+  const int64_t per_wg = static_cast<int64_t>(blk) * kSf8Rows * 2;
+  int64_t want = (args.m + per_wg - 1) / per_wg;
+  if (want < 1) want = 1;
+  const int64_t max_grid = static_cast<int64_t>(num_cus()) * wgs_per_cu;  // resident workgroups only: each strides over the chunk
+  hipLaunchKernelGGL((agg_sf8_kernel<NIN, NK, KB>), dim3(static_cast<unsigned int>(want < max_grid ? want : max_grid)), dim3(blk), lds, st, args);
+}
+template <int NIN>
+static void launch_sf8_n(const SfArgs &args, int nk, bool kb, int blk, int wgs_per_cu, size_t lds, hipStream_t st) {
+  if (nk == 1 && kb) launch_sf8_nk<NIN, 1, true>(args, blk, wgs_per_cu, lds, st);
+  else if (nk == 1) launch_sf8_nk<NIN, 1, false>(args, blk, wgs_per_cu, lds, st);
+  else if (kb) launch_sf8_nk<NIN, 2, true>(args, blk, wgs_per_cu, lds, st);
+  else launch_sf8_nk<NIN, 2, false>(args, blk, wgs_per_cu, lds, st);
+}
+// Slots of agg_sf8_kernel from the deduplicated inputs: plain columns first, each followed by the projections that
+// extend it (x, then x op1 y, then (x op1 y) op2 z as consecutive slots; a two-operation input without its one-operation
+// prefix among the inputs gets a slot nobody accumulates).  false: more than kSfMaxIn slots.
+static bool sf8_slots(SfArgs &args, int nin) {
+  SfIn slots[kSfMaxIn];
+  int slot_of[kSfMaxIn];
+  bool placed[kSfMaxIn] = {};
+  int n = 0;
+  auto emit = [&](const void *x, bool chain, int op, const double *y, int type, int acc) -> bool {
+    if (n == kSfMaxIn) return false;
+    SfIn &t = slots[n];
+    std::memset(&t, 0, sizeof(t));
+    t.x = x;
+    t.y = y;
+    t.op1 = static_cast<int8_t>(op);
+    t.op2 = -1;
+    t.type = static_cast<int8_t>(type);
+    t.chain = chain ? 1 : 0;
+    t.p_sum = t.p_hi = t.p_min = t.p_max = -1;
+    if (acc >= 0) {
+      const SfIn &e = args.in[acc];
+      t.p_sum = e.p_sum, t.p_hi = e.p_hi, t.p_min = e.p_min, t.p_max = e.p_max;
+      slot_of[acc] = n;
+      placed[acc] = true;
+    }
+    n++;
+    return true;
+  };
+  auto one_op_over = [&](const void *x) {
+    for (int i = 0; i < nin; i++)
+      if (!placed[i] && args.in[i].x == x && args.in[i].op1 >= 0 && args.in[i].op2 < 0) return i;
+    return -1;
+  };
+  auto two_op_over = [&](const void *x, int op1, const double *y) {  // op1 < 0: any first operation
+    for (int i = 0; i < nin; i++)
+      if (!placed[i] && args.in[i].x == x && args.in[i].op2 >= 0 && (op1 < 0 || (args.in[i].op1 == op1 && args.in[i].y == y))) return i;
+    return -1;
+  };
+  auto extend = [&](const void *x, int type) -> bool {  // the previous slot holds the column x
+    const int j = one_op_over(x);
+    if (j >= 0) {
+      if (!emit(nullptr, true, args.in[j].op1, args.in[j].y, type, j)) return false;
+      const int k = two_op_over(x, args.in[j].op1, args.in[j].y);
+      return k < 0 || emit(nullptr, true, args.in[k].op2, args.in[k].z, type, k);
+    }
+    const int k = two_op_over(x, -1, nullptr);
+    if (k < 0) return true;
+    return emit(nullptr, true, args.in[k].op1, args.in[k].y, type, -1) && emit(nullptr, true, args.in[k].op2, args.in[k].z, type, k);
+  };
+  for (int i = 0; i < nin; i++) {
+    if (placed[i] || args.in[i].op1 >= 0) continue;
+    if (!emit(args.in[i].x, false, -1, nullptr, args.in[i].type, i) || !extend(args.in[i].x, args.in[i].type)) return false;
+  }
+  for (int i = 0; i < nin; i++) {
+    if (placed[i] || args.in[i].op2 >= 0) continue;
+    const SfIn e = args.in[i];
+    if (!emit(e.x, false, e.op1, e.y, e.type, i)) return false;
+    const int k = two_op_over(e.x, e.op1, e.y);
+    if (k >= 0 && !emit(nullptr, true, args.in[k].op2, args.in[k].z, e.type, k)) return false;
+  }
+  for (int i = 0; i < nin; i++) {
+    if (placed[i]) continue;
+    const SfIn e = args.in[i];
+    if (!emit(e.x, false, e.op1, e.y, e.type, -1) || !emit(nullptr, true, e.op2, e.z, e.type, i)) return false;
+  }
+  for (int f = 0; f < args.nops; f++)
+    if (args.ops[f].in >= 0) args.ops[f].in = static_cast<int8_t>(slot_of[args.ops[f].in]);
+  for (int i = 0; i < n; i++) args.in[i] = slots[i];
+  args._pad = static_cast<uint32_t>(n);  // (the planes are unchanged: slots only reorder who feeds them)
+  return n > 0;
+}
 static crgpu_status try_sumfam(crgpu_agg *a, const PassInput &in, uint32_t *miss_list, const AccPlan &plan, bool *done) {
   *done = false;
   static const bool enabled = [] { const char *v = std::getenv("CRGPU_AGG_SUMFAM"); return v == nullptr || v[0] != '0'; }();
@@ -3437,12 +3846,83 @@ static crgpu_status try_sumfam(crgpu_agg *a, const PassInput &in, uint32_t *miss
   args.C = plan.C;
   args.miss_list = miss_list;
   args.counters = a->counters.as<unsigned int>();
+  hipStream_t st = stream();
+  // the loads-up-front form: one or two NULL-free key columns, 8-byte inputs, rows addressable by 32-bit byte offsets
+  static const bool sf8_on = [] { const char *v = std::getenv("CRGPU_AGG_SF8"); return v == nullptr || v[0] != '0'; }();
+  bool sf8 = sf8_on && in.m < (int64_t(1) << 32) && (in.keys.n == 1 || in.keys.n == 2);
+  bool key_bytes = false;  // key form: every column BYTES, or every column 8 bytes wide
+  for (int c = 0; sf8 && c < in.keys.n; c++) {
+    const DCol &kc = in.keys.c[c];
+    const bool is_b = kc.type == CRGPU_BYTES;
+    sf8 = kc.valid == nullptr && (is_b || type_width(kc.type) == 8) && (c == 0 || is_b == key_bytes);
+    key_bytes = is_b;
+  }
+  for (int i = 0; sf8 && i < nin; i++) sf8 = args.in[i].type == CRGPU_FLOAT64;
+  for (int f = 0; sf8 && f < nops; f++) {
+    const int kd = args.ops[f].kind;
+    sf8 = kd == ACC_COUNT_ROWS || kd == ACC_COUNT || kd == ACC_SUM_F64 || kd == ACC_AVG_F64;
+  }
+  if (sf8) {
+    SfArgs a8 = args;
+    a8.nops = nops;
+    if (sf8_slots(a8, nin)) {
+      const int nslots = static_cast<int>(a8._pad);
+      a8._pad = 0;
+      // 16 waves per CU (measured: 46 B/row streams at 5.8 TB/s with 4 waves per SIMD, 4.6-4.8 with 7-8): 4 workgroups of
+      // 256 threads while the partial table fits a quarter of the LDS; lane-private replicas (64) when they fit
+      const size_t per_rep8 = static_cast<size_t>(kSf8Planes(nslots)) * (G + 1) * 8;
+      if (per_rep8 + table > kLdsLarge) return CRGPU_OK;  // (cannot happen before the generic form refuses: it has more planes)
+      uint32_t R8 = 1;
+      while (R8 < 64u && per_rep8 * (R8 * 2) + table <= 36u * 1024u) R8 *= 2;
+      const size_t lds8 = ((per_rep8 * R8 + table) + 15) & ~size_t(15);
+      const int wgs8 = lds8 <= 36u * 1024u ? 4 : lds8 <= 76u * 1024u ? 2 : 1;
+      const int blk8 = 1024 / wgs8;
+      a8.R = R8;
+      ProfScope prof("agg_fused_sumfam");
+      // the kernel addresses rows by 32-bit byte offsets: one launch per 2^28 rows, the column bases moved along
+      // (the launches share the miss list and its counter; nothing is read back in between)
+      const int64_t kSeg = int64_t(1) << 28;
+      for (int64_t base = 0; base < in.m; base += kSeg) {
+        SfArgs s8 = a8;
+        s8.m = in.m - base < kSeg ? in.m - base : kSeg;
+        s8.row_base = static_cast<uint32_t>(base);
+        for (int c = 0; c < in.keys.n; c++) {
+          DCol &kc = s8.keys.c[c];
+          if (kc.type == CRGPU_BYTES) kc.offsets += base;
+          else kc.data = static_cast<const uint8_t *>(kc.data) + base * 8;
+        }
+        for (int i = 0; i < nslots; i++) {
+          if (s8.in[i].x != nullptr) s8.in[i].x = static_cast<const uint8_t *>(s8.in[i].x) + base * 8;
+          if (s8.in[i].y != nullptr) s8.in[i].y += base;
+        }
+        if (s8.cf_kind == 2) {
+          s8.cf_sel.data += base;
+          if (s8.cf_sel.valid != nullptr) s8.cf_sel.valid += base >> 3;
+        } else if (s8.cf_kind == 1) {
+          s8.cf_data += base;
+          if (s8.cf_valid != nullptr) s8.cf_valid += base >> 3;
+        }
+        switch (nslots) {
+          case 1: launch_sf8_n<1>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          case 2: launch_sf8_n<2>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          case 3: launch_sf8_n<3>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          case 4: launch_sf8_n<4>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          case 5: launch_sf8_n<5>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          case 6: launch_sf8_n<6>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          case 7: launch_sf8_n<7>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+          default: launch_sf8_n<8>(s8, in.keys.n, key_bytes, blk8, wgs8, lds8, st); break;
+        }
+        CRGPU_HIP(hipGetLastError());
+      }
+      *done = true;
+      return CRGPU_OK;
+    }
+  }
   const int64_t per_wg = static_cast<int64_t>(blk) * kAccRows * 2;
   int64_t want = (in.m + per_wg - 1) / per_wg;
   if (want < 1) want = 1;
   const int64_t max_grid = static_cast<int64_t>(num_cus()) * wgs_per_cu;
   const dim3 grid(static_cast<unsigned int>(want < max_grid ? want : max_grid)), block(blk);
-  hipStream_t st = stream();
   ProfScope prof("agg_fused_sumfam");
   switch (nin) {
     case 1: launch_sumfam_n<1>(args, grid, block, lds, st); break;
@@ -3979,8 +4459,10 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
     // 2^16 rows, then 2^22 (refines the share of new groups, which picks claim-first or look-first), then 2^27
     // (a first chunk that found hardly any new group per row -- a low-cardinality GROUP BY -- needs no refinement: every
     // chunk costs ~0.15 ms of launches and read-backs, a third of the time of a Q1-shaped pass over 2^27 rows)
+    // (settled with few groups: chunks of up to 2^30 rows -- the fused LDS pass has no per-row temporaries besides the
+    // 4-byte miss list)
     const bool settled = a->seq > 0 && a->new_ratio < 1e-3;
-    const int64_t kChunk = (a->seq >= (1u << 22) || settled) ? int64_t(1) << 27 : int64_t(1) << 22;
+    const int64_t kChunk = settled && a->ngroups <= 4096 ? int64_t(1) << 30 : (a->seq >= (1u << 22) || settled) ? int64_t(1) << 27 : int64_t(1) << 22;
     int64_t len = n - pos < kChunk ? n - pos : kChunk;
     if (a->seq == 0 && len > 16384 && n > (int64_t(1) << 20)) len = 16384;  // (a small input is one chunk: discovery would cost more than it can save)
     std::vector<DCol> chunk = in;
