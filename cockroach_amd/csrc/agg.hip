@@ -4034,9 +4034,12 @@ static crgpu_status read_counters(crgpu_agg *a, unsigned int *out2) {
 
 static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, int64_t remaining) {
   hipStream_t st = stream();
-  // BYTES key payload / BYTES ANY_NOT_NULL values: reserve room for every byte of the chunk
+  // BYTES key payload / BYTES ANY_NOT_NULL values: room for every byte of the chunk, reserved when the chunk turns out
+  // to have rows the fused pass did not place (only those can append): a steady-state chunk skips the read-back
   // (all the boundary offsets are requested together: one wait per chunk, not one per column)
-  {
+  bool reserved = false;
+  auto reserve_bytes = [&]() -> crgpu_status {
+    reserved = true;
     std::vector<const DCol *> bcols;
     for (size_t k = 0; k < a->ks.size(); k++)
       if (cols[a->group_cols[k]].type == CRGPU_BYTES) bcols.push_back(&cols[a->group_cols[k]]);
@@ -4062,7 +4065,9 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
       CRGPU_TRY(op.any_buf.ensure(static_cast<size_t>(op.any_tail + (bounds[2 * i + 1] - bounds[2 * i]) + 16), true));
       i++;
     }
-  }
+    return CRGPU_OK;
+  };
+  if (a->need_any_fix || a->ngroups == 0) CRGPU_TRY(reserve_bytes());  // (value stores may be appended to by any pass)
   CRGPU_TRY(upload_descriptors(a, &cols));  // the chunk's column pointers are part of the op descriptors
 
   PassInput in;
@@ -4094,6 +4099,10 @@ static crgpu_status consume_chunk(crgpu_agg *a, const std::vector<DCol> &cols, i
   }
   for (int round = 0; in.m > 0; round++) {
     if (round >= 40) return fail(CRGPU_ERR_HIP, "crgpu_dev_agg_consume: deferred rows did not converge");
+    if (!reserved) {
+      CRGPU_TRY(reserve_bytes());
+      if (a->descriptors_dirty) CRGPU_TRY(upload_descriptors(a, &cols));
+    }
     // index capacity: at most half full after the expected (later rounds: worst-case) number of new groups
     uint64_t est = static_cast<uint64_t>(in.m);
     if (round == 0 && a->new_ratio < 1.0) {
