@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--q9-sf", type=float, default=0.0,
                     help="scale factor of the distributed TPC-H Q9 leg (BASELINE.json configs[3]); 0: SF100 on N > 1 GPUs, "
                          "SF10 for --force-distributed with one rank")
-    ap.add_argument("--variant", default="hit100", choices=["hit100", "hit50", "zipf", "null1"],
+    ap.add_argument("--variant", default="hit100", choices=["hit100", "hit50", "zipf", "null1", "sparse"],
                     help="probe-key variants of config J (SURVEY.md 8(d)): 100%% hit (the headline), 50%% hit, "
                          "Zipf-like skew (theta=1), 1%% NULL probe keys")
     return ap.parse_args(argv)
@@ -158,9 +158,9 @@ def cpu_baseline_pway(lb, lp, P):
                       f"(ora_distribute, {t_route:.1f} s), then {P} joiner threads (ora_hash_join per bucket), {dt:.1f} s in all"}
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02", "bench_J_pmc_summary.txt")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03", "bench_J_pmc_summary.txt")
 KERNEL_SYMBOL = {"join_probe": "radix_probe_kernel<0, 0", "radix_build_split": "radix_split_kernel",
-                 "radix_build_table": "radix_table_kernel"}
+                 "radix_build_table": "_table_kernel"}
 
 
 def pmc_traffic(prof_name, streamed_read_bytes):
@@ -241,6 +241,13 @@ def main(argv=None):
         bits = (~isnull).view(-1, 8).to(torch.uint8)  # coldata.Nulls: bit = 1 => present, LSB first
         pk_valid = (bits * (2 ** torch.arange(8, device=device, dtype=torch.uint8))).sum(1, dtype=torch.uint8).contiguous()
     pw = torch.arange(npr, device=device, dtype=torch.int64) + rank * npr
+    pk_base = pk  # the key's position in the dense domain: what the result check reasons about
+    if args.variant == "sparse":
+        # the same 100 %-hit workload over keys 7919 apart: the build keys are not dense, so the join takes the hashed
+        # (cuckoo) sub-partition tables instead of the direct-addressed ones
+        bk = bk * 7919 + 13
+        bv = bk * 3 + 1
+        pk = pk * 7919 + 13
     torch.cuda.synchronize()
 
     I64 = cd.INT64
@@ -298,7 +305,7 @@ def main(argv=None):
     # The union of all ranks' build keys is a permutation of [0, nb * world) (rank r holds k * world + r), so a probe row
     # hits iff its key is below nb * world (and not NULL): what THIS rank's probe rows must contribute to the output of
     # the whole job -- rows, sum(v) = sum(3k + 1), sum(w) -- is known from its inputs, wherever the exchange sent them.
-    hit = pk < nb * world
+    hit = pk_base < nb * world
     if args.variant == "null1":
         hit = hit & ~isnull
     want = torch.stack([hit.sum(), ((pk * 3 + 1) * hit).sum(), (pw * hit).sum()]).to(torch.int64)
@@ -354,7 +361,7 @@ def main(argv=None):
             "data": "synthetic",
             "config": {"workload": f"hash join microbench: int64 keys, 2^{args.log2_build} build x "
                                    f"2^{args.log2_probe} probe rows per GPU, INNER, unique build keys, "
-                                   f"{ {'hit100': '100% hit', 'hit50': '50% hit', 'zipf': 'Zipf-like probe keys (theta=1)', 'null1': '1% NULL probe keys'}[args.variant]}, "
+                                   f"{ {'hit100': '100% hit', 'hit50': '50% hit', 'zipf': 'Zipf-like probe keys (theta=1)', 'null1': '1% NULL probe keys', 'sparse': '100% hit, build keys 7919 apart (hashed tables)'}[args.variant]}, "
                                    "output (w, v)",
                        "parallelism": "single GPU" if world == 1 else f"hash repartition all-to-all over {world} GPUs",
                        "result_check": "ok" if ok else "MISMATCH"},
@@ -376,7 +383,7 @@ def main(argv=None):
         for h in (part_b, part_p, xch_p):
             h.close()
         part_b = part_p = xch_p = None
-        del bk, bv, pk, pw, res, _b, _p, w_out, v_out, hit
+        del bk, bv, pk, pk_base, pw, res, _b, _p, w_out, v_out, hit
         torch.cuda.empty_cache()
         _lib.load().crgpu_mem_trim()
         q9 = None
@@ -568,7 +575,12 @@ def other_paths(device_index):
         out["tpch_q3_q9_sf10"] = [
             {k: r[k] for k in ("case", "rows", "groups", "ms", "rows_per_s", "algorithmic_bytes", "frac_of_8TBps", "kernels_ms",
                                "result_check", "cpu_baseline")}
-            for r in load("bench_tpch").measure(10.0, reps=3, cpu_sf=0.05, device_index=device_index)]
+            for r in load("bench_tpch").measure(10.0, reps=3, cpu_sf=1.0, device_index=device_index)]
+        torch.cuda.empty_cache()
+        _lib_trim()
+        # north_star's sizes on one GPU: Q1 in full on 6e8 rows, Q9 at SF100 (scripts/bench_sf100.py); the Q1 line's
+        # cpu_baseline is BASELINE.json configs[0] (SF1 Q1 on the CPU)
+        out["tpch_sf100_one_gpu"] = load("bench_sf100").measure(device_index, reps=3, cpu=True, q9_sf=100.0)
         torch.cuda.empty_cache()
         _lib_trim()
         misc = load("bench_misc")

@@ -107,6 +107,7 @@ SYMBOLS = [
     ("crgpu_shutdown", None, []),
     ("crgpu_last_error", C.c_char_p, []),
     ("crgpu_mem_usage", _I64, []),
+    ("crgpu_handle_mem_usage", _I32, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("crgpu_live_handles", _I64, []),
     ("crgpu_mem_cached", _I64, []),
     ("crgpu_mem_trim", None, []),

@@ -2792,7 +2792,16 @@ __global__ __launch_bounds__(256) void agg_finish_small_kernel(FinSmallArgs a) {
   const FinSmallCol &c = a.c[blockIdx.x];
   const AggOpDev &op = a.ops[blockIdx.x];
   const int ng = a.ngroups;
-  if (!c.bytes) {
+  if (c.bytes == 2) {  // SUM over INT: 16 bytes per group
+    for (int s = threadIdx.x; s < ng; s += 256) {
+      const uint8_t p = op.seen[s];
+      reinterpret_cast<unsigned long long *>(c.out_data)[2 * s] = p ? op.w0[s] : 0ull;
+      reinterpret_cast<unsigned long long *>(c.out_data)[2 * s + 1] = p ? op.w1[s] : 0ull;
+      c.out_offsets[s] = 16u * static_cast<uint32_t>(s);
+      present[s] = p;
+    }
+    if (threadIdx.x == 0) c.out_offsets[ng] = 16u * static_cast<uint32_t>(ng);
+  } else if (!c.bytes) {
     for (int s = threadIdx.x; s < ng; s += 256) {
       uint8_t p;
       const unsigned long long v = finalize_value(op, c.out_type, c.key_data, c.key_present, a.err, s, &p);
@@ -2832,6 +2841,19 @@ __global__ __launch_bounds__(256) void agg_finish_small_kernel(FinSmallArgs a) {
     uint32_t bits = 0;
     for (int j = 0; j < 8 && b * 8 + j < ng; j++) bits |= (present[b * 8 + j] ? 1u : 0u) << j;
     c.out_valid[b] = static_cast<uint8_t>(bits);
+  }
+}
+
+// SUM over INT (AggOpHost::dec128): row s of the BYTES output is the 16 bytes {lo, hi} of group s's exact total
+__global__ __launch_bounds__(256) void agg_sum128_out_kernel(const unsigned long long *__restrict__ lo, const unsigned long long *__restrict__ hi,
+                                                             const uint8_t *__restrict__ seen, int64_t ngroups,
+                                                             unsigned long long *__restrict__ out, uint8_t *__restrict__ present_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t s = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; s < ngroups; s += stride) {
+    const uint8_t p = seen[s];
+    out[2 * s] = p ? lo[s] : 0ull;
+    out[2 * s + 1] = p ? hi[s] : 0ull;
+    present_out[s] = p;
   }
 }
 
@@ -2904,6 +2926,7 @@ struct AggOpHost {
   // FILTER as a selection: filter_col is then an INT64 column compared with f_cst
   int f_cmp = -1;
   long long f_cst = 0;
+  bool dec128 = false;  // SUM over an integer column: the exact 128-bit total goes out as 16 bytes (little endian)
   int lw0 = -1, lw1 = -1, lseen = -1;
   bool has_w0 = false, has_w1 = false, has_seen = false;
   DevBuf w0, w1, seen;
@@ -3216,10 +3239,16 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
       case CRGPU_COUNT_ROWS: op.kind = ACC_COUNT_ROWS; op.out_type = CRGPU_INT64; op.col = -1; break;
       case CRGPU_COUNT: op.kind = ACC_COUNT; op.out_type = CRGPU_INT64; break;
       case CRGPU_SUM:
-        if (t != CRGPU_FLOAT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: SUM over INT yields DECIMAL (apd): CPU operator");
+        if (is_int_type(t) && d.col < n_phys) {
+          // SUM over INT yields DECIMAL in the reference (apd additions, hash_sum_agg.eg.go:30-373).  The total of
+          // 64-bit integers is exact in 128 bits: the SUM_INT accumulators without the range check, handed out as a
+          // BYTES column of 16-byte little-endian two's-complement values the shell turns into apd.Decimal.
+          op.kind = ACC_SUM_I128; op.out_type = CRGPU_BYTES; op.dec128 = true; break;
+        }
+        if (t != CRGPU_FLOAT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: SUM over this type: CPU operator");
         op.kind = ACC_SUM_F64; op.out_type = CRGPU_FLOAT64; break;
       case CRGPU_AVG:
-        if (t != CRGPU_FLOAT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: AVG over INT yields DECIMAL (apd): CPU operator");
+        if (t != CRGPU_FLOAT64) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: AVG over INT yields DECIMAL (apd): ask for SUM and COUNT and divide in the shell, or keep the CPU operator");
         op.kind = ACC_AVG_F64; op.out_type = CRGPU_FLOAT64; break;
       case CRGPU_SUM_INT:
         if (!is_int_type(t)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: SUM_INT needs an integer column");
@@ -4618,7 +4647,12 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
       CRGPU_TRY(o.valid.ensure(static_cast<size_t>((ng + 7) / 8 + 1)));
       c.out_valid = o.valid.as<uint8_t>();
       c.out_type = op.out_type;
-      if (op.out_type == CRGPU_BYTES) {
+      if (op.dec128) {
+        CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(ng + 1) * 4));
+        CRGPU_TRY(o.data.ensure(static_cast<size_t>(ng) * 16));
+        c.bytes = 2;
+        c.out_offsets = o.offsets.as<uint32_t>();
+      } else if (op.out_type == CRGPU_BYTES) {
         const bool any_row = op.kind == ACC_ANY_ROW, stored = any_row || is_minmax_bytes(op.kind);
         // every group's value lies in the store once: its fill level bounds the output
         const uint64_t bound = stored ? op.any_tail : a->ks[op.key_idx].tail;
@@ -4674,7 +4708,16 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
       alias[f] = a->ks[op.key_idx].b_buf.p;
       continue;
     }
-    if (op.out_type == CRGPU_BYTES) {
+    if (op.dec128) {
+      if (ng >= (int64_t(1) << 28)) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_finish: BYTES output exceeds 4 GiB");
+      CRGPU_TRY(o.offsets.ensure(static_cast<size_t>(ng + 1) * 4));
+      CRGPU_TRY(o.data.ensure(static_cast<size_t>(ng > 0 ? ng : 1) * 16));
+      hipLaunchKernelGGL(iota16_kernel, dim3(grid_for(ng + 1, 256)), dim3(256), 0, st, ng + 1, o.offsets.as<uint32_t>());
+      if (ng > 0)
+        hipLaunchKernelGGL(agg_sum128_out_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, ops[f].w0, ops[f].w1, ops[f].seen, ng,
+                           o.data.as<unsigned long long>(), a->present_tmp.as<uint8_t>());
+      CRGPU_HIP(hipGetLastError());
+    } else if (op.out_type == CRGPU_BYTES) {
       // ANY_NOT_NULL over a BYTES group key or BYTES column
       // ... or MIN / MAX over a BYTES column (present = a value was stored)
       const bool any_row = op.kind == ACC_ANY_ROW, stored = any_row || is_minmax_bytes(op.kind);

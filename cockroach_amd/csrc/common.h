@@ -65,6 +65,9 @@ struct Handle {
   hipEvent_t ev = nullptr;      // orders st after the work queued so far on the device's default stream
   uint64_t seen_epoch = 0;
   std::atomic<int32_t> cancelled{0};  // set by crgpu_cancel from any thread; sticky until reset
+  // bytes this handle's calls hold: device buffers (DevBuf) and pinned host staging, for the caller's per-operator
+  // memory account (crgpu_handle_mem_usage; colmem.Allocator in the reference)
+  std::atomic<int64_t> mem_dev{0}, mem_pinned{0};
   Handle() = default;
   Handle(const Handle &) = delete;
   Handle &operator=(const Handle &) = delete;
@@ -84,6 +87,7 @@ struct Shell {
 // makes the handle's stream the thread's current stream() and restores both on exit.  Nests (layer 2 calls layer 1).
 struct CallScope {
   hipStream_t prev_stream;
+  Handle *prev_handle;
   int prev_device;
   bool prev_in_call;
   crgpu_status st;
@@ -98,11 +102,14 @@ struct CallScope {
     if ((h)->cancelled.load(std::memory_order_relaxed)) return ::crgpu::fail(CRGPU_ERR_CANCELLED, "operation cancelled (crgpu_cancel)"); \
   } while (0)
 
-// Grow-only device buffer; every byte is accounted in crgpu_mem_usage().
+Handle *current_handle();  // the handle of the outermost extern "C" call on this thread (nullptr: a handle-less call)
+void account_mem(Handle *owner, int64_t device_delta, int64_t pinned_delta);  // no-op for a handle that is gone
+// Grow-only device buffer; every byte is accounted in crgpu_mem_usage() and in its owner's mem_dev.
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
   int device = -1;  // the device the block lives on (its pool)
+  Handle *owner = nullptr;  // the handle whose call allocated the block (accounting only; checked against the live set)
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;

@@ -12,6 +12,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -45,6 +46,7 @@ class PinnedPool {
       if (!free_[b].empty()) {
         void *p = free_[b].back();
         free_[b].pop_back();
+        own(p, size);
         return p;
       }
       if (pinned_bytes_ + size > max_bytes_) return std::malloc(bytes);
@@ -58,14 +60,18 @@ class PinnedPool {
       return std::malloc(bytes);
     }
     std::lock_guard<std::mutex> g(mu_);
-    pinned_.insert(p);
+    pinned_.emplace(p, nullptr);
+    own(p, size);
     return p;
   }
   void release(void *p, size_t bytes) {
     if (p == nullptr) return;
     if (bytes >= kMin) {
       std::lock_guard<std::mutex> g(mu_);
-      if (pinned_.count(p)) {
+      auto it = pinned_.find(p);
+      if (it != pinned_.end()) {
+        account_mem(it->second, 0, -(int64_t(1) << bucket(bytes)));
+        it->second = nullptr;
         free_[bucket(bytes)].push_back(p);
         return;
       }
@@ -86,7 +92,12 @@ class PinnedPool {
   }
   std::mutex mu_;
   std::vector<void *> free_[64];
-  std::unordered_set<void *> pinned_;
+  void own(void *p, size_t size) {  // mu_ held: the block belongs to the handle whose call took it
+    Handle *o = current_handle();
+    pinned_[p] = o;
+    account_mem(o, 0, static_cast<int64_t>(size));
+  }
+  std::unordered_map<void *, Handle *> pinned_;  // pinned block -> current owner (nullptr: idle or unowned)
   size_t pinned_bytes_ = 0, max_bytes_ = 0;
 };
 

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_set>
 #include <mutex>
 
 #include "common.h"
@@ -26,6 +27,9 @@ static thread_local std::string t_err;
 static thread_local int t_device = -1;            // this thread's library device
 static thread_local hipStream_t t_stream = nullptr;  // current handle stream inside a handle call
 static thread_local bool t_in_call = false;
+static thread_local Handle *t_handle = nullptr;   // handle of the outermost call in progress
+static std::mutex g_live_mu;
+static std::unordered_set<Handle *> g_live;        // handles between open() and close()
 static std::atomic<int64_t> g_mem{0};
 static std::atomic<int64_t> g_handles{0};
 static std::atomic<int> g_default_device{-1};
@@ -114,9 +118,17 @@ crgpu_status Handle::open() {
     CRGPU_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   }
   g_handles.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.insert(this);
+  }
   return CRGPU_OK;
 }
 void Handle::close() {
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live.erase(this);
+  }
   if (st != nullptr) {
     (void)hipStreamSynchronize(st);
     bool kept = false;
@@ -143,11 +155,12 @@ void Handle::close() {
   magic = 0;
 }
 
-CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_device(t_device), prev_in_call(t_in_call), st(CRGPU_OK) {
+CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_handle(t_handle), prev_device(t_device), prev_in_call(t_in_call), st(CRGPU_OK) {
   if (h == nullptr) {
     if (!t_in_call) {  // a handle-less call nested in a handle call keeps the handle's stream
       st = ensure_init();
       t_stream = nullptr;
+      t_handle = nullptr;
     }
     t_in_call = true;
     return;
@@ -162,6 +175,7 @@ CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_device(t_device), 
   }
   st = bind_thread(h->device);
   if (st != CRGPU_OK) return;
+  if (!t_in_call || t_handle == nullptr) t_handle = h;  // memory is accounted to the outermost handle of a call
   if (!t_in_call || t_stream == nullptr) {
     t_stream = h->st;
     // results of handle-less calls queued on the default stream (projections, selections, hashes) feed handle calls
@@ -181,8 +195,18 @@ CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_device(t_device), 
 }
 CallScope::~CallScope() {
   t_stream = prev_stream;
+  t_handle = prev_handle;
   t_in_call = prev_in_call;
   if (prev_device >= 0 && prev_device != t_device && g_dev[prev_device].ready.load()) (void)bind_thread(prev_device);
+}
+
+Handle *current_handle() { return t_handle; }
+void account_mem(Handle *owner, int64_t device_delta, int64_t pinned_delta) {
+  if (owner == nullptr) return;
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  if (g_live.count(owner) == 0) return;
+  owner->mem_dev.fetch_add(device_delta);
+  owner->mem_pinned.fetch_add(pinned_delta);
 }
 
 // ------------------------------------------------------------------ device memory pool
@@ -283,11 +307,14 @@ crgpu_status DevBuf::ensure(size_t bytes, bool keep) {
     device = device >= 0 ? device : dev;
     if (!pool_put(device, p, cap)) (void)hipFree(p);
     g_mem -= static_cast<int64_t>(cap);
+    account_mem(owner, -static_cast<int64_t>(cap), 0);
   }
   p = np;
   cap = ncap;
   device = dev;
+  owner = t_handle;
   g_mem += static_cast<int64_t>(cap);
+  account_mem(owner, static_cast<int64_t>(cap), 0);
   return CRGPU_OK;
 }
 
@@ -295,9 +322,11 @@ void DevBuf::release() {
   if (p != nullptr) {
     if (!pool_put(device, p, cap)) (void)hipFree(p);
     g_mem -= static_cast<int64_t>(cap);
+    account_mem(owner, -static_cast<int64_t>(cap), 0);
   }
   p = nullptr;
   cap = 0;
+  owner = nullptr;
 }
 
 // ------------------------------------------------------------------ profiling
@@ -390,6 +419,15 @@ int64_t crgpu_mem_cached(void) {
 void crgpu_mem_trim(void) {
   for (int i = 0; i < kMaxDevices; i++)
     if (g_dev[i].ready.load()) pool_trim(i);
+}
+
+crgpu_status crgpu_handle_mem_usage(void *handle, int64_t *device_bytes, int64_t *pinned_bytes) {
+  Handle *h = static_cast<Handle *>(handle);
+  if (h != nullptr && h->magic == kShellMagic) h = static_cast<Shell *>(handle)->inner;  // layer-2 shell: its device handle
+  if (h == nullptr || h->magic != kHandleMagic) return fail(CRGPU_ERR_INVALID, "crgpu_handle_mem_usage: not a live handle");
+  if (device_bytes != nullptr) *device_bytes = h->mem_dev.load();
+  if (pinned_bytes != nullptr) *pinned_bytes = h->mem_pinned.load();
+  return CRGPU_OK;
 }
 
 crgpu_status crgpu_cancel(void *handle) {

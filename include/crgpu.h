@@ -93,6 +93,13 @@ const char *crgpu_last_error(void);
 /* Device bytes currently held by the library; the Go shell reports the delta
  * through colmem.Allocator.AdjustMemoryUsage (sql/colmem/allocator.go:526). */
 int64_t crgpu_mem_usage(void);
+/* Bytes held on behalf of ONE handle (any handle type of this header): the device buffers and the pinned host staging
+ * its calls allocated and have not released.  This is the figure an operator reports to its own account: each
+ * operator of the reference owns a colmem.Allocator bound to its memory monitor (sql/colmem/allocator.go:34-60,
+ * AdjustMemoryUsage :526, ReleaseAll :560), and the process-wide crgpu_mem_usage cannot be split between two
+ * operators that run at the same time.  Buffers allocated by a call are accounted to the handle of the OUTERMOST
+ * call on the thread (a layer-2 shell resolves to its device handle); either pointer may be NULL. */
+crgpu_status crgpu_handle_mem_usage(void *handle, int64_t *device_bytes, int64_t *pinned_bytes);
 /* Freed library buffers are kept in a per-device pool and reused by later handles (a query builds fresh operators on
  * every execution; hipMalloc/hipFree per operator would dominate).  crgpu_mem_cached: idle bytes held by the pool
  * (not part of crgpu_mem_usage); crgpu_mem_trim returns them to the driver -- call it under memory pressure from

@@ -1244,6 +1244,7 @@ typedef struct agg_state {
   /* one per (group, aggregate function), like the generated *HashAgg structs */
   double fsum;          /* sumFloat64HashAgg.curAgg / avg curSum */
   int64_t isum;         /* sumIntInt64HashAgg.curAgg, count */
+  __int128 dsum;        /* SUM over INT: the exact total (the reference adds apd decimals: hash_sum_agg.eg.go:287-373) */
   int64_t count;        /* numNonNull / curCount */
   uint8_t found;        /* foundNonNullForCurrentGroup */
   uint8_t bval;
@@ -1298,6 +1299,16 @@ static int agg_compute(agg_state *s, const ora_agg_spec *spec, const ora_col *co
     }
     return 0;
   case ORA_SUM: /* float: hash_sum_agg.eg.go:505-583 */
+    if (is_int_type(col->type)) { /* int16/32/64 -> DECIMAL: hash_sum_agg.eg.go:30-373; exact, so a 128-bit integer here */
+      for (int64_t k = 0; k < n; k++) {
+        int64_t i = sel[k];
+        if (col_is_null(col, i)) continue;
+        s->dsum += (__int128)col_get_int(col, i);
+        s->count++;
+      }
+      return 0;
+    }
+    /* fallthrough */
   case ORA_AVG: /* float: hash_avg_agg.eg.go:525-604 */
     for (int64_t k = 0; k < n; k++) {
       int64_t i = sel[k];
@@ -1375,7 +1386,8 @@ static int agg_output_type(const ora_agg_spec *spec, const ora_col *cols) {
   /* colexecagg.ProcessAggregations output types (aggregate_funcs.go:587-612) */
   switch (spec->func) {
   case ORA_COUNT: case ORA_COUNT_ROWS: case ORA_SUM_INT: return ORA_INT64;
-  case ORA_SUM: case ORA_AVG: return ORA_FLOAT64;
+  case ORA_SUM: if (is_int_type(cols[spec->col].type)) return ORA_BYTES; /* 16 bytes, little endian two's complement */ return ORA_FLOAT64;
+  case ORA_AVG: return ORA_FLOAT64;
   case ORA_BOOL_AND: case ORA_BOOL_OR: return ORA_BOOL;
   default: return cols[spec->col].type;
   }
@@ -1392,6 +1404,18 @@ static void agg_flush(const agg_state *s, const ora_agg_spec *spec, const ora_co
   case ORA_SUM_INT:
     if (s->count == 0) null = 1; else ((int64_t *)out->data)[d] = s->isum; break;
   case ORA_SUM:
+    if (out->type == ORA_BYTES) { /* SUM over INT */
+      if (s->count == 0) { null = 1; break; }
+      if (out->buflen + 16 > out->bufcap) {
+        int64_t nc = out->bufcap ? out->bufcap : 256;
+        while (nc < out->buflen + 16) nc *= 2;
+        out->buf = (uint8_t *)xrealloc(out->buf, (size_t)nc);
+        out->bufcap = nc;
+      }
+      memcpy(out->buf + out->buflen, &s->dsum, 16);
+      out->buflen += 16;
+      break;
+    }
     if (s->count == 0) null = 1; else ((double *)out->data)[d] = s->fsum; break;
   case ORA_AVG:
     if (s->count == 0) null = 1; else ((double *)out->data)[d] = s->fsum / (double)s->count; break;
@@ -1577,7 +1601,8 @@ ora_result *ora_hash_agg(const ora_col *cols, int ncols, int64_t n,
     const ora_agg_spec *s = &aggs[f];
     int t = s->col >= 0 ? cols[s->col].type : -1;
     int ok = 1;
-    if ((s->func == ORA_SUM || s->func == ORA_AVG) && t != ORA_FLOAT64) ok = 0; /* INT/DECIMAL => apd, out of scope */
+    if (s->func == ORA_SUM && t != ORA_FLOAT64 && !is_int_type(t)) ok = 0;
+    if (s->func == ORA_AVG && t != ORA_FLOAT64) ok = 0; /* AVG over INT: SUM + COUNT and a DECIMAL division in the shell */
     if (s->func == ORA_SUM_INT && !is_int_type(t)) ok = 0;
     if ((s->func == ORA_BOOL_AND || s->func == ORA_BOOL_OR) && t != ORA_BOOL) ok = 0;
     if (!ok) { if (err) *err = 2; return NULL; }

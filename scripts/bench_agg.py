@@ -164,9 +164,23 @@ def run_q1_fused(n, dv, g, rf, ls, offs, f, reps):
         if cnt:
             kern[k] = {"ms_per_pass": round(ms / reps, 3), "launches_per_pass": cnt / reps}
     a.close()
+    cpu = None
+    if CPU_SAMPLE:  # the same plan on the host: selection -> projections -> hashAggregator, one thread
+        from oracle import oracle as O
+        m = min(n, CPU_SAMPLE)
+        host = [to_host_vec(c, m) for c in base]
+        t1 = time.perf_counter()
+        keep = O.select_i64_const("LE", host[0], cutoff)
+        sel = [v.take(keep) for v in host]
+        dp = O.project_f64("*", sel[4], O.project_f64("-", 1.0, sel[5]))
+        ch = O.project_f64("*", dp, O.project_f64("+", 1.0, sel[6]))
+        O.hash_agg(sel + [dp, ch], [1, 2], [(x[0], x[1], -1) for x in aggs])
+        cdt = time.perf_counter() - t1
+        cpu = {"value": m / cdt, "unit": "rows/s", "cores": 1, "kind": "port",
+               "sample": f"first {m} rows: numpy selection + projections, then oracle/crdb_oracle.c hashAggregator (1 thread), {cdt:.1f} s"}
     return {"case": "Q1 full, fused: WHERE shipdate <= c and the 2 projections evaluated inside the aggregation kernel, GROUP BY 2 bytes keys, 4 SUM + 3 AVG + COUNT_ROWS",
             "rows": n, "groups": ngroups, "ms": dt * 1e3, "rows_per_s": n / dt, "alg_GBps": n * 42.0 / dt / 1e9,
-            "frac_of_8TBps": n * 42.0 / dt / 8e12, "kernels": kern, "cpu_baseline": None}
+            "frac_of_8TBps": n * 42.0 / dt / 8e12, "kernels": kern, "cpu_baseline": cpu}
 
 
 def measure(lg=27, only=None, reps=5, cpu_sample=None, device_index=0):

@@ -71,3 +71,23 @@ def test_aggregator_random(oracle, group_size, num_batches, has_nulls):
             (F["AVG"], 1, -1)]
     out = oracle.hash_agg(cols, [0], aggs, initial_buckets=int(rng.integers(1, 32)))
     H.assert_same_multiset(H.vecs_to_tuples(out), exp, "random")
+
+
+def test_sum_over_int_is_exact(oracle):
+    """SUM over INT: 16-byte little-endian totals, pinned by Python's integers (the reference's tables hold no such case:
+    their SUM inputs are DECIMAL; hash_sum_agg.eg.go:30-373 adds apd decimals, which is exact too)."""
+    rng = np.random.default_rng(5)
+    n = 20000
+    g = rng.integers(0, 50, n, dtype=np.int64)
+    x = rng.integers(np.iinfo(np.int64).min, np.iinfo(np.int64).max, n, dtype=np.int64, endpoint=True)
+    valid = rng.random(n) > 0.2
+    valid[g == 7] = False
+    cols = [cd.Vec.from_numpy(cd.INT64, g), cd.Vec.from_numpy(cd.INT64, x, valid)]
+    out = H.vecs_to_tuples(oracle.hash_agg(cols, [0], [(0, 0, -1), (10, 1, -1)]))
+    want = {}
+    for gi, xi, vi in zip(g.tolist(), x.tolist(), valid.tolist()):
+        want.setdefault(gi, None)
+        if vi:
+            want[gi] = (want[gi] or 0) + xi
+    got = {r[0]: (None if r[1] is None else int.from_bytes(r[1], "little", signed=True)) for r in out}
+    assert got == want and got[7] is None
