@@ -575,7 +575,7 @@ def other_paths(device_index):
         out["tpch_q3_q9_sf10"] = [
             {k: r[k] for k in ("case", "rows", "groups", "ms", "rows_per_s", "algorithmic_bytes", "frac_of_8TBps", "kernels_ms",
                                "result_check", "cpu_baseline")}
-            for r in load("bench_tpch").measure(10.0, reps=3, cpu_sf=1.0, device_index=device_index)]
+            for r in load("bench_tpch").measure(10.0, reps=3, cpu_sf=5.0, device_index=device_index)]
         torch.cuda.empty_cache()
         _lib_trim()
         # north_star's sizes on one GPU: Q1 in full on 6e8 rows, Q9 at SF100 (scripts/bench_sf100.py); the Q1 line's

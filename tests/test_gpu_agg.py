@@ -746,3 +746,38 @@ def test_sum_over_int_is_the_exact_128_bit_total(oracle, itype, ngroups):
     assert got == ora
     if itype == cd.INT64:
         assert any(v[0] is not None and abs(v[0]) >= 2 ** 63 for v in got.values())
+
+
+def test_agg_two_to_the_thirty_rows_in_one_call():
+    """One consume() call of more than 2^30 rows (17 GB of input): the settled low-cardinality path takes it in chunks of
+    up to 2^30 rows, each chunk as one launch per 2^28 rows with the column bases moved along (agg.hip, try_sumfam), and
+    rows of a group the first chunk has not seen reach the resolve pass with their ABSOLUTE row numbers.  Checked through
+    size-independent properties: the counts add up to n, every group's count and sums are what its key's arithmetic
+    progression gives."""
+    import torch
+    from cockroach_amd import _lib, device as dev
+    _lib.check(_lib.load().crgpu_init(0))
+    n = (1 << 30) + 12345
+    NG = 6
+    i = torch.arange(n, device="cuda", dtype=torch.int64)
+    k = i % NG
+    # group 6 appears only behind row 2^29 + 7 (later than the discovery chunk) and far apart: 9 rows in all
+    late = torch.tensor([(1 << 29) + 7 + j * 60_000_001 for j in range(9)], device="cuda")
+    k[late] = 6
+    x = (i % 1000).to(torch.float64)
+    del i
+    torch.cuda.synchronize()
+    a = dev.Agg([cd.INT64, cd.FLOAT64], [0], [(F["ANY_NOT_NULL"], 0, -1), (F["COUNT_ROWS"], -1, -1), (F["SUM"], 1, -1), (F["AVG"], 1, -1)])
+    try:
+        a.consume([dev.from_torch(cd.INT64, k), dev.from_torch(cd.FLOAT64, x)], n)
+        got = {r[0]: r[1:] for r in H.vecs_to_tuples(dev.result_to_vecs(a.finish()))}
+    finally:
+        a.close()
+    assert sorted(got) == list(range(7))
+    assert sum(v[0] for v in got.values()) == n
+    for g in range(7):
+        m = k == g
+        cnt = int(m.sum().item())
+        s = float(x[m].sum().item())  # integers below 2^53: exact in any order
+        assert got[g][0] == cnt and got[g][1] == s and got[g][2] == s / cnt
+    assert got[6][0] == 9
