@@ -340,6 +340,103 @@ __global__ __launch_bounds__(1024) void bloom_filter_kernel(KeyPack kp, int64_t 
   }
 }
 
+// The radix path's counterpart: a bitmap over the FIRST key column's value range (bit d = some build row has
+// value lo + d).  TPC-H's keys are dense integers, so the bitmap of Q9's 20 M part keys is 2.5 MB and stays in the L2s,
+// and a pass over ONE probe column rejects the 95 % of the lineitems whose part is not green before anything is
+// scattered: the radix probe then partitions and probes the survivors only.  (A superset test: the other key columns
+// are compared by the join itself.)
+__global__ __launch_bounds__(256) void key0_bitmap_build_kernel(DCol c0, long long lo, int64_t n, uint32_t *__restrict__ bitmap) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (col_is_null(c0, i)) continue;
+    const uint64_t d = static_cast<uint64_t>(col_get_ival(c0, i)) - static_cast<uint64_t>(lo);
+    atomicOr(&bitmap[d >> 5], 1u << (d & 31));
+  }
+}
+// FAST: the column is INT64 without NULLs and 16-byte aligned: two rows per vector load.  The survivors' values go out
+// beside their row numbers (`vals`: the compacted first key column, so that only the other key columns are gathered).
+template <bool FAST>
+__global__ __launch_bounds__(1024) void key0_filter_kernel(DCol c0, long long lo, unsigned long long range, int64_t n,
+                                                           const uint32_t *__restrict__ bitmap, int32_t *__restrict__ list,
+                                                           long long *__restrict__ vals, unsigned long long *__restrict__ count) {
+  constexpr int TB = 1024, RPT = 8, kWaves = TB / 64, kTile = TB * RPT;  // 8192-row tiles: one reservation atomic each
+  __shared__ uint32_t s_cnt[RPT * kWaves];
+  __shared__ unsigned long long s_base;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t tbase = tile * kTile;
+    uint64_t d[RPT];
+    uint32_t w[RPT];
+    bool look[RPT];
+    int64_t row[RPT];
+    if (FAST) {
+#pragma unroll
+      for (int j = 0; j < RPT; j += 2) {  // rows 2q, 2q + 1 of the tile, q = (j / 2) * TB + tid
+        row[j] = tbase + 2 * (static_cast<int64_t>(j / 2) * TB + tid);
+        row[j + 1] = row[j] + 1;
+        long long a = 0, b = 0;
+        if (row[j + 1] < n) {
+          typedef long long ll2v __attribute__((ext_vector_type(2)));
+          const ll2v v = __builtin_nontemporal_load(reinterpret_cast<const ll2v *>(c0.data) + (row[j] >> 1));
+          a = v.x, b = v.y;
+        } else if (row[j] < n) {
+          a = static_cast<const long long *>(c0.data)[row[j]];
+        }
+        d[j] = static_cast<uint64_t>(a) - static_cast<uint64_t>(lo);
+        d[j + 1] = static_cast<uint64_t>(b) - static_cast<uint64_t>(lo);
+        look[j] = row[j] < n && d[j] <= range;
+        look[j + 1] = row[j + 1] < n && d[j + 1] <= range;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        row[j] = tbase + static_cast<int64_t>(j) * TB + tid;
+        look[j] = row[j] < n && !col_is_null(c0, row[j]);
+        d[j] = look[j] ? static_cast<uint64_t>(col_get_ival(c0, row[j])) - static_cast<uint64_t>(lo) : 0;
+        look[j] = look[j] && d[j] <= range;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) w[j] = look[j] ? bitmap[d[j] >> 5] : 0u;
+    uint32_t rank[RPT];
+    bool keep[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      keep[j] = look[j] && ((w[j] >> (d[j] & 31)) & 1u);
+      const uint64_t m = __ballot(keep[j]);
+      rank[j] = rank_in_mask(m);
+      if (lane_id() == 0) s_cnt[j * kWaves + wave] = popc64(m);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const uint32_t c0n = s_cnt[2 * tid], c1n = s_cnt[2 * tid + 1];
+      const uint32_t incl = wave_incl_scan_u32(c0n + c1n);
+      const uint32_t total = __shfl(incl, 63, 64);
+      unsigned long long base = 0;
+      if (tid == 0 && total) base = atomicAdd(count, static_cast<unsigned long long>(total));
+      if (tid == 0) s_base = base;
+      s_cnt[2 * tid] = incl - c0n - c1n;
+      s_cnt[2 * tid + 1] = incl - c1n;
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      if (keep[j]) {
+        const unsigned long long at = base + s_cnt[j * kWaves + wave] + rank[j];
+        list[at] = static_cast<int32_t>(row[j]);
+        vals[at] = static_cast<long long>(d[j] + static_cast<uint64_t>(lo));
+      }
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void widen_i32_i64_kernel(const int32_t *__restrict__ in, int64_t n, long long *__restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
 // ------------------------------------------------------------------ CHAINED build / probe
 // The chained table is laid out bucket by bucket (a counting sort of the build rows by hash bucket): start[b] .. start[b+1]
 // delimits bucket b in grp[] (build row ids) and, for a single integer key column, gkey[] ({key value, row id} pairs).
@@ -843,6 +940,14 @@ struct crgpu_join : crgpu::Handle {
   std::vector<OutCol> sel_cols;
   uint32_t bloom_mask = 0;
   bool bloom_on = false;    // built with the table; switched off after a probe chunk in which most rows matched
+  // radix path: bitmap over the first key column's value range (key0_bitmap_build_kernel), the survivors' compacted key /
+  // payload / row-id columns of the current probe chunk
+  DevBuf key0_bits;
+  long long key0_lo = 0;
+  unsigned long long key0_range = 0;
+  bool key0_on = false;
+  OutCol pf_key[kMaxPackCols], pf_pay;
+  DevBuf pf_rowid, pf_key0;
   DevBuf mcache;  // chained probe: first matches of every probe row (pass 1 -> pass 3)
   uint64_t cap = 0;
   bool covering = false;
@@ -982,6 +1087,34 @@ extern "C" crgpu_status crgpu_dev_join_reset(crgpu_join *j) {
 static int64_t env_i64(const char *name, int64_t def) {
   const char *v = std::getenv(name);
   return (v != nullptr && *v != 0) ? std::atoll(v) : def;
+}
+// INNER / LEFT SEMI joins through the radix tables: a bitmap over the first key column's values when their range is
+// small enough to be worth a pass over the probe side (<= 2^27 bits = 16 MiB; dense surrogate keys are far below).
+static crgpu_status build_key0_bitmap(crgpu_join *j, int64_t n) {
+  const char *env = std::getenv("CRGPU_JOIN_KEY0_BITMAP");  // "0": no first-key bitmap (tests, measurements)
+  if ((env != nullptr && env[0] == '0') || !(j->join_type == CRGPU_INNER || j->join_type == CRGPU_LEFT_SEMI)) return CRGPU_OK;
+  long long lo;
+  unsigned long long range;
+  const DCol &c0 = j->kp.c[0];
+  if (j->kp.n > 1) {
+    lo = j->kp.lo[0], range = j->kp.range[0];
+  } else if (j->radix.direct.span != 0 && c0.type != CRGPU_FLOAT64) {
+    lo = static_cast<long long>(j->radix.direct.lo), range = j->radix.direct.span - 1;
+  } else {
+    return CRGPU_OK;
+  }
+  if (range >= (1ull << 27)) return CRGPU_OK;
+  hipStream_t st = stream();
+  const size_t bytes = static_cast<size_t>((range >> 5) + 1) * 4;
+  CRGPU_TRY(j->key0_bits.ensure(bytes));
+  CRGPU_HIP(hipMemsetAsync(j->key0_bits.p, 0, bytes, st));
+  ProfScope prof("join_build");
+  hipLaunchKernelGGL(key0_bitmap_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, c0, lo, n, j->key0_bits.as<uint32_t>());
+  CRGPU_HIP(hipGetLastError());
+  j->key0_lo = lo;
+  j->key0_range = range;
+  j->key0_on = true;
+  return CRGPU_OK;
 }
 static bool radix_eligible(const crgpu_join *j, int64_t n) {
   const int jt = j->join_type;
@@ -1180,6 +1313,8 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
         CRGPU_TRY(radix_build(j->radix, src, n, &ok));
       }
       j->use_radix = ok;
+      j->key0_on = false;
+      if (ok && n > 0) CRGPU_TRY(build_key0_bitmap(j, n));
     }
     if (!j->use_radix) {
       CRGPU_TRY(j->slots.ensure(j->cap * sizeof(Slot)));
@@ -1482,7 +1617,62 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
     else pay_col = os.src;
   }
   if (need_pairs_p) pay_col = -1;
-  RadixSrc src = radix_src(probe_keypack(j, left), pay_col >= 0 ? &left[pay_col] : nullptr);
+  KeyPack pkp = probe_keypack(j, left);
+  DCol pf_pay_col;
+  const DCol *pay_ptr = pay_col >= 0 ? &left[pay_col] : nullptr;
+  // A probe side much larger than the build side whose first key column mostly misses the build side's values: reject
+  // those rows in a pass over that one column and hand the radix probe the survivors -- compacted key columns, the
+  // payload column (or the survivors' ORIGINAL row numbers as the payload: the pairs then name rows of `left`).
+  bool nullable_key = false;
+  for (int c = 0; c < pkp.n; c++) nullable_key = nullable_key || pkp.c[c].valid != nullptr;
+  if (j->key0_on && !j->use_radix_dup && !nullable_key && n >= env_i64("CRGPU_JOIN_PREFILTER_MIN", int64_t(1) << 21) &&
+      n >= 4 * j->n_build && n <= 0x7FFFFFF0ll) {
+    CRGPU_TRY(j->cand.ensure(static_cast<size_t>(n) * 4));
+    CRGPU_TRY(j->counter.ensure(8));
+    CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
+    {
+      ProfScope prof("join_probe");
+      // (the survivors' first-column values come out of the pass itself, sized for the worst case it is still worth it: n / 2)
+      CRGPU_TRY(j->pf_key0.ensure(static_cast<size_t>(n) * 8));
+      const bool fast = pkp.c[0].type == CRGPU_INT64 && aligned16(pkp.c[0].data);
+      if (fast)
+        hipLaunchKernelGGL(key0_filter_kernel<true>, dim3(grid_for(n, 1024 * 8)), dim3(1024), 0, st, pkp.c[0], j->key0_lo, j->key0_range, n,
+                           j->key0_bits.as<uint32_t>(), j->cand.as<int32_t>(), j->pf_key0.as<long long>(), j->counter.as<unsigned long long>());
+      else
+        hipLaunchKernelGGL(key0_filter_kernel<false>, dim3(grid_for(n, 1024 * 8)), dim3(1024), 0, st, pkp.c[0], j->key0_lo, j->key0_range, n,
+                           j->key0_bits.as<uint32_t>(), j->cand.as<int32_t>(), j->pf_key0.as<long long>(), j->counter.as<unsigned long long>());
+      CRGPU_HIP(hipGetLastError());
+    }
+    unsigned long long m = 0;
+    CRGPU_HIP(hipMemcpyAsync(&m, j->counter.p, 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (m * 2 > static_cast<unsigned long long>(n)) {
+      j->key0_on = false;  // most rows pass: the bitmap only adds a pass, here and in the chunks that follow
+    } else {
+      const int64_t ms = static_cast<int64_t>(m);
+      const int32_t *list = j->cand.as<int32_t>();
+      pkp.c[0] = DCol{CRGPU_INT64, 0, j->pf_key0.p, nullptr, nullptr};  // (widened to INT64 by the pass: the value, whatever the column's type)
+      for (int c = 1; c < pkp.n; c++) {
+        CRGPU_TRY(materialize(pkp.c[c], list, ms, false, j->pf_key[c], j->scratch));
+        pkp.c[c] = to_dcol(j->pf_key[c].view());
+        pkp.c[c].valid = nullptr;
+      }
+      if (pay_col >= 0) {
+        CRGPU_TRY(materialize(left[pay_col], list, ms, false, j->pf_pay, j->scratch));
+        pf_pay_col = to_dcol(j->pf_pay.view());
+        pf_pay_col.valid = nullptr;
+      } else {
+        CRGPU_TRY(j->pf_rowid.ensure(static_cast<size_t>(ms > 0 ? ms : 1) * 8));
+        if (ms > 0) hipLaunchKernelGGL(widen_i32_i64_kernel, dim3(grid_for(ms, 256)), dim3(256), 0, st, list, ms, j->pf_rowid.as<long long>());
+        CRGPU_HIP(hipGetLastError());
+        pf_pay_col = DCol{CRGPU_INT64, 0, j->pf_rowid.p, nullptr, nullptr};
+      }
+      pay_ptr = &pf_pay_col;
+      n = ms;
+      cap_rows = n > 0 ? n : 1;
+    }
+  }
+  RadixSrc src = radix_src(pkp, pay_ptr);
   int64_t min_probe = j->n_build >> 3;
   if (min_probe < (int64_t(1) << 20)) min_probe = int64_t(1) << 20;
   const bool partitioned = n >= env_i64("CRGPU_RADIX_MIN_PROBE", min_probe);

@@ -195,6 +195,49 @@ def test_join_packed_key_bitmap_selective_probe(oracle, bitmap, two_cols, monkey
         assert np.array_equal(got[np.lexsort(got.T[::-1])], want), (jt, bitmap, two_cols)
 
 
+@pytest.mark.parametrize("keys", ["two_cols", "one_col_direct"])
+@pytest.mark.parametrize("outputs", ["pairs", "fused_payload"])
+def test_join_radix_first_key_bitmap_prefilter(oracle, keys, outputs, monkeypatch):
+    """The radix path's prefilter (join.hip, key0_filter_kernel): a bitmap over the first key column's value range
+    rejects probe rows before anything is scattered; the radix probe sees the survivors' compacted key columns and
+    either their compacted payload column or their ORIGINAL row numbers (the pairs the later gathers use).  Selective
+    chunks (5 % of the first-column values exist on the build side, and not every survivor matches on the second
+    column), then a chunk of hits only, which switches the bitmap off; against the oracle, with the prefilter and
+    without it."""
+    monkeypatch.setenv("CRGPU_RADIX_MIN_BUILD", "1")
+    monkeypatch.setenv("CRGPU_RADIX_MIN_PROBE", "1")
+    monkeypatch.setenv("CRGPU_JOIN_PREFILTER_MIN", "1000")
+    rng = np.random.default_rng(23)
+    nb, npr = 20_000, 400_000
+    if keys == "two_cols":
+        parts = rng.permutation(400_000)[:5_000].astype(np.int64) + 7           # 5000 "green parts" of 400 000
+        bk0 = np.repeat(parts, 4)
+        bk1 = np.tile(np.arange(4, dtype=np.int64), 5_000) * 1000 + bk0 % 1000    # 4 suppliers per part
+        pk0 = rng.integers(7, 400_007, npr, dtype=np.int64)
+        pk1 = rng.integers(0, 5, npr, dtype=np.int64) * 1000 + pk0 % 1000         # every fifth survivor misses on column 2
+        pk0[200_000:250_000] = rng.choice(parts, 50_000)                          # a chunk in which every row survives
+        lkeys = [cd.Vec.from_numpy(cd.INT64, pk0), cd.Vec.from_numpy(cd.INT64, pk1)]
+        rkeys = [cd.Vec.from_numpy(cd.INT64, bk0), cd.Vec.from_numpy(cd.INT64, bk1)]
+    else:
+        bk = (rng.permutation(60_000)[:nb].astype(np.int64)) + 1_000_000          # dense enough for direct-addressed tables
+        pk = rng.integers(1_000_000 - 50_000, 1_000_000 + 600_000, npr, dtype=np.int64)
+        pk[200_000:250_000] = rng.choice(bk, 50_000)
+        lkeys, rkeys = [cd.Vec.from_numpy(cd.INT64, pk)], [cd.Vec.from_numpy(cd.INT64, bk)]
+    nk = len(lkeys)
+    left = lkeys + [cd.Vec.from_numpy(cd.INT64, np.arange(npr, dtype=np.int64))]
+    if outputs == "pairs":  # two more probe columns (one nullable): gathered by pair afterwards
+        left += [cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(npr)), cd.Vec.from_numpy(cd.INT32, (np.arange(npr) % 97).astype(np.int32), rng.random(npr) > 0.1)]
+    right = rkeys + [cd.Vec.from_numpy(cd.FLOAT64, rng.standard_normal(len(rkeys[0])))]
+    eq = list(range(nk))
+    for jt in ("INNER", "LEFT_SEMI"):
+        want = G.rows_as_sorted_array(oracle.hash_join(H.JOIN_TYPE[jt], left, right, eq, eq, True))
+        for on in ("1", "0"):
+            monkeypatch.setenv("CRGPU_JOIN_KEY0_BITMAP", on)
+            parts_out, _ = G.gpu_join_vecs(jt, left, right, eq, eq, True, probe_chunks=8)
+            got = np.concatenate([G.rows_as_sorted_array(p) for p in parts_out])
+            assert np.array_equal(got[np.lexsort(got.T[::-1])], want), (jt, keys, outputs, on)
+
+
 @pytest.mark.parametrize("jt", ALL_JOIN_TYPES)
 @pytest.mark.parametrize("table", ["packed", "packed_bitmap_prefilter", "radix", "chained_dups", "chained_bytes"])
 def test_join_probe_selected_equals_deselect_then_probe(oracle, jt, table, monkeypatch):
