@@ -264,17 +264,50 @@ __global__ __launch_bounds__(256) void narrow_offsets_kernel(const uint64_t *__r
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n1; i += stride)
     out[i] = static_cast<uint32_t>(in[i]);
 }
+// The payload of a gathered BYTES column, written by OUTPUT position: the output bytes of a tile of 1024 rows are one
+// contiguous range, so consecutive lanes store consecutive bytes (whole lines leave the CU) and find their row by a
+// binary search over the tile's offsets in LDS.  One thread per row copying its bytes one by one wrote a byte per lane
+// to addresses a value apart: 2.0 ms for the 32 M nation names of Q9 at SF100 (288 MB).
 __global__ __launch_bounds__(256) void bytes_copy_kernel(DCol src, const int32_t *__restrict__ idx, int64_t n,
                                                          const uint32_t *__restrict__ dst_off,
                                                          uint8_t *__restrict__ dst) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  constexpr int kTile = 1024;
+  __shared__ uint32_t s_off[kTile + 1];
+  __shared__ uint32_t s_src[kTile];
   const uint8_t *sdata = static_cast<const uint8_t *>(src.data);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int32_t r = idx[i];
-    uint32_t o = dst_off[i], len = dst_off[i + 1] - o;
-    if (len == 0) continue;
-    const uint8_t *s = sdata + src.offsets[r];
-    for (uint32_t t = 0; t < len; t++) dst[o + t] = s[t];
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * kTile;
+    const int rows = static_cast<int>(n - r0 < kTile ? n - r0 : kTile);
+    for (int t = threadIdx.x; t <= rows; t += 256) s_off[t] = dst_off[r0 + t];
+    for (int t = threadIdx.x; t < rows; t += 256) {
+      const int32_t r = idx[r0 + t];
+      s_src[t] = r >= 0 ? src.offsets[r] : 0u;  // (rows without a value have length 0: never looked up)
+    }
+    __syncthreads();
+    const uint32_t lo = s_off[0], hi = s_off[rows];
+    // four output bytes per thread and step: their searches and loads are independent, so their latencies overlap
+    for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += 4 * 256) {
+      uint8_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = p0 + u * 256;
+        int a = 0, b = rows;  // the last row whose offset is <= p
+#pragma unroll
+        for (int step = 0; step < 10; step++) {  // kTile = 2^10
+          const int m = (a + b) >> 1;
+          const bool right = b - a > 1 && s_off[m] <= p;
+          const bool left = b - a > 1 && !right;
+          a = right ? m : a;
+          b = left ? m : b;
+        }
+        v[u] = p < hi ? sdata[s_src[a] + (p - s_off[a])] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (p0 + u * 256 < hi) dst[p0 + u * 256] = v[u];
+    }
+    __syncthreads();
   }
 }
 
@@ -297,7 +330,7 @@ crgpu_status gather_bytes(const DCol &src, const int32_t *idx, int64_t n, DevBuf
   hipLaunchKernelGGL(narrow_offsets_kernel, dim3(grid_for(n + 1, 256)), dim3(256), 0, stream(), offs64.as<uint64_t>(),
                      n + 1, dst_offsets.as<uint32_t>());
   CRGPU_TRY(dst_data.ensure(static_cast<size_t>(total ? total : 1)));
-  hipLaunchKernelGGL(bytes_copy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream(), src, idx, n,
+  hipLaunchKernelGGL(bytes_copy_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, stream(), src, idx, n,
                      dst_offsets.as<uint32_t>(), dst_data.as<uint8_t>());
   CRGPU_HIP(hipGetLastError());
   CRGPU_HIP(hipStreamSynchronize(stream()));  // lens/offs64 are freed on return

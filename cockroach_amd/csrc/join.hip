@@ -345,12 +345,15 @@ __global__ __launch_bounds__(1024) void bloom_filter_kernel(KeyPack kp, int64_t 
 // and a pass over ONE probe column rejects the 95 % of the lineitems whose part is not green before anything is
 // scattered: the radix probe then partitions and probes the survivors only.  (A superset test: the other key columns
 // are compared by the join itself.)
-__global__ __launch_bounds__(256) void key0_bitmap_build_kernel(DCol c0, long long lo, int64_t n, uint32_t *__restrict__ bitmap) {
+__global__ __launch_bounds__(256) void key0_bitmap_build_kernel(DCol c0, long long lo, unsigned long long range, int64_t n,
+                                                                uint32_t *__restrict__ bitmap) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (col_is_null(c0, i)) continue;
     const uint64_t d = static_cast<uint64_t>(col_get_ival(c0, i)) - static_cast<uint64_t>(lo);
-    atomicOr(&bitmap[d >> 5], 1u << (d & 31));
+    // (the range was taken over the rows that HAVE a key: a row with a NULL in another key column may lie outside it,
+    // and matches nothing)
+    if (d <= range) atomicOr(&bitmap[d >> 5], 1u << (d & 31));
   }
 }
 // FAST: the column is INT64 without NULLs and 16-byte aligned: two rows per vector load.  The survivors' values go out
@@ -1109,7 +1112,7 @@ static crgpu_status build_key0_bitmap(crgpu_join *j, int64_t n) {
   CRGPU_TRY(j->key0_bits.ensure(bytes));
   CRGPU_HIP(hipMemsetAsync(j->key0_bits.p, 0, bytes, st));
   ProfScope prof("join_build");
-  hipLaunchKernelGGL(key0_bitmap_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, c0, lo, n, j->key0_bits.as<uint32_t>());
+  hipLaunchKernelGGL(key0_bitmap_build_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, c0, lo, range, n, j->key0_bits.as<uint32_t>());
   CRGPU_HIP(hipGetLastError());
   j->key0_lo = lo;
   j->key0_range = range;
