@@ -38,6 +38,10 @@ class JoinSpec(C.Structure):  # crgpu_join_spec
                 ("out_cols", C.POINTER(C.c_int32))]
 
 
+class HandleStats(C.Structure):  # crgpu_handle_stats_t
+    _fields_ = [(n, C.c_int64) for n in ("calls", "busy_ns", "rows_in", "rows_out", "device_bytes", "pinned_bytes")]
+
+
 class AggDesc(C.Structure):  # crgpu_agg_desc
     _fields_ = [("func", C.c_int32), ("col", C.c_int32), ("filter_col", C.c_int32), ("distinct", C.c_int32)]
 
@@ -108,6 +112,7 @@ SYMBOLS = [
     ("crgpu_last_error", C.c_char_p, []),
     ("crgpu_mem_usage", _I64, []),
     ("crgpu_handle_mem_usage", _I32, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("crgpu_handle_stats", _I32, [_VP, C.POINTER(HandleStats)]),
     ("crgpu_live_handles", _I64, []),
     ("crgpu_mem_cached", _I64, []),
     ("crgpu_mem_trim", None, []),

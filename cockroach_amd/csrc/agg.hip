@@ -4543,7 +4543,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   return CRGPU_OK;
 }
 
-extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
+static crgpu_status crgpu_dev_agg_consume_impl(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
   if (a == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null handle");
   CRGPU_ENTER(a);
   CRGPU_CHECK_CANCEL(a);
@@ -4602,6 +4602,12 @@ extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *co
   return CRGPU_OK;
 }
 
+extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
+  const crgpu_status s_ = crgpu_dev_agg_consume_impl(a, cols, n);
+  if (s_ == CRGPU_OK && a != nullptr) note_rows(a, n, 0);
+  return s_;
+}
+
 // Output columns that need no finalisation pass: the accumulator word (or the stored group key) of group g already is
 // the value of output row g.  Below kAliasMinGroups the copy costs nothing and keeps the result independent of the
 // handle's arrays.
@@ -4623,7 +4629,7 @@ static bool alias_source(crgpu_agg *a, const AggOpHost &op, const AggOpDev &dev,
   }
 }
 
-extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res) {
+static crgpu_status crgpu_dev_agg_finish_impl(crgpu_agg *a, crgpu_dev_result *res) {
   if (a == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_finish: null argument");
   CRGPU_ENTER(a);
   CRGPU_CHECK_CANCEL(a);
@@ -4792,4 +4798,10 @@ extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res
   res->_pad = 0;
   res->cols = a->views.data();
   return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res) {
+  const crgpu_status s_ = crgpu_dev_agg_finish_impl(a, res);
+  if (s_ == CRGPU_OK && a != nullptr) note_rows(a, 0, res->n);
+  return s_;
 }

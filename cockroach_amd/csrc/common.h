@@ -68,6 +68,9 @@ struct Handle {
   // bytes this handle's calls hold: device buffers (DevBuf) and pinned host staging, for the caller's per-operator
   // memory account (crgpu_handle_mem_usage; colmem.Allocator in the reference)
   std::atomic<int64_t> mem_dev{0}, mem_pinned{0};
+  // per-operator execution statistics (crgpu_handle_stats; execinfrapb.ComponentStats in the reference): calls that named
+  // this handle outermost and the wall time inside them, rows handed in and rows produced
+  std::atomic<int64_t> st_calls{0}, st_ns{0}, st_rows_in{0}, st_rows_out{0};
   Handle() = default;
   Handle(const Handle &) = delete;
   Handle &operator=(const Handle &) = delete;
@@ -88,6 +91,8 @@ struct Shell {
 struct CallScope {
   hipStream_t prev_stream;
   Handle *prev_handle;
+  Handle *timed = nullptr;  // the handle this scope made current (outermost call): its time is taken at exit
+  int64_t t0_ns = 0;
   int prev_device;
   bool prev_in_call;
   crgpu_status st;
@@ -104,6 +109,10 @@ struct CallScope {
 
 Handle *current_handle();  // the handle of the outermost extern "C" call on this thread (nullptr: a handle-less call)
 void account_mem(Handle *owner, int64_t device_delta, int64_t pinned_delta);  // no-op for a handle that is gone
+inline void note_rows(Handle *h, int64_t rows_in, int64_t rows_out) {
+  h->st_rows_in.fetch_add(rows_in, std::memory_order_relaxed);
+  h->st_rows_out.fetch_add(rows_out, std::memory_order_relaxed);
+}
 // Grow-only device buffer; every byte is accounted in crgpu_mem_usage() and in its owner's mem_dev.
 struct DevBuf {
   void *p = nullptr;

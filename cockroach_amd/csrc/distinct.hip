@@ -549,7 +549,7 @@ static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol>
   return CRGPU_OK;
 }
 
-extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *res) {
+static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *res) {
   if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_distinct_consume: null argument");
   CRGPU_ENTER(d);
   CRGPU_CHECK_CANCEL(d);
@@ -692,4 +692,10 @@ extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgp
   res->cols = d->views.data();
   if (d->error_on_dup && m < n) return fail(CRGPU_ERR_DUPLICATE, "crgpu_dev_distinct_consume: duplicate tuple (errorOnDup)");
   return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_distinct_consume(crgpu_distinct *d, const crgpu_dcol *cols, int64_t n, crgpu_dev_result *res) {
+  const crgpu_status s_ = crgpu_dev_distinct_consume_impl(d, cols, n, res);
+  if (s_ == CRGPU_OK && d != nullptr) note_rows(d, n, res->n);
+  return s_;
 }

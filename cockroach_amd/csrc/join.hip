@@ -1266,7 +1266,7 @@ static KeyPack probe_keypack(const crgpu_join *j, const std::vector<DCol> &left)
   return kp;
 }
 
-extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
+static crgpu_status crgpu_dev_join_build_impl(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
   if (j == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_join_build: null handle");
   CRGPU_ENTER(j);
   CRGPU_CHECK_CANCEL(j);
@@ -1407,6 +1407,12 @@ extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *ri
   CRGPU_HIP(hipStreamSynchronize(st));
   j->built = true;
   return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_join_build(crgpu_join *j, const crgpu_dcol *right_cols, int64_t n) {
+  const crgpu_status s_ = crgpu_dev_join_build_impl(j, right_cols, n);
+  if (s_ == CRGPU_OK && j != nullptr) note_rows(j, n, 0);
+  return s_;
 }
 
 // Output column bookkeeping ------------------------------------------------
@@ -1906,12 +1912,16 @@ static crgpu_status join_probe_impl(crgpu_join *j, const crgpu_dcol *left_cols, 
 
 extern "C" crgpu_status crgpu_dev_join_probe(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
                                              crgpu_dev_result *res) {
-  return join_probe_impl(j, left_cols, n, nullptr, res);
+  const crgpu_status s_ = join_probe_impl(j, left_cols, n, nullptr, res);
+  if (s_ == CRGPU_OK && j != nullptr) note_rows(j, n, res->n);
+  return s_;
 }
 
 extern "C" crgpu_status crgpu_dev_join_probe_selected(crgpu_join *j, const crgpu_dcol *left_cols, int64_t n,
                                                       const uint8_t *keep_bool, crgpu_dev_result *res) {
-  return join_probe_impl(j, left_cols, n, keep_bool, res);
+  const crgpu_status s_ = join_probe_impl(j, left_cols, n, keep_bool, res);
+  if (s_ == CRGPU_OK && j != nullptr) note_rows(j, n, res->n);
+  return s_;
 }
 
 extern "C" crgpu_status crgpu_dev_join_emit_right(crgpu_join *j, crgpu_dev_result *res) {

@@ -922,7 +922,7 @@ static crgpu_status kv_check_error(crgpu_decoder *d, const char *phase) {
                                      " (" + phase + " " + std::to_string(e.first_row) + ")");
 }
 
-extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
+static crgpu_status crgpu_dev_decode_kv_impl(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
                                             int64_t n_batches, crgpu_dev_result *res) {
   if (d == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_decode_kv: null argument");
   CRGPU_ENTER(d);
@@ -1157,4 +1157,11 @@ extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *rep
   res->_pad = 0;
   res->cols = d->views.data();
   return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_decode_kv(crgpu_decoder *d, const uint8_t *repr_dev, const int64_t *batch_offsets_host,
+                                            int64_t n_batches, crgpu_dev_result *res) {
+  const crgpu_status s_ = crgpu_dev_decode_kv_impl(d, repr_dev, batch_offsets_host, n_batches, res);
+  if (s_ == CRGPU_OK && d != nullptr) note_rows(d, n_batches, res->n);
+  return s_;
 }

@@ -338,7 +338,7 @@ extern "C" void crgpu_dev_partitioner_destroy(crgpu_partitioner *p) {
   delete p;
 }
 
-extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n,
+static crgpu_status crgpu_dev_partition_impl(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n,
                                             crgpu_dev_result *res, int64_t *counts_host) {
   if (p == nullptr || res == nullptr || counts_host == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_partition: null argument");
   CRGPU_ENTER(p);
@@ -460,6 +460,13 @@ extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dc
   res->_pad = 0;
   res->cols = p->views.data();
   return CRGPU_OK;
+}
+
+extern "C" crgpu_status crgpu_dev_partition(crgpu_partitioner *p, const crgpu_dcol *cols, int64_t n,
+                                            crgpu_dev_result *res, int64_t *counts_host) {
+  const crgpu_status s_ = crgpu_dev_partition_impl(p, cols, n, res, counts_host);
+  if (s_ == CRGPU_OK && p != nullptr) note_rows(p, n, n);
+  return s_;
 }
 
 // The one entry point that allocates nothing (include/crgpu.h): same kernels as crgpu_dev_partition, scratch from the

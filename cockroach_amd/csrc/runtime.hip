@@ -1,6 +1,7 @@
 // runtime.hip -- library lifecycle, per-device contexts, per-handle streams, error reporting, memory accounting,
 // HIP-event profiling, cancellation.
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -175,7 +176,11 @@ CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_handle(t_handle), 
   }
   st = bind_thread(h->device);
   if (st != CRGPU_OK) return;
-  if (!t_in_call || t_handle == nullptr) t_handle = h;  // memory is accounted to the outermost handle of a call
+  if (!t_in_call || t_handle == nullptr) {  // memory and time are accounted to the outermost handle of a call
+    t_handle = h;
+    timed = h;
+    t0_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
   if (!t_in_call || t_stream == nullptr) {
     t_stream = h->st;
     // results of handle-less calls queued on the default stream (projections, selections, hashes) feed handle calls
@@ -194,6 +199,11 @@ CallScope::CallScope(Handle *h) : prev_stream(t_stream), prev_handle(t_handle), 
   t_in_call = true;
 }
 CallScope::~CallScope() {
+  if (timed != nullptr) {
+    const int64_t t1 = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    timed->st_ns.fetch_add(t1 - t0_ns, std::memory_order_relaxed);
+    timed->st_calls.fetch_add(1, std::memory_order_relaxed);
+  }
   t_stream = prev_stream;
   t_handle = prev_handle;
   t_in_call = prev_in_call;
@@ -427,6 +437,19 @@ crgpu_status crgpu_handle_mem_usage(void *handle, int64_t *device_bytes, int64_t
   if (h == nullptr || h->magic != kHandleMagic) return fail(CRGPU_ERR_INVALID, "crgpu_handle_mem_usage: not a live handle");
   if (device_bytes != nullptr) *device_bytes = h->mem_dev.load();
   if (pinned_bytes != nullptr) *pinned_bytes = h->mem_pinned.load();
+  return CRGPU_OK;
+}
+
+crgpu_status crgpu_handle_stats(void *handle, crgpu_handle_stats_t *out) {
+  Handle *h = static_cast<Handle *>(handle);
+  if (h != nullptr && h->magic == kShellMagic) h = static_cast<Shell *>(handle)->inner;
+  if (h == nullptr || h->magic != kHandleMagic || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_handle_stats: not a live handle");
+  out->calls = h->st_calls.load();
+  out->busy_ns = h->st_ns.load();
+  out->rows_in = h->st_rows_in.load();
+  out->rows_out = h->st_rows_out.load();
+  out->device_bytes = h->mem_dev.load();
+  out->pinned_bytes = h->mem_pinned.load();
   return CRGPU_OK;
 }
 

@@ -100,6 +100,16 @@ int64_t crgpu_mem_usage(void);
  * operators that run at the same time.  Buffers allocated by a call are accounted to the handle of the OUTERMOST
  * call on the thread (a layer-2 shell resolves to its device handle); either pointer may be NULL. */
 crgpu_status crgpu_handle_mem_usage(void *handle, int64_t *device_bytes, int64_t *pinned_bytes);
+/* Execution statistics of ONE handle, for the operator's ComponentStats (execinfrapb.ComponentStats as collected by
+ * colflow's vectorizedStatsCollector: batchInfoCollector counts batches / tuples and times Next, stats.go:41-137; the
+ * process-wide crgpu_prof_* timings cannot be attributed to an operator).  calls / busy_ns: calls that named this
+ * handle outermost and the wall time spent inside them (device work included: every call returns after its device
+ * work); rows_in / rows_out: rows handed to build / probe / consume / partition / decode (KV batches for the decoder)
+ * and rows of the results handed back. */
+typedef struct {
+  int64_t calls, busy_ns, rows_in, rows_out, device_bytes, pinned_bytes;
+} crgpu_handle_stats_t;
+crgpu_status crgpu_handle_stats(void *handle, crgpu_handle_stats_t *out);
 /* Freed library buffers are kept in a per-device pool and reused by later handles (a query builds fresh operators on
  * every execution; hipMalloc/hipFree per operator would dominate).  crgpu_mem_cached: idle bytes held by the pool
  * (not part of crgpu_mem_usage); crgpu_mem_trim returns them to the driver -- call it under memory pressure from

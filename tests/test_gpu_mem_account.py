@@ -79,3 +79,39 @@ def test_rejects_what_is_not_a_handle():
     junk = (C.c_uint8 * 64)()
     d = C.c_int64()
     assert lib.crgpu_handle_mem_usage(C.cast(junk, C.c_void_p), C.byref(d), None) == _lib.ERR_INVALID
+
+
+def test_handle_stats_count_rows_calls_and_time():
+    """crgpu_handle_stats: per-operator calls, busy time, rows in / out (ComponentStats, colflow/stats.go:41-137)."""
+    import torch
+    from cockroach_amd import device as dev
+    lib = _lib.load()
+    _lib.check(lib.crgpu_init(0))
+
+    def stats(h):
+        s = _lib.HandleStats()
+        _lib.check(lib.crgpu_handle_stats(h, C.byref(s)))
+        return s
+
+    nb, npr = 1 << 16, 1 << 18
+    bk = torch.randperm(nb, device="cuda", dtype=torch.int64)
+    pk = torch.randint(0, 2 * nb, (npr,), device="cuda", dtype=torch.int64)
+    torch.cuda.synchronize()
+    j = dev.Join(0, [cd.INT64], [cd.INT64], [0], [0], True)
+    other = dev.Join(0, [cd.INT64], [cd.INT64], [0], [0], True)
+    try:
+        c0 = stats(j.h).calls  # (create is a call on the handle too)
+        assert c0 <= 1 and stats(j.h).rows_in == 0
+        j.build([dev.from_torch(cd.INT64, bk)], nb)
+        res = j.probe([dev.from_torch(cd.INT64, pk)], npr)
+        hits = int((pk < nb).sum().item())
+        assert int(res.n) == hits
+        s = stats(j.h)
+        assert s.calls == c0 + 2 and s.busy_ns > 0
+        assert s.rows_in == nb + npr and s.rows_out == hits
+        assert s.device_bytes > 0
+        o = stats(other.h)
+        assert o.calls <= 1 and o.rows_in == 0 and o.rows_out == 0  # another operator's statistics are its own
+    finally:
+        j.close()
+        other.close()
