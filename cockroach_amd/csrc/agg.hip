@@ -2893,6 +2893,17 @@ __global__ __launch_bounds__(256) void bytes_copy_groups_kernel(const uint64_t *
     for (uint32_t t = 0; t < len; t++) dst[o + t] = src[t];
   }
 }
+__global__ __launch_bounds__(256) void bool_and_valid_kernel(const uint8_t *__restrict__ b, const uint8_t *__restrict__ valid, int64_t n,
+                                                             uint8_t *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256)
+    out[i] = b[i] != 0 && ((valid[i >> 3] >> (i & 7)) & 1);
+}
+__global__ __launch_bounds__(256) void iota64_kernel(int64_t n, long long *__restrict__ out) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256) out[i] = i;
+}
+__global__ __launch_bounds__(256) void mask_rows_kernel(const long long *__restrict__ rows, int64_t m, uint8_t *__restrict__ mask) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < m; i += static_cast<int64_t>(gridDim.x) * 256) mask[rows[i]] = 1;
+}
 __global__ __launch_bounds__(256) void iota16_kernel(int64_t n, uint32_t *__restrict__ out) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256)
     out[i] = static_cast<uint32_t>(i) * 16u;
@@ -2977,6 +2988,24 @@ struct crgpu_agg : crgpu::Handle {
   std::vector<OutCol> out;
   std::vector<crgpu_dcol> views;
   std::vector<AggOpDev> ops_stage;  // host staging of upload_descriptors
+  // DISTINCT aggregations (aggregators_util.go:298-373: a row contributes iff its (group, input) tuple was not seen
+  // before): one unordered-DISTINCT table per (input column, FILTER) over (group columns..., input, row number); the
+  // rows it lets through become a BOOL column that is the aggregation's FILTER -- a hidden input column behind the
+  // physical ones
+  struct DistinctSet {
+    int col = -1, filter_col = -1, hidden = -1;
+    crgpu_distinct *h = nullptr;
+    crgpu_deselector *desel = nullptr;
+    DevBuf mask;
+  };
+  std::vector<std::unique_ptr<DistinctSet>> dsets;
+  DevBuf d_rowid;
+  ~crgpu_agg() {
+    for (auto &d : dsets) {
+      if (d->h != nullptr) crgpu_dev_distinct_destroy(d->h);
+      if (d->desel != nullptr) crgpu_dev_deselector_destroy(d->desel);
+    }
+  }
   std::vector<void *> ptrs_stage;
 };
 
@@ -3212,7 +3241,8 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
     op.func = d.func;
     op.col = d.col;
     op.filter_col = d.filter_col;
-    if (d.distinct) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: DISTINCT aggregation is planned on the CPU operator");
+    if (d.distinct && (n_virtual > 0 || d.func == CRGPU_COUNT_ROWS))
+      return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: DISTINCT with computed columns / on COUNT_ROWS");
     if (d.filter_col >= 0 && (d.filter_col >= spec->n_cols || a->types[d.filter_col] != CRGPU_BOOL))
       return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: FILTER column must be a BOOL column");
     if (d.func != CRGPU_COUNT_ROWS && (d.col < 0 || d.col >= spec->n_cols))
@@ -3291,6 +3321,31 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
     }
     if (op.has_seen) op.lseen = a->lds_seen++;
   }
+  // DISTINCT: COUNT / SUM / SUM_INT / AVG only see the first row of every (group, input) tuple (it changes nothing for
+  // MIN / MAX / ANY_NOT_NULL / BOOL_AND / BOOL_OR); aggregations over the same (input, FILTER) share one table
+  for (int f = 0; f < spec->n_aggs; f++) {
+    const crgpu_agg_desc &d = spec->aggs[f];
+    if (!d.distinct || !(d.func == CRGPU_COUNT || d.func == CRGPU_SUM || d.func == CRGPU_SUM_INT || d.func == CRGPU_AVG)) continue;
+    crgpu_agg::DistinctSet *ds = nullptr;
+    for (auto &x : a->dsets)
+      if (x->col == d.col && x->filter_col == d.filter_col) ds = x.get();
+    if (ds == nullptr) {
+      a->dsets.emplace_back(new crgpu_agg::DistinctSet());
+      ds = a->dsets.back().get();
+      ds->col = d.col;
+      ds->filter_col = d.filter_col;
+      ds->hidden = static_cast<int>(a->types.size());
+      a->types.push_back(CRGPU_BOOL);
+      std::vector<int32_t> dt, dc;
+      for (int g : a->group_cols) dt.push_back(a->types[g]);
+      dt.push_back(a->types[d.col]);
+      for (size_t i = 0; i < dt.size(); i++) dc.push_back(static_cast<int32_t>(i));
+      dt.push_back(CRGPU_INT64);  // the row number rides along
+      CRGPU_TRY(crgpu_dev_distinct_create(dt.data(), static_cast<int32_t>(dt.size()), dc.data(), static_cast<int32_t>(dc.size()), 0, 0, &ds->h));
+      if (d.filter_col >= 0) CRGPU_TRY(crgpu_dev_deselector_create(dt.data(), static_cast<int32_t>(dt.size()), &ds->desel));
+    }
+    a->ops[f].filter_col = ds->hidden;  // (the user's FILTER is applied before the DISTINCT test: it is part of the mask)
+  }
   a->out = std::vector<OutCol>(spec->n_aggs);
   a->views.resize(spec->n_aggs);
   CRGPU_TRY(a->counters.ensure(16));
@@ -3344,6 +3399,7 @@ extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   a->dense16 = false;
   for (auto &k : a->ks) k.tail = 0;
   for (auto &o : a->ops) o.any_tail = 0;
+  for (auto &d : a->dsets) CRGPU_TRY(crgpu_dev_distinct_reset(d->h));
   CRGPU_HIP(hipMemsetAsync(a->tails_dev.p, 0, kMaxKeyCols * 8, stream()));
   CRGPU_HIP(hipMemsetAsync(a->any_tails_dev.p, 0, a->ops.size() * 8, stream()));
   CRGPU_HIP(hipMemsetAsync(a->meta.p, 0xFF, static_cast<size_t>(a->cap) * 8, stream()));
@@ -4558,6 +4614,67 @@ static crgpu_status crgpu_dev_agg_consume_impl(crgpu_agg *a, const crgpu_dcol *c
     if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null data pointer");
     in.push_back(to_dcol(cols[c]));
   }
+  if (!a->dsets.empty()) {
+    // DISTINCT aggregations: the rows each table lets through (first occurrence of the (group, input) tuple among the
+    // rows that pass the aggregation's FILTER) as a BOOL column that is the aggregation's FILTER for this call
+    hipStream_t st = stream();
+    CRGPU_TRY(a->d_rowid.ensure(static_cast<size_t>(n) * 8));
+    hipLaunchKernelGGL(iota64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, n, a->d_rowid.as<long long>());
+    CRGPU_HIP(hipGetLastError());
+    for (auto &dsp : a->dsets) {
+      crgpu_agg::DistinctSet &ds = *dsp;
+      CRGPU_TRY(ds.mask.ensure(static_cast<size_t>(n)));
+      CRGPU_HIP(hipMemsetAsync(ds.mask.p, 0, static_cast<size_t>(n), st));
+      const int64_t kSlice = int64_t(1) << 27;  // (the DISTINCT table takes at most 2^28 rows per call)
+      for (int64_t lo = 0; lo < n; lo += kSlice) {
+        const int64_t len = n - lo < kSlice ? n - lo : kSlice;
+        if ((lo & 7) != 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: internal slice offset not byte aligned");
+        std::vector<crgpu_dcol> dc;
+        auto slice = [&](const DCol &c) {
+          crgpu_dcol o;
+          std::memset(&o, 0, sizeof(o));
+          o.type = c.type;
+          if (c.type == CRGPU_BYTES) {
+            o.data = c.data;
+            o.offsets = c.offsets + lo;
+          } else {
+            o.data = static_cast<const uint8_t *>(c.data) + lo * type_width(c.type);
+          }
+          o.valid = c.valid != nullptr ? c.valid + (lo >> 3) : nullptr;
+          return o;
+        };
+        for (int g : a->group_cols) dc.push_back(slice(in[g]));
+        dc.push_back(slice(in[ds.col]));
+        dc.push_back(slice(DCol{CRGPU_INT64, 0, a->d_rowid.p, nullptr, nullptr}));
+        const crgpu_dcol *cols_d = dc.data();
+        int64_t n_d = len;
+        crgpu_dev_result sel;
+        if (ds.filter_col >= 0) {  // FILTER first (aggregators_util.go: the filtering helper wraps the distinct one): NULL = false
+          const DCol &fc = in[ds.filter_col];
+          const uint8_t *keep = static_cast<const uint8_t *>(fc.data) + lo;
+          DevBuf keep_nn;
+          if (fc.valid != nullptr) {  // a NULL filter value does not pass: AND the validity bits in
+            CRGPU_TRY(keep_nn.ensure(static_cast<size_t>(len)));
+            hipLaunchKernelGGL(bool_and_valid_kernel, dim3(grid_for(len, 256)), dim3(256), 0, st, keep, fc.valid + (lo >> 3), len, keep_nn.as<uint8_t>());
+            CRGPU_HIP(hipGetLastError());
+            keep = keep_nn.as<uint8_t>();
+          }
+          CRGPU_TRY(crgpu_dev_deselect(ds.desel, cols_d, n_d, keep, &sel));
+          CRGPU_HIP(hipStreamSynchronize(st));  // keep_nn is released here
+          cols_d = sel.cols;
+          n_d = sel.n;
+        }
+        crgpu_dev_result kept;
+        CRGPU_TRY(crgpu_dev_distinct_consume(ds.h, cols_d, n_d, &kept));
+        if (kept.n > 0) {
+          hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(kept.n, 256)), dim3(256), 0, st,
+                             static_cast<const long long *>(kept.cols[kept.ncols - 1].data), kept.n, ds.mask.as<uint8_t>());
+          CRGPU_HIP(hipGetLastError());
+        }
+      }
+    }
+    for (auto &dsp : a->dsets) in.push_back(DCol{CRGPU_BOOL, 0, dsp->mask.p, nullptr, nullptr});
+  }
   {
     bool done = false;
     CRGPU_TRY(try_bulk(a, in, n, &done));
@@ -4588,7 +4705,7 @@ static crgpu_status crgpu_dev_agg_consume_impl(crgpu_agg *a, const crgpu_dcol *c
     int64_t len = n - pos < kChunk ? n - pos : kChunk;
     if (a->seq == 0 && len > 16384 && n > (int64_t(1) << 20)) len = 16384;  // (a small input is one chunk: discovery would cost more than it can save)
     std::vector<DCol> chunk = in;
-    for (int c = 0; c < nc; c++) {
+    for (size_t c = 0; c < chunk.size(); c++) {  // (the hidden DISTINCT masks too)
       DCol &d = chunk[c];
       if (d.valid != nullptr && (pos & 7) != 0)
         return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: internal chunk offset not byte aligned");

@@ -266,8 +266,9 @@ class HashAggregator(Operator):
         self.capacity = capacity
         descs = (_lib.AggDesc * max(len(aggs), 1))()
         self.out_types = []
-        for i, (f, c, fc) in enumerate(aggs):
-            descs[i] = _lib.AggDesc(f, c, fc, 0)
+        for i, a in enumerate(aggs):  # (func, col, filter_col[, distinct])
+            f, c, fc = a[0], a[1], a[2]
+            descs[i] = _lib.AggDesc(f, c, fc, int(bool(a[3])) if len(a) > 3 else 0)
             self.out_types.append(AGG_OUTPUT_TYPE.get(f, types[c] if c >= 0 else cd.INT64))
         self._keep = (_i32(types), _i32(group_cols), descs)
         spec = _lib.AggSpec(len(types), len(group_cols), self._keep[0], self._keep[1], len(aggs), 0, descs)

@@ -213,7 +213,10 @@ typedef struct crgpu_agg_desc {
   int32_t func;       /* crgpu_agg_func */
   int32_t col;        /* AggregatorSpec_Aggregation.ColIdx[0]; -1 for COUNT_ROWS */
   int32_t filter_col; /* FilterColIdx (BOOL column) or -1 */
-  int32_t distinct;   /* must be 0: DISTINCT aggregation => CRGPU_ERR_UNSUPPORTED */
+  int32_t distinct;   /* AggregatorSpec_Aggregation.Distinct: COUNT / SUM / SUM_INT / AVG see the first row of every (group,
+                       * input) tuple among the rows passing their FILTER (aggregators_util.go:298-373); ignored for
+                       * MIN / MAX / ANY_NOT_NULL / BOOL_AND / BOOL_OR; COUNT_ROWS or computed columns =>
+                       * CRGPU_ERR_UNSUPPORTED */
 } crgpu_agg_desc;
 
 typedef struct crgpu_agg_spec {

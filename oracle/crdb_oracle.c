@@ -1252,6 +1252,9 @@ typedef struct agg_state {
   int64_t ival;
   double fval;
   uint8_t *bytes; uint32_t blen, bcap;
+  /* DISTINCT: the input values this (group, aggregation) has seen, as [null u8][len u32][bytes] records
+   * (aggregators_util.go:298-373 keeps a map of encoded tuples per bucket) */
+  uint8_t *seen; int64_t seen_len, seen_cap;
 } agg_state;
 
 typedef struct agg_bucket { agg_state *fns; } agg_bucket;
@@ -1470,11 +1473,47 @@ typedef struct hash_aggregator {
   agg_bucket *buckets; int64_t nbuckets, buckets_cap;
   int_list *eq_chains; int64_t eq_cap;
   int64_t *int_slice, *another_int_slice, *sel;
-  int64_t *filter_sel;
+  int64_t *filter_sel, *distinct_sel;
   int err;
 } hash_aggregator;
 
 static _Thread_local hash_aggregator *g_last_agg = NULL;
+
+/* 1 if row i's value of `col` is new for this state (and remembers it) */
+static int distinct_is_new(agg_state *s, const ora_col *col, int64_t i) {
+  uint8_t rec[5 + 8];
+  const uint8_t *val = NULL;
+  uint32_t len = 0;
+  uint8_t isnull = col_is_null(col, i) ? 1 : 0;
+  int64_t iv; double fv; uint8_t bv;
+  if (!isnull) {
+    switch (col->type) {
+    case ORA_BYTES: val = col_get_bytes(col, i, &len); break;
+    case ORA_FLOAT64: fv = col_get_f64(col, i); if (fv == 0) fv = 0; val = (const uint8_t *)&fv; len = 8; break;
+    case ORA_BOOL: bv = col_get_bool(col, i); val = &bv; len = 1; break;
+    default: iv = col_get_int(col, i); val = (const uint8_t *)&iv; len = 8; break;
+    }
+  }
+  (void)rec;
+  for (int64_t p = 0; p < s->seen_len;) {
+    uint8_t n0 = s->seen[p];
+    uint32_t l0;
+    memcpy(&l0, s->seen + p + 1, 4);
+    if (n0 == isnull && l0 == len && (len == 0 || memcmp(s->seen + p + 5, val, len) == 0)) return 0;
+    p += 5 + l0;
+  }
+  if (s->seen_len + 5 + len > s->seen_cap) {
+    int64_t nc = s->seen_cap ? s->seen_cap * 2 : 64;
+    while (nc < s->seen_len + 5 + len) nc *= 2;
+    s->seen = (uint8_t *)xrealloc(s->seen, (size_t)nc);
+    s->seen_cap = nc;
+  }
+  s->seen[s->seen_len] = isnull;
+  memcpy(s->seen + s->seen_len + 1, &len, 4);
+  if (len) memcpy(s->seen + s->seen_len + 5, val, len);
+  s->seen_len += 5 + len;
+  return 1;
+}
 
 /* aggregatorHelper.performAggregation (aggregators_util.go:102-108) and its
  * FILTER flavour (:216-234, filter = rows whose BOOL filter column is true). */
@@ -1490,6 +1529,14 @@ static void ha_perform_aggregation(hash_aggregator *op, const ora_col *cols, con
       for (int64_t k = 0; k < n; k++)
         if (!col_is_null(fc, chain[k]) && col_get_bool(fc, chain[k])) op->filter_sel[len++] = chain[k];
       sel = op->filter_sel;
+      if (len == 0) continue;
+    }
+    if (spec->distinct && spec->col >= 0) { /* after the FILTER (the filtering helper wraps the distinct one) */
+      int64_t m = 0;
+      for (int64_t k = 0; k < len; k++)
+        if (distinct_is_new(&bucket->fns[f], &cols[spec->col], sel[k])) op->distinct_sel[m++] = sel[k];
+      sel = op->distinct_sel;
+      len = m;
       if (len == 0) continue;
     }
     int e = agg_compute(&bucket->fns[f], spec, cols, sel, len);
@@ -1518,6 +1565,7 @@ static void ha_online_agg(hash_aggregator *op, const ora_col *cols, int64_t n) {
     op->another_int_slice = (int64_t *)xrealloc(op->another_int_slice, (size_t)n * 8);
     op->sel = (int64_t *)xrealloc(op->sel, (size_t)n * 8);
     op->filter_sel = (int64_t *)xrealloc(op->filter_sel, (size_t)n * 8);
+    op->distinct_sel = (int64_t *)xrealloc(op->distinct_sel, (size_t)n * 8);
     op->eq_cap = n;
   }
   /* Step 1 */
@@ -1581,12 +1629,12 @@ static void ha_destroy(hash_aggregator *op) {
   if (!op) return;
   ht_free(&op->ht);
   for (int64_t b = 0; b < op->nbuckets; b++) {
-    for (int f = 0; f < op->naggs; f++) free(op->buckets[b].fns[f].bytes);
+    for (int f = 0; f < op->naggs; f++) { free(op->buckets[b].fns[f].bytes); free(op->buckets[b].fns[f].seen); }
     free(op->buckets[b].fns);
   }
   free(op->buckets);
   for (int64_t i = 0; i < op->eq_cap; i++) free(op->eq_chains[i].v);
-  free(op->eq_chains); free(op->int_slice); free(op->another_int_slice); free(op->sel); free(op->filter_sel);
+  free(op->eq_chains); free(op->int_slice); free(op->another_int_slice); free(op->sel); free(op->filter_sel); free(op->distinct_sel);
   free(op);
 }
 

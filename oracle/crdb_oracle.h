@@ -61,7 +61,7 @@ typedef struct ora_agg_spec {
   int32_t func;       /* ORA_* aggregate */
   int32_t col;        /* input column ordinal, -1 for COUNT_ROWS */
   int32_t filter_col; /* BOOL column ordinal or -1 (FILTER clause) */
-  int32_t _pad;
+  int32_t distinct;   /* AggregatorSpec_Aggregation.Distinct */
 } ora_agg_spec;
 
 typedef struct ora_result ora_result;

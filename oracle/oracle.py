@@ -24,7 +24,7 @@ class OraCol(C.Structure):
 
 
 class OraAggSpec(C.Structure):
-    _fields_ = [("func", C.c_int32), ("col", C.c_int32), ("filter_col", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("func", C.c_int32), ("col", C.c_int32), ("filter_col", C.c_int32), ("distinct", C.c_int32)]
 
 
 def build(force=False):
@@ -177,13 +177,14 @@ class OracleError(Exception):
 
 
 def hash_agg(cols, group_cols, aggs, batch_size=cd.BATCH_SIZE, max_buffered=cd.MAX_BATCH_SIZE, initial_buckets=256):
-    """aggs: list of (func, col or -1, filter_col or -1)."""
+    """aggs: list of (func, col or -1, filter_col or -1[, distinct])."""
     cc, _k = make_cols(cols)
     gc = np.ascontiguousarray(group_cols, dtype=np.int32)
     specs = (OraAggSpec * max(len(aggs), 1))()
     for i, a in enumerate(aggs):
         specs[i].func, specs[i].col = a[0], a[1]
         specs[i].filter_col = a[2] if len(a) > 2 else -1
+        specs[i].distinct = int(bool(a[3])) if len(a) > 3 else 0
     err = C.c_int32(0)
     n = len(cols[0]) if cols else 0
     res = lib().ora_hash_agg(cc, len(cols), n, _ptr(gc), len(gc), specs, len(aggs), batch_size, max_buffered,

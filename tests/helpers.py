@@ -219,8 +219,6 @@ def dropped_agg_pairs():
                 t = c["types"][col] if col >= 0 else None
                 if fn not in SUPPORTED_AGGS:
                     out.append((cid, i, fn, "function outside the GPU path"))
-                elif c.get("agg_distinct") and c["agg_distinct"][i]:
-                    out.append((cid, i, fn, "DISTINCT aggregation"))
                 elif fn in ("SUM", "AVG") and t != "float64" and type_id(t) != cd.FLOAT64:
                     out.append((cid, i, fn, f"{fn} over {t}: DECIMAL result (apd)"))
     return out
@@ -228,7 +226,7 @@ def dropped_agg_pairs():
 
 def prepare_agg_case(c):
     """Returns (cols, group_cols, aggs[(func, col, filter)], expected_rows) keeping
-    only the aggregations in scope (no DISTINCT, no CONCAT_AGG, SUM/AVG over
+    only the aggregations in scope (no CONCAT_AGG, SUM/AVG over
     float only); expected columns are projected accordingly."""
     types = [type_id(t) for t in c["types"]]
     cols = tuples_to_vecs(c["input"], types)
@@ -236,14 +234,12 @@ def prepare_agg_case(c):
     for i, fn in enumerate(c["agg_fns"]):
         if fn not in SUPPORTED_AGGS:
             continue
-        if c.get("agg_distinct") and c["agg_distinct"][i]:
-            continue
         col = c["agg_cols"][i][0] if c["agg_cols"][i] else -1
         if fn in ("SUM", "AVG") and types[col] != cd.FLOAT64:
             continue  # SUM/AVG over INT => DECIMAL result (apd), out of scope
         flt = c["agg_filter"][i] if c.get("agg_filter") else -1
         keep.append(i)
-        aggs.append((AGG_FUNC[fn], col, flt))
+        aggs.append((AGG_FUNC[fn], col, flt, bool(c.get("agg_distinct") and c["agg_distinct"][i])))
     c.setdefault("_dropped", [(i, fn) for i, fn in enumerate(c["agg_fns"]) if i not in keep])
     expected = []
     for r in c["expected"]:

@@ -698,11 +698,11 @@ def test_agg_dropped_reference_columns_are_exactly_the_unsupported_specs():
     from cockroach_amd import _lib
     from cockroach_amd import device as dev
     dropped = H.dropped_agg_pairs()
-    assert len(dropped) == 11 and sum(1 for d in dropped if d[1] < 0) == 2
+    assert len(dropped) == 5 and sum(1 for d in dropped if d[1] < 0) == 2
     reasons = {d[3].split(":")[0] for d in dropped if d[1] >= 0}
-    assert reasons == {"function outside the GPU path", "DISTINCT aggregation"}
-    with pytest.raises(_lib.CrgpuError) as e:  # DISTINCT
-        dev.Agg([cd.INT64, cd.INT64], [0], [(F["COUNT"], 1, -1, True)])
+    assert reasons == {"function outside the GPU path"}
+    with pytest.raises(_lib.CrgpuError) as e:  # DISTINCT on COUNT_ROWS has no input to be distinct over
+        dev.Agg([cd.INT64, cd.INT64], [0], [(F["COUNT_ROWS"], -1, -1, True)])
     assert e.value.code == _lib.ERR_UNSUPPORTED
     with pytest.raises(_lib.CrgpuError) as e:  # CONCAT_AGG (execinfrapb.AggregatorSpec_CONCAT_AGG = 4)
         dev.Agg([cd.INT64, cd.BYTES], [0], [(4, 1, -1)])
@@ -781,3 +781,46 @@ def test_agg_two_to_the_thirty_rows_in_one_call():
         s = float(x[m].sum().item())  # integers below 2^53: exact in any order
         assert got[g][0] == cnt and got[g][1] == s and got[g][2] == s / cnt
     assert got[6][0] == 9
+
+
+@pytest.mark.parametrize("xtype", [cd.INT64, cd.FLOAT64, cd.BYTES])
+@pytest.mark.parametrize("ngroups", [5, 3000])
+def test_distinct_aggregations_vs_oracle(oracle, xtype, ngroups):
+    """DISTINCT aggregations (aggregators_util.go:298-373; the reference's DistinctAggregation and
+    DistinctFilteringAggregation cases run with the golden tables): COUNT / SUM_INT / SUM / AVG over the first row of
+    every (group, input) tuple among the rows that pass the aggregation's FILTER, NULL inputs and NULL filter values
+    included, beside plain aggregations of the same columns, fed in several consume() calls."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(ngroups * 7 + xtype)
+    n = 60_000
+    g = cd.Vec.from_numpy(cd.INT64, rng.integers(0, ngroups, n, dtype=np.int64), rng.random(n) > 0.02)
+    xi = rng.integers(0, 12, n, dtype=np.int64)
+    xvalid = rng.random(n) > 0.1
+    if xtype == cd.INT64:
+        x = cd.Vec.from_numpy(cd.INT64, xi * 1_000_003 - 5, xvalid)
+        fns = [F["COUNT"], F["SUM_INT"], F["SUM"]]
+    elif xtype == cd.FLOAT64:
+        x = cd.Vec.from_numpy(cd.FLOAT64, xi.astype(np.float64) * 0.25, xvalid)
+        fns = [F["COUNT"], F["SUM"], F["AVG"]]
+    else:
+        x = cd.Vec.from_values(cd.BYTES, [None if not v else b"v%d" % k * (1 + k % 3) for k, v in zip(xi.tolist(), xvalid.tolist())])
+        fns = [F["COUNT"]]
+    flt = cd.Vec.from_numpy(cd.BOOL, rng.random(n) > 0.4, rng.random(n) > 0.1)
+    cols = [g, x, flt]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1, False), (F["COUNT_ROWS"], -1, -1, False)]
+    for fn in fns:
+        aggs += [(fn, 1, -1, True), (fn, 1, 2, True), (fn, 1, -1, False)]
+    want = H.vecs_to_tuples(oracle.hash_agg(cols, [0], aggs))
+    a = dev.Agg([v.type for v in cols], [0], aggs)
+    try:
+        for lo in range(0, n, 16_384):
+            part = [v.take(np.arange(lo, min(n, lo + 16_384))) for v in cols]
+            a.consume([dev.upload(v) for v in part], len(part[0]))
+        got = H.vecs_to_tuples(dev.result_to_vecs(a.finish()))
+        H.assert_same_multiset(got, want)
+        a.reset()  # the DISTINCT tables are reset with the aggregator
+        a.consume([dev.upload(v.take(np.arange(0, 5000))) for v in cols], 5000)
+        got = H.vecs_to_tuples(dev.result_to_vecs(a.finish()))
+        H.assert_same_multiset(got, H.vecs_to_tuples(oracle.hash_agg([v.take(np.arange(0, 5000)) for v in cols], [0], aggs)))
+    finally:
+        a.close()

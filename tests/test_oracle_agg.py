@@ -2,7 +2,7 @@
 tables (pkg/sql/colexec/aggregators_test.go:186-785,
 hash_aggregator_test.go:34-397) and the random recipe of TestAggregatorRandom
 (aggregators_test.go:841-983).  DECIMAL columns run as FLOAT64 and
-DISTINCT / CONCAT_AGG aggregations are projected away (out of scope)."""
+CONCAT_AGG aggregations are projected away (out of scope); DISTINCT aggregations run."""
 import numpy as np
 import pytest
 
