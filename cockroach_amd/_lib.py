@@ -48,7 +48,7 @@ class AggDesc(C.Structure):  # crgpu_agg_desc
 
 class AggSpec(C.Structure):  # crgpu_agg_spec
     _fields_ = [("n_cols", C.c_int32), ("n_group", C.c_int32), ("types", C.POINTER(C.c_int32)),
-                ("group_cols", C.POINTER(C.c_int32)), ("n_aggs", C.c_int32), ("_pad", C.c_int32),
+                ("group_cols", C.POINTER(C.c_int32)), ("n_aggs", C.c_int32), ("n_ordered", C.c_int32),
                 ("aggs", C.POINTER(AggDesc))]
 
 
@@ -137,6 +137,7 @@ SYMBOLS = [
     ("crgpu_dev_agg_create_fused", _I32, [C.POINTER(AggSpec), _I32, C.POINTER(AggVcol), C.POINTER(_VP)]),
     ("crgpu_dev_agg_consume", _I32, [_VP, C.POINTER(DCol), _I64]),
     ("crgpu_dev_agg_finish", _I32, [_VP, C.POINTER(DevResult)]),
+    ("crgpu_dev_agg_emit_ready", _I32, [_VP, C.POINTER(DevResult)]),
     ("crgpu_dev_agg_reset", _I32, [_VP]),
     ("crgpu_dev_agg_destroy", None, [_VP]),
     ("crgpu_dev_partitioner_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(_VP)]),

@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 
 #include "device.h"
@@ -2947,7 +2948,28 @@ struct AggOpHost {
   bool uses_any_store() const { return (kind == ACC_ANY_ROW && in_type == CRGPU_BYTES) || is_minmax_bytes(kind); }
 };
 
+// Partially ordered input (AggregatorSpec.OrderedGroupCols; hash_aggregator_tmpl.go:160-169, 256-306): see the section
+// at the end of this file.
+struct OrderedPiece {
+  std::vector<OutCol> cols;
+  int64_t n = 0;
+};
+struct OrderedState {
+  crgpu_agg *inner = nullptr;   // aggregates (the caller's columns..., row number) with MIN(row number) behind the caller's aggregations
+  std::vector<int> ordered_cols;  // input ordinals of the ordered grouping columns
+  int n_cols = 0, n_aggs = 0;
+  int64_t rows_since_flush = 0;   // row numbers restart at every flush
+  bool has_prev = false;
+  int prev_slot = 0;
+  DevBuf hashes, rowid, prev_hash, last_b, flags, pos, perm, scratch;
+  std::vector<DevBuf> shifted;    // validity bitmaps of a sub-batch that does not start at a byte boundary
+  std::deque<std::unique_ptr<OrderedPiece>> ready;
+  std::unique_ptr<OrderedPiece> handed;  // the piece the caller holds (valid until the next call on the handle)
+  std::vector<crgpu_dcol> views;
+};
+
 struct crgpu_agg : crgpu::Handle {
+  std::unique_ptr<OrderedState> ord;  // set: this handle only routes to ord->inner
   std::vector<int> types, group_cols;
   std::vector<AggOpHost> ops;
   bool need_any_fix = false;
@@ -3001,6 +3023,7 @@ struct crgpu_agg : crgpu::Handle {
   std::vector<std::unique_ptr<DistinctSet>> dsets;
   DevBuf d_rowid;
   ~crgpu_agg() {
+    if (ord && ord->inner != nullptr) crgpu_dev_agg_destroy(ord->inner);
     for (auto &d : dsets) {
       if (d->h != nullptr) crgpu_dev_distinct_destroy(d->h);
       if (d->desel != nullptr) crgpu_dev_deselector_destroy(d->desel);
@@ -3168,12 +3191,15 @@ static PackSpec plan_pack(const std::vector<int> &types, const std::vector<int> 
 }
 
 static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtual, const crgpu_agg_vcol *vcols, crgpu_agg **out);
+static crgpu_status ordered_create(const crgpu_agg_spec *spec, crgpu_agg **out);
 extern "C" crgpu_status crgpu_dev_agg_create(const crgpu_agg_spec *spec, crgpu_agg **out) {
+  if (spec != nullptr && spec->n_ordered != 0) return ordered_create(spec, out);
   return agg_create_impl(spec, 0, nullptr, out);
 }
 extern "C" crgpu_status crgpu_dev_agg_create_fused(const crgpu_agg_spec *spec, int32_t n_virtual, const crgpu_agg_vcol *vcols,
                                                    crgpu_agg **out) {
   if (n_virtual < 0 || (n_virtual > 0 && vcols == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create_fused: null computed columns");
+  if (spec != nullptr && spec->n_ordered != 0) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create_fused: ordered grouping columns with computed columns");
   return agg_create_impl(spec, n_virtual, vcols, out);
 }
 
@@ -3388,10 +3414,12 @@ extern "C" void crgpu_dev_agg_destroy(crgpu_agg *a) {
   delete a;
 }
 
+static crgpu_status ordered_reset(crgpu_agg *a);
 extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   if (a == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_reset: null handle");
   CRGPU_ENTER(a);
   a->cancelled = 0;
+  if (a->ord) return ordered_reset(a);
   a->ngroups = 0;
   a->seq = 0;
   a->new_ratio = 1.0;
@@ -4719,8 +4747,10 @@ static crgpu_status crgpu_dev_agg_consume_impl(crgpu_agg *a, const crgpu_dcol *c
   return CRGPU_OK;
 }
 
+static crgpu_status ordered_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n);
+static crgpu_status ordered_finish(crgpu_agg *a, crgpu_dev_result *res);
 extern "C" crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
-  const crgpu_status s_ = crgpu_dev_agg_consume_impl(a, cols, n);
+  const crgpu_status s_ = a != nullptr && a->ord ? ordered_consume(a, cols, n) : crgpu_dev_agg_consume_impl(a, cols, n);
   if (s_ == CRGPU_OK && a != nullptr) note_rows(a, n, 0);
   return s_;
 }
@@ -4918,7 +4948,313 @@ static crgpu_status crgpu_dev_agg_finish_impl(crgpu_agg *a, crgpu_dev_result *re
 }
 
 extern "C" crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *res) {
-  const crgpu_status s_ = crgpu_dev_agg_finish_impl(a, res);
+  const crgpu_status s_ = a != nullptr && a->ord ? ordered_finish(a, res) : crgpu_dev_agg_finish_impl(a, res);
   if (s_ == CRGPU_OK && a != nullptr) note_rows(a, 0, res->n);
+  return s_;
+}
+
+// ====================================================================== partially ordered input
+// AggregatorSpec.OrderedGroupCols (hash_aggregator_tmpl.go:160-169, 256-306; cases oneOrderedCol ... spilloverAfterEmit,
+// hash_aggregator_test.go:104-397): the input arrives sorted on some of the grouping columns, so every group is complete
+// once those columns change, and the reference aggregates one run of equal ordered values at a time, emits its groups and
+// starts over with an empty table -- the output is ordered on the ordered columns (PartialOrderedVerifier,
+// colexectestutils/utils.go:1337-1400: the runs in input order, any order inside a run) and the table never holds more
+// than one run.  Here: per call, the LAST place where the ordered columns change is found (64-bit hashes of the ordered
+// columns of neighbouring rows are compared: equal values hash equal, so a run is never cut in two; a collision between
+// two neighbouring runs only delays their emission, the table still keys on every grouping column); the rows in front
+// of it complete every group seen so far: they are consumed, the whole table is finished into a "piece" whose rows are
+// put in the order of each group's first input row (a hidden MIN(row number) aggregation; first-row order is run order),
+// the table is reset and the rest of the call is consumed.  Pieces are handed out by crgpu_dev_agg_emit_ready (and by
+// crgpu_dev_agg_finish for the last ones), one per call, oldest first.  One flush per call at most: the cost of the
+// ordering is a hash pass over the ordered columns and, per call with a change, one finish + one gather of the results.
+__global__ __launch_bounds__(256) void ord_last_change_kernel(const uint64_t *__restrict__ h, int64_t n, const uint64_t *__restrict__ prev,
+                                                              int has_prev, long long *__restrict__ last, uint64_t *__restrict__ prev_out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  long long mine = -1;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t cur = h[i];
+    const uint64_t before = i > 0 ? h[i - 1] : (has_prev ? prev[0] : cur);
+    if (cur != before) mine = i;  // (i grows along the loop)
+    if (i == n - 1) prev_out[0] = cur;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long other = __shfl_xor(mine, off);
+    mine = other > mine ? other : mine;
+  }
+  if ((threadIdx.x & 63) == 0 && mine >= 0) atomicMax(last, mine);
+}
+__global__ __launch_bounds__(256) void ord_iota_kernel(long long base, int64_t n, long long *__restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = base + i;
+}
+// dst bit j = src bit (bit_off + j), j < n (dst bytes beyond are zero-filled up to the last one written)
+__global__ __launch_bounds__(256) void ord_bitmap_shift_kernel(const uint8_t *__restrict__ src, int64_t bit_off, int64_t n, uint8_t *__restrict__ dst) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t nbytes = (n + 7) >> 3;
+  if (j >= nbytes) return;
+  const int64_t b0 = (bit_off >> 3) + j;
+  const int s = static_cast<int>(bit_off & 7);
+  const int64_t last_src = (bit_off + n - 1) >> 3;
+  unsigned v = src[b0] >> s;
+  if (s != 0 && b0 + 1 <= last_src) v |= static_cast<unsigned>(src[b0 + 1]) << (8 - s);
+  dst[j] = static_cast<uint8_t>(v);
+}
+__global__ __launch_bounds__(256) void ord_mark_kernel(const long long *__restrict__ first, int64_t ng, int64_t span, uint8_t *__restrict__ flags,
+                                                       unsigned int *__restrict__ bad) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const long long r = first[g];
+  if (r < 0 || r >= span) { atomicOr(bad, 1u); return; }
+  flags[r] = 1;
+}
+// pos[0..ng) = the marked row numbers in ascending order; group g goes to the place of its first row
+__global__ __launch_bounds__(256) void ord_rank_kernel(const long long *__restrict__ first, const int32_t *__restrict__ pos, int64_t ng,
+                                                       int32_t *__restrict__ perm) {
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const int32_t want = static_cast<int32_t>(first[g]);
+  int64_t lo = 0, hi = ng - 1;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (pos[mid] < want) lo = mid + 1;
+    else hi = mid;
+  }
+  perm[lo] = static_cast<int32_t>(g);
+}
+
+static constexpr int64_t kOrdSlice = int64_t(1) << 27;             // rows hashed / split per step (a multiple of 8)
+static constexpr int64_t kOrdMaxRun = (int64_t(1) << 31) - kOrdSlice - 8;  // row numbers are gathered through 32-bit indices
+
+static crgpu_status ordered_create(const crgpu_agg_spec *spec, crgpu_agg **out) {
+  CRGPU_TRY(ensure_init());
+  if (out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: null argument");
+  if (spec->n_ordered < 0 || spec->n_ordered > spec->n_group)
+    return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_create: n_ordered counts leading entries of group_cols");
+  if (spec->n_cols < 0 || spec->n_cols + 1 > kMaxCols || spec->n_aggs < 1 || spec->n_aggs + 1 > kMaxAggs)
+    return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_create: no room for the row-number column of the ordered form");
+  std::vector<int32_t> types(spec->types, spec->types + spec->n_cols);
+  types.push_back(CRGPU_INT64);
+  std::vector<crgpu_agg_desc> aggs(spec->aggs, spec->aggs + spec->n_aggs);
+  crgpu_agg_desc first_row;
+  std::memset(&first_row, 0, sizeof(first_row));
+  first_row.func = CRGPU_MIN;
+  first_row.col = spec->n_cols;
+  first_row.filter_col = -1;
+  aggs.push_back(first_row);
+  crgpu_agg_spec in = *spec;
+  in.n_cols = spec->n_cols + 1;
+  in.types = types.data();
+  in.n_aggs = spec->n_aggs + 1;
+  in.aggs = aggs.data();
+  in.n_ordered = 0;
+  crgpu_agg *inner = nullptr;
+  CRGPU_TRY(agg_create_impl(&in, 0, nullptr, &inner));
+  std::unique_ptr<crgpu_agg> a(new crgpu_agg());
+  a->ord.reset(new OrderedState());
+  a->ord->inner = inner;  // (destroyed with `a` from here on)
+  {
+    crgpu_status os = a->open();
+    if (os != CRGPU_OK) return os;
+  }
+  CRGPU_ENTER(a.get());
+  OrderedState &o = *a->ord;
+  o.n_cols = spec->n_cols;
+  o.n_aggs = spec->n_aggs;
+  for (int i = 0; i < spec->n_cols; i++) a->types.push_back(spec->types[i]);
+  for (int i = 0; i < spec->n_group; i++) a->group_cols.push_back(spec->group_cols[i]);
+  for (int i = 0; i < spec->n_ordered; i++) o.ordered_cols.push_back(spec->group_cols[i]);
+  a->n_phys = spec->n_cols;
+  o.shifted = std::vector<DevBuf>(static_cast<size_t>(spec->n_cols));
+  o.views.resize(static_cast<size_t>(spec->n_aggs));
+  CRGPU_TRY(o.prev_hash.ensure(16));
+  CRGPU_TRY(o.last_b.ensure(16));
+  *out = a.release();
+  return CRGPU_OK;
+}
+
+static crgpu_status ordered_reset(crgpu_agg *a) {
+  OrderedState &o = *a->ord;
+  CRGPU_TRY(crgpu_dev_agg_reset(o.inner));
+  o.rows_since_flush = 0;
+  o.has_prev = false;
+  o.ready.clear();
+  o.handed.reset();
+  return CRGPU_OK;
+}
+
+// rows [off, off + m) of the caller's columns + their row numbers -> the inner aggregator
+static crgpu_status ordered_feed(crgpu_agg *a, const crgpu_dcol *cols, int64_t off, int64_t m) {
+  if (m <= 0) return CRGPU_OK;
+  OrderedState &o = *a->ord;
+  hipStream_t st = stream();
+  std::vector<crgpu_dcol> dc(static_cast<size_t>(o.n_cols) + 1);
+  for (int c = 0; c < o.n_cols; c++) {
+    crgpu_dcol d = cols[c];
+    if (d.type == CRGPU_BYTES) d.offsets = d.offsets + off;
+    else d.data = static_cast<const uint8_t *>(d.data) + off * type_width(d.type);
+    if (d.valid != nullptr) {
+      if ((off & 7) == 0) {
+        d.valid = d.valid + (off >> 3);
+      } else {
+        DevBuf &sb = o.shifted[static_cast<size_t>(c)];
+        CRGPU_TRY(sb.ensure(static_cast<size_t>((m + 7) / 8 + 8)));
+        hipLaunchKernelGGL(ord_bitmap_shift_kernel, dim3(grid_for((m + 7) / 8, 256)), dim3(256), 0, st, cols[c].valid, off, m, sb.as<uint8_t>());
+        CRGPU_HIP(hipGetLastError());
+        d.valid = sb.as<uint8_t>();
+      }
+    }
+    dc[static_cast<size_t>(c)] = d;
+  }
+  CRGPU_TRY(o.rowid.ensure(static_cast<size_t>(m) * 8));
+  hipLaunchKernelGGL(ord_iota_kernel, dim3(grid_for(m, 256)), dim3(256), 0, st, static_cast<long long>(o.rows_since_flush), m, o.rowid.as<long long>());
+  CRGPU_HIP(hipGetLastError());
+  crgpu_dcol &rc = dc[static_cast<size_t>(o.n_cols)];
+  std::memset(&rc, 0, sizeof(rc));
+  rc.type = CRGPU_INT64;
+  rc.data = o.rowid.p;
+  CRGPU_TRY(crgpu_dev_agg_consume_impl(o.inner, dc.data(), m));
+  // (the inner call may return with its kernels still queued: rowid / shifted are rewritten by this stream only)
+  o.rows_since_flush += m;
+  return CRGPU_OK;
+}
+
+// every group in the table is complete: finish, order by first row, keep as a piece, start over
+static crgpu_status ordered_flush(crgpu_agg *a) {
+  OrderedState &o = *a->ord;
+  hipStream_t st = stream();
+  if (o.rows_since_flush == 0) return CRGPU_OK;
+  crgpu_dev_result r;
+  CRGPU_TRY(crgpu_dev_agg_finish_impl(o.inner, &r));
+  const int64_t ng = r.n;
+  if (ng > 0) {
+    if (r.ncols != o.n_aggs + 1) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg: ordered form lost its row-number column");
+    const long long *first = static_cast<const long long *>(r.cols[o.n_aggs].data);
+    const int64_t span = o.rows_since_flush;
+    CRGPU_TRY(o.flags.ensure(static_cast<size_t>(span)));
+    CRGPU_TRY(o.pos.ensure(static_cast<size_t>(ng) * 4));
+    CRGPU_TRY(o.perm.ensure(static_cast<size_t>(ng) * 4));
+    CRGPU_HIP(hipMemsetAsync(o.flags.p, 0, static_cast<size_t>(span), st));
+    CRGPU_HIP(hipMemsetAsync(o.last_b.p, 0, 16, st));
+    unsigned int *bad = o.last_b.as<unsigned int>() + 2;
+    hipLaunchKernelGGL(ord_mark_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, first, ng, span, o.flags.as<uint8_t>(), bad);
+    CRGPU_HIP(hipGetLastError());
+    int64_t marked = 0;
+    CRGPU_TRY(select_flagged(o.flags.as<uint8_t>(), span, o.pos.as<int32_t>(), o.scratch, &marked));
+    unsigned int bad_h = 0;
+    CRGPU_HIP(hipMemcpyAsync(&bad_h, bad, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (bad_h != 0 || marked != ng) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg: first rows of the groups are not distinct row numbers");
+    hipLaunchKernelGGL(ord_rank_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, first, o.pos.as<int32_t>(), ng, o.perm.as<int32_t>());
+    CRGPU_HIP(hipGetLastError());
+    std::unique_ptr<OrderedPiece> piece(new OrderedPiece());
+    piece->n = ng;
+    piece->cols = std::vector<OutCol>(static_cast<size_t>(o.n_aggs));
+    for (int c = 0; c < o.n_aggs; c++)
+      CRGPU_TRY(materialize(to_dcol(r.cols[c]), o.perm.as<int32_t>(), ng, false, piece->cols[static_cast<size_t>(c)], o.scratch));
+    o.ready.push_back(std::move(piece));
+  }
+  CRGPU_TRY(crgpu_dev_agg_reset(o.inner));
+  o.rows_since_flush = 0;
+  return CRGPU_OK;
+}
+
+static crgpu_status ordered_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t n) {
+  CRGPU_ENTER(a);
+  CRGPU_CHECK_CANCEL(a);
+  if (n < 0) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: negative row count");
+  if (n == 0) return CRGPU_OK;
+  if (cols == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null columns");
+  OrderedState &o = *a->ord;
+  for (int c = 0; c < o.n_cols; c++) {
+    if (cols[c].type != a->types[static_cast<size_t>(c)]) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: column type differs from the spec");
+    if (cols[c].type == CRGPU_BYTES && cols[c].offsets == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: BYTES column without offsets");
+    if (cols[c].type != CRGPU_BYTES && cols[c].data == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_consume: null data pointer");
+  }
+  hipStream_t st = stream();
+  for (int64_t lo = 0; lo < n; lo += kOrdSlice) {
+    const int64_t len = n - lo < kOrdSlice ? n - lo : kOrdSlice;
+    long long b = -1;
+    if (o.ordered_cols.empty()) {
+      b = -1;  // no ordered column: one run
+    } else {
+      KeyCols kc;
+      std::memset(&kc, 0, sizeof(kc));
+      kc.n = static_cast<int32_t>(o.ordered_cols.size());
+      for (int i = 0; i < kc.n; i++) {
+        DCol d = to_dcol(cols[o.ordered_cols[static_cast<size_t>(i)]]);
+        if (d.type == CRGPU_BYTES) d.offsets += lo;
+        else d.data = static_cast<const uint8_t *>(d.data) + lo * type_width(d.type);
+        if (d.valid != nullptr) d.valid += lo >> 3;  // (lo is a multiple of 2^27)
+        kc.c[i] = d;
+      }
+      CRGPU_TRY(o.hashes.ensure(static_cast<size_t>(len) * 8));
+      CRGPU_TRY(launch_hash(kc, len, 1, 64, 0, o.hashes.p));
+      const long long minus1 = -1;
+      CRGPU_HIP(hipMemcpyAsync(o.last_b.p, &minus1, 8, hipMemcpyHostToDevice, st));
+      const int64_t want = (len + 255) / 256;
+      const int grid = static_cast<int>(want < 4096 ? want : 4096);
+      hipLaunchKernelGGL(ord_last_change_kernel, dim3(grid), dim3(256), 0, st, o.hashes.as<uint64_t>(), len,
+                         o.prev_hash.as<uint64_t>() + o.prev_slot, o.has_prev ? 1 : 0, o.last_b.as<long long>(),
+                         o.prev_hash.as<uint64_t>() + (o.prev_slot ^ 1));
+      CRGPU_HIP(hipGetLastError());
+      CRGPU_HIP(hipMemcpyAsync(&b, o.last_b.p, 8, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipStreamSynchronize(st));
+      o.prev_slot ^= 1;
+      o.has_prev = true;
+    }
+    if (b >= 0) {
+      CRGPU_TRY(ordered_feed(a, cols, lo, b));
+      CRGPU_TRY(ordered_flush(a));
+      CRGPU_TRY(ordered_feed(a, cols, lo + b, len - b));
+    } else {
+      if (o.rows_since_flush + len > kOrdMaxRun)
+        return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^31 rows without a change in the ordered columns: plan the unordered form");
+      CRGPU_TRY(ordered_feed(a, cols, lo, len));
+    }
+  }
+  return CRGPU_OK;
+}
+
+static crgpu_status ordered_hand_out(crgpu_agg *a, crgpu_dev_result *res) {
+  OrderedState &o = *a->ord;
+  o.handed.reset();
+  res->n = 0;
+  res->ncols = o.n_aggs;
+  res->_pad = 0;
+  res->cols = o.views.data();
+  if (o.ready.empty()) {
+    for (auto &v : o.views) std::memset(&v, 0, sizeof(v));
+    return CRGPU_OK;
+  }
+  // (a piece's buffers go back to the pool when it is dropped: nothing queued may still read them)
+  o.handed = std::move(o.ready.front());
+  o.ready.pop_front();
+  for (int c = 0; c < o.n_aggs; c++) o.views[static_cast<size_t>(c)] = o.handed->cols[static_cast<size_t>(c)].view();
+  res->n = o.handed->n;
+  return CRGPU_OK;
+}
+
+static crgpu_status ordered_finish(crgpu_agg *a, crgpu_dev_result *res) {
+  if (res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_finish: null argument");
+  CRGPU_ENTER(a);
+  CRGPU_CHECK_CANCEL(a);
+  CRGPU_TRY(ordered_flush(a));
+  a->ord->has_prev = false;
+  return ordered_hand_out(a, res);
+}
+
+extern "C" crgpu_status crgpu_dev_agg_emit_ready(crgpu_agg *a, crgpu_dev_result *res) {
+  if (a == nullptr || res == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_emit_ready: null argument");
+  CRGPU_ENTER(a);
+  CRGPU_CHECK_CANCEL(a);
+  if (!a->ord) {  // unordered input: nothing is complete before the input ends
+    res->n = 0;
+    res->ncols = static_cast<int32_t>(a->ops.size());
+    res->_pad = 0;
+    res->cols = nullptr;
+    return CRGPU_OK;
+  }
+  const crgpu_status s_ = ordered_hand_out(a, res);
+  if (s_ == CRGPU_OK) note_rows(a, 0, res->n);
   return s_;
 }

@@ -358,6 +358,8 @@ extern "C" crgpu_status crgpu_dev_grace_join_create(const crgpu_join_spec *spec,
 extern "C" crgpu_status crgpu_dev_grace_agg_create(const crgpu_agg_spec *spec, const crgpu_grace_opts *opts, crgpu_grace **out) {
   CRGPU_TRY(ensure_init());
   if (spec == nullptr || out == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_grace_agg_create: null argument");
+  // (external_hash_aggregator.go:88-118 restores the ordering with a sort behind the partitioned aggregation)
+  if (spec->n_ordered != 0) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_grace_agg_create: ordered grouping columns: hash partitions do not keep the input order");
   std::unique_ptr<crgpu_grace> g(new crgpu_grace());
   CRGPU_TRY(g->open());
   CRGPU_TRY(grace_common(g.get(), opts));

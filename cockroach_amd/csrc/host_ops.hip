@@ -709,6 +709,7 @@ struct crgpu_ha : crgpu::Shell {
   std::vector<HostCol> tracked;
   std::unique_ptr<HostResult> export_copy;
   bool released = false;
+  bool ordered = false;  // AggregatorSpec.OrderedGroupCols: completed groups are emitted while the input is still read
 };
 
 extern "C" crgpu_status crgpu_agg_new(const crgpu_agg_spec *spec, crgpu_ha **out) {
@@ -718,10 +719,23 @@ extern "C" crgpu_status crgpu_agg_new(const crgpu_agg_spec *spec, crgpu_ha **out
   auto h = new crgpu_ha();
   h->dev = dev;
   h->inner = reinterpret_cast<Handle *>(dev);
+  h->ordered = spec->n_ordered > 0;
   for (int i = 0; i < spec->n_cols; i++) h->types.push_back(spec->types[i]);
   init_cols(h->stage, h->types);
   *out = h;
   return CRGPU_OK;
+}
+
+// partially ordered input: the pieces the device aggregator has completed so far (crgpu_dev_agg_emit_ready) -> outq
+static crgpu_status ha_pull_ready(crgpu_ha *h) {
+  for (;;) {
+    crgpu_dev_result r;
+    CRGPU_TRY(crgpu_dev_agg_emit_ready(h->dev, &r));
+    if (r.n == 0) return CRGPU_OK;
+    std::unique_ptr<HostResult> hr(new HostResult());
+    CRGPU_TRY(download_result(r, *hr));
+    h->outq.push_back(std::move(hr));
+  }
 }
 
 extern "C" void crgpu_agg_free(crgpu_ha *h) {
@@ -761,6 +775,7 @@ static crgpu_status ha_flush(crgpu_ha *h) {
   }
   st = crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n);
   clear_cols(h->stage);  // (tracked rows keep the batch when tracking is on)
+  if (st == CRGPU_OK && h->ordered) st = ha_pull_ready(h);
   return st;
 }
 
@@ -841,6 +856,7 @@ extern "C" crgpu_status crgpu_agg_finish(crgpu_ha *h) {
     CRGPU_TRY(download_result(r, *hr));
     h->outq.push_back(std::move(hr));
   }
+  if (h->ordered) CRGPU_TRY(ha_pull_ready(h));
   h->finished = true;
   return CRGPU_OK;
 }
@@ -850,7 +866,9 @@ extern "C" crgpu_status crgpu_agg_next_output(crgpu_ha *h, crgpu_out_batch *out)
   CRGPU_ENTER(h->inner);
   CRGPU_CHECK_CANCEL(h->inner);
   out->length = 0;
-  if (!h->finished) return CRGPU_OK;  // the hash aggregator emits only after its input is exhausted
+  // the hash aggregator emits only after its input is exhausted -- unless the input is ordered on some grouping
+  // columns: then the groups of every completed run are there already (hash_aggregator_tmpl.go:256-306)
+  if (!h->finished && !h->ordered) return CRGPU_OK;
   return emit_from_queue(h->outq, out);
 }
 

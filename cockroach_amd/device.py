@@ -184,13 +184,14 @@ class Join:
 class Agg:
     """crgpu_agg handle (online hash aggregation)."""
 
-    def __init__(self, types, group_cols, aggs):
-        """aggs: list of (func, col or -1, filter_col or -1[, distinct])."""
+    def __init__(self, types, group_cols, aggs, n_ordered=0):
+        """aggs: list of (func, col or -1, filter_col or -1[, distinct]); n_ordered: the input is sorted on the first
+        n_ordered grouping columns (AggregatorSpec.OrderedGroupCols) -- see emit_ready."""
         self._types, self._groups = _i32arr(types), _i32arr(group_cols)
         self._aggs = (_lib.AggDesc * max(len(aggs), 1))()
         for i, a in enumerate(aggs):
             self._aggs[i] = _lib.AggDesc(a[0], a[1], a[2] if len(a) > 2 else -1, int(a[3]) if len(a) > 3 else 0)
-        spec = _lib.AggSpec(len(types), len(group_cols), self._types, self._groups, len(aggs), 0, self._aggs)
+        spec = _lib.AggSpec(len(types), len(group_cols), self._types, self._groups, len(aggs), n_ordered, self._aggs)
         self.h = C.c_void_p()
         _lib.check(_lib.load().crgpu_dev_agg_create(C.byref(spec), C.byref(self.h)))
 
@@ -201,6 +202,12 @@ class Agg:
     def finish(self) -> _lib.DevResult:
         res = _lib.DevResult()
         _lib.check(_lib.load().crgpu_dev_agg_finish(self.h, C.byref(res)))
+        return res
+
+    def emit_ready(self) -> _lib.DevResult:
+        """Partially ordered input: the next piece of completed groups (n == 0: none yet / no more)."""
+        res = _lib.DevResult()
+        _lib.check(_lib.load().crgpu_dev_agg_emit_ready(self.h, C.byref(res)))
         return res
 
     def reset(self):

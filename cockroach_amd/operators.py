@@ -257,10 +257,17 @@ AGG_OUTPUT_TYPE = {  # colexecagg.ProcessAggregations output types for the suppo
 
 
 class HashAggregator(Operator):
-    """colexec.NewHashAggregator(args): aggs = [(func, col, filter_col)]."""
+    """colexec.NewHashAggregator(args): aggs = [(func, col, filter_col[, distinct])]; ordered_cols =
+    AggregatorSpec.OrderedGroupCols (a subset of group_cols the input is sorted on): the groups of a run of equal
+    ordered values are emitted as soon as the run is over (hash_aggregator_tmpl.go:160-169, 256-306)."""
 
-    def __init__(self, types, group_cols, aggs, input: Operator, capacity=cd.BATCH_SIZE, track_input=False):
+    def __init__(self, types, group_cols, aggs, input: Operator, capacity=cd.BATCH_SIZE, track_input=False, ordered_cols=()):
         self.lib = _lib.load()
+        ordered_cols = list(ordered_cols)
+        if any(c not in group_cols for c in ordered_cols):
+            raise ValueError("ordered columns must be grouping columns")
+        group_cols = ordered_cols + [c for c in group_cols if c not in ordered_cols]  # the C-ABI wants them first
+        self.ordered = len(ordered_cols) > 0
         self.input = input
         self.types = list(types)
         self.capacity = capacity
@@ -271,7 +278,7 @@ class HashAggregator(Operator):
             descs[i] = _lib.AggDesc(f, c, fc, int(bool(a[3])) if len(a) > 3 else 0)
             self.out_types.append(AGG_OUTPUT_TYPE.get(f, types[c] if c >= 0 else cd.INT64))
         self._keep = (_i32(types), _i32(group_cols), descs)
-        spec = _lib.AggSpec(len(types), len(group_cols), self._keep[0], self._keep[1], len(aggs), 0, descs)
+        spec = _lib.AggSpec(len(types), len(group_cols), self._keep[0], self._keep[1], len(aggs), len(ordered_cols), descs)
         self.h = C.c_void_p()
         _lib.check(self.lib.crgpu_agg_new(C.byref(spec), C.byref(self.h)))
         if track_input:  # planned under a disk spiller: hashAggregator.inputTrackingState (hash_aggregator.go:138-153)
@@ -286,6 +293,10 @@ class HashAggregator(Operator):
     def next(self):
         if self.state == "aggregating":
             while True:
+                if self.ordered:  # groups of completed runs go out while the input is still being read
+                    out = self.out.call(self.lib.crgpu_agg_next_output, self.h)
+                    if out.length > 0:
+                        return out
                 b = self.input.next()
                 if b.length == 0:
                     break

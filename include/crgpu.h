@@ -225,7 +225,8 @@ typedef struct crgpu_agg_spec {
   const int32_t *types;      /* crgpu_type per input column */
   const int32_t *group_cols; /* AggregatorSpec.GroupCols */
   int32_t n_aggs;
-  int32_t _pad;
+  int32_t n_ordered; /* AggregatorSpec.OrderedGroupCols: the input is sorted on the first n_ordered entries of group_cols
+                      * (list the ordered grouping columns first); 0 = unordered input.  See crgpu_dev_agg_emit_ready. */
   const crgpu_agg_desc *aggs;
 } crgpu_agg_spec;
 
@@ -236,6 +237,16 @@ crgpu_status crgpu_dev_agg_consume(crgpu_agg *a, const crgpu_dcol *cols, int64_t
 /* One row per group, one column per aggregation (hashAggregatorOutputting,
  * hash_aggregator_tmpl.go:331-387); arbitrary row order. */
 crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *out);
+/* Partially ordered input (spec.n_ordered > 0; hash_aggregator_tmpl.go:160-169, 256-306: the reference aggregates one run
+ * of equal ordered-column values at a time and emits its groups before it reads on).  The groups completed by the
+ * crgpu_dev_agg_consume calls so far -- every group in front of the last change of the ordered columns -- are handed
+ * out in pieces, one per call, oldest first, out->n == 0 when there is none (yet): rows in the order of the runs in the
+ * input, any order inside a run (what colexectestutils.PartialOrderedVerifier accepts, utils.go:1337-1400), and removed
+ * from the table, which therefore holds the groups behind the last change only.  After the last consume,
+ * crgpu_dev_agg_finish completes the remaining groups and returns the OLDEST piece not yet handed out; the caller then
+ * calls crgpu_dev_agg_emit_ready until out->n == 0.  Without ordered columns every call returns n == 0.  Limits: no
+ * computed columns; at most 2^31 rows between two changes of the ordered columns (CRGPU_ERR_UNSUPPORTED). */
+crgpu_status crgpu_dev_agg_emit_ready(crgpu_agg *a, crgpu_dev_result *out);
 crgpu_status crgpu_dev_agg_reset(crgpu_agg *a);
 void crgpu_dev_agg_destroy(crgpu_agg *a);
 

@@ -308,3 +308,29 @@ def kv_key_canonical(vec):
     d[d == 0] = 0.0
     d[np.isnan(d)] = np.nan
     return cd.Vec(cd.FLOAT64, d, vec.valid)
+
+
+# ---------------------------------------------------------------------------
+# partially ordered hash aggregation
+# ---------------------------------------------------------------------------
+def ordered_agg_cases():
+    """The cases of hash_aggregator_test.go:104-397 that set orderedCols."""
+    return [c for c in agg_cases() if c.get("ordered_cols")]
+
+
+def assert_partial_order(actual, expected, ordered_positions, msg=""):
+    """PartialOrderedVerifier (colexectestutils/utils.go:1337-1400): both row lists are cut where the values in the
+    ordered columns change; the runs must come in the same order and hold the same multiset of rows."""
+    def runs(rows):
+        out, key = [], object()
+        for r in rows:
+            k = tuple(_sort_key((r[p],)) for p in ordered_positions)
+            if k != key:
+                out.append([])
+                key = k
+            out[-1].append(tuple(r))
+        return out
+    ra, re_ = runs(actual), runs(expected)
+    assert len(ra) == len(re_), f"{msg}: {len(ra)} runs of ordered values, expected {len(re_)}\nactual={actual[:30]}\nexpected={expected[:30]}"
+    for i, (a, e) in enumerate(zip(ra, re_)):
+        assert_same_multiset(a, e, f"{msg}: run {i}")

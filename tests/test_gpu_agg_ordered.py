@@ -1,0 +1,173 @@
+"""GPU parity: hash aggregation over partially ordered input (AggregatorSpec.OrderedGroupCols;
+hash_aggregator_tmpl.go:160-169, 256-306).  The reference's own cases (hash_aggregator_test.go:104-397: oneOrderedCol,
+twoOrderedCol, PartialOrderWithNulls, orderedColSpansMultMaxBufferBoundary, orderedColUnique, spilloverAfterEmit) are
+checked the way the reference checks them -- colexectestutils.PartialOrderedVerifier: the runs of equal ordered values
+in input order, any order inside a run -- at layer 1 (crgpu_dev_agg_emit_ready) and through the operator; random inputs
+against the oracle, whose rows are cut into the same runs."""
+import numpy as np
+import pytest
+
+from cockroach_amd import coldata as cd
+from cockroach_amd import device as dev
+from cockroach_amd import operators as ops
+from cockroach_amd import _lib
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+F = H.AGG_FUNC
+CASES = H.ordered_agg_cases()
+
+
+def _ordered_first(group_cols, ordered_cols):
+    return list(ordered_cols) + [g for g in group_cols if g not in ordered_cols]
+
+
+def run_ordered(cols, group_cols, ordered_cols, aggs, bounds):
+    """Feeds rows [bounds[i], bounds[i+1]) per consume call; returns (rows, rows handed out before finish)."""
+    a = dev.Agg([v.type for v in cols], _ordered_first(group_cols, ordered_cols), aggs, n_ordered=len(ordered_cols))
+    rows, early = [], 0
+    try:
+        for s, e in zip(bounds[:-1], bounds[1:]):
+            if e == s:
+                continue
+            a.consume([dev.upload(v.slice(int(s), int(e))) for v in cols], int(e - s))
+            while True:
+                r = a.emit_ready()
+                if r.n == 0:
+                    break
+                rows += H.vecs_to_tuples(dev.result_to_vecs(r))
+        early = len(rows)
+        r = a.finish()
+        while r.n > 0:
+            rows += H.vecs_to_tuples(dev.result_to_vecs(r))
+            r = a.emit_ready()
+    finally:
+        a.close()
+    return rows, early
+
+
+def test_the_reference_has_ordered_cases():
+    assert {c["name"] for c in CASES} >= {"oneOrderedCol", "twoOrderedCol", "PartialOrderWithNulls", "orderedColUnique",
+                                          "orderedColSpansMultMaxBufferBoundary", "spilloverAfterEmit"}
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_ordered_agg_golden_case_layer1(case):
+    cols, group_cols, aggs, expected = H.prepare_agg_case(case)
+    n = len(case["input"])
+    oc = case["ordered_cols"]
+    for step in (n, 1, 3, 5):
+        bounds = list(range(0, n, step)) + [n]
+        rows, _ = run_ordered(cols, group_cols, oc, aggs, bounds)
+        H.assert_partial_order(rows, expected, oc, f"{case['id']} step={step}")
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_ordered_agg_golden_case_operator(case):
+    cols, group_cols, aggs, expected = H.prepare_agg_case(case)
+    types = [v.type for v in cols]
+    for batch_size in (1, 2, 3, 16, 1024):
+        n = len(cols[0])
+        batches = [cd.Batch([v.slice(s, min(n, s + batch_size)) for v in cols], min(n, s + batch_size) - s)
+                   for s in range(0, n, batch_size)]
+        src = ops.BatchSource(batches, types)
+        ha = ops.HashAggregator(types, group_cols, aggs, src, capacity=4, ordered_cols=case["ordered_cols"])
+        ha.init()
+        for attempt in ("first run", "after Reset"):
+            rows = []
+            while True:
+                b = ha.next()
+                if b.length == 0:
+                    break
+                rows += H.vecs_to_tuples(b.cols, b.length)
+            H.assert_partial_order(rows, expected, case["ordered_cols"], f"{case['id']} bs={batch_size} {attempt}")
+            ha.reset()
+        ha.close()
+
+
+def _oracle_in_run_order(oracle, cols, group_cols, ordered_cols, aggs):
+    """The oracle's groups, ordered by the first input row of their run of ordered values."""
+    want = H.vecs_to_tuples(oracle.hash_agg(cols, group_cols, aggs))
+    first = {}
+    vals = [cols[c].to_values() for c in ordered_cols]
+    for i in range(len(cols[0])):
+        first.setdefault(tuple(repr(v[i]) for v in vals), i)
+    # output column p carries ANY_NOT_NULL of ordered column p (the aggregations below are laid out that way)
+    want.sort(key=lambda r: first[tuple(repr(r[p]) for p in range(len(ordered_cols)))])
+    return want
+
+
+@pytest.mark.parametrize("kind", ["int", "bytes", "two"])
+def test_ordered_agg_random_vs_oracle(oracle, kind):
+    rng = np.random.default_rng({"int": 1, "bytes": 2, "two": 3}[kind])
+    n = 120_000
+    run = np.sort(rng.integers(0, 900, size=n))  # ~130 rows per run; the first run is the NULL run
+    if kind == "bytes":
+        o0 = cd.Vec.from_values(cd.BYTES, [None if r == 0 else b"k%05d" % r + b"x" * int(r % 11) for r in run])
+    else:
+        o0 = cd.Vec.from_numpy(cd.INT64, run * 7 - 1000, run != 0)
+    o1 = cd.Vec.from_numpy(cd.INT32, (np.arange(n) // 17 % 5).astype(np.int32)) if kind == "two" else None
+    g = cd.Vec.from_numpy(cd.INT16, rng.integers(0, 9, size=n).astype(np.int16), rng.random(n) > 0.05)
+    x = cd.Vec.from_numpy(cd.INT64, rng.integers(-10**9, 10**9, size=n, dtype=np.int64), rng.random(n) > 0.1)
+    f = cd.Vec.from_numpy(cd.FLOAT64, rng.random(n) * 64 - 32, rng.random(n) > 0.1)
+    s = cd.Vec.from_values(cd.BYTES, [None if i % 13 == 0 else b"v%d" % (i % 1000) for i in range(n)])
+    if kind == "two":
+        # the second ordered column is only sorted inside a run of the first
+        o1 = cd.Vec.from_numpy(cd.INT32, np.concatenate([np.sort((np.arange(c) * 5 // max(c, 1)).astype(np.int32))
+                                                        for c in np.bincount(run)]).astype(np.int32))
+        cols, ordered, group = [o0, o1, g, x, f, s], [0, 1], [0, 1, 2]
+        lead = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 1, -1), (F["ANY_NOT_NULL"], 2, -1)]
+        xi, fi, si = 3, 4, 5
+    else:
+        cols, ordered, group = [o0, g, x, f, s], [0], [1, 0]  # (grouping columns given in the other order on purpose)
+        lead = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 1, -1)]
+        xi, fi, si = 2, 3, 4
+    aggs = lead + [(F["COUNT_ROWS"], -1, -1), (F["SUM_INT"], xi, -1), (F["MIN"], xi, -1), (F["SUM"], fi, -1), (F["AVG"], fi, -1),
+                   (F["MAX"], si, -1), (F["COUNT"], si, -1), (F["SUM"], xi, -1)]
+    want = _oracle_in_run_order(oracle, cols, group, ordered, aggs)
+    for bounds in ([0, n], [0, 1, 7, 4099, 4100, 50_001, 99_999, n], list(range(0, n, 4096)) + [n]):
+        rows, early = run_ordered(cols, group, ordered, aggs, bounds)
+        H.assert_partial_order(rows, want, list(range(len(ordered))), f"{kind} {len(bounds) - 1} calls")
+        assert early > 0.9 * len(rows), "groups of completed runs must be handed out before the input ends"
+
+
+def test_ordered_agg_one_long_run_and_reset(oracle):
+    """No change of the ordered column at all: nothing is ready before finish; a second use after reset gives the same."""
+    rng = np.random.default_rng(5)
+    n = 50_000
+    o0 = cd.Vec.from_numpy(cd.INT64, np.full(n, 42, dtype=np.int64))
+    g = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 3000, size=n, dtype=np.int64))
+    x = cd.Vec.from_numpy(cd.FLOAT64, rng.random(n))
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 1, -1), (F["SUM"], 2, -1), (F["COUNT_ROWS"], -1, -1)]
+    want = H.vecs_to_tuples(oracle.hash_agg([o0, g, x], [0, 1], aggs))
+    a = dev.Agg([cd.INT64, cd.INT64, cd.FLOAT64], [0, 1], aggs, n_ordered=1)
+    for _ in range(2):
+        for s in range(0, n, 10_000):
+            a.consume([dev.upload(v.slice(s, s + 10_000)) for v in (o0, g, x)], 10_000)
+            assert a.emit_ready().n == 0
+        rows = H.vecs_to_tuples(dev.result_to_vecs(a.finish()))
+        assert a.emit_ready().n == 0
+        H.assert_same_multiset(rows, want)
+        a.reset()
+    a.close()
+
+
+def test_ordered_agg_spec_errors():
+    with pytest.raises(_lib.CrgpuError):  # more ordered columns than grouping columns
+        dev.Agg([cd.INT64, cd.INT64], [0], [(F["COUNT_ROWS"], -1, -1)], n_ordered=2)
+    with pytest.raises(_lib.CrgpuError) as e:
+        import ctypes as C  # (spec built by hand: the python FusedAgg class has no n_ordered argument)
+        types = dev._i32arr([cd.FLOAT64, cd.FLOAT64, cd.FLOAT64])
+        groups = dev._i32arr([0])
+        descs = (_lib.AggDesc * 1)(_lib.AggDesc(F["SUM"], 2, -1, 0))
+        vc = (_lib.AggVcol * 1)(_lib.AggVcol(0, 0, 0, 1, 0))
+        spec = _lib.AggSpec(3, 1, types, groups, 1, 1, descs)
+        h = C.c_void_p()
+        _lib.check(_lib.load().crgpu_dev_agg_create_fused(C.byref(spec), 1, vc, C.byref(h)))
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    # an unordered handle never has anything ready
+    a = dev.Agg([cd.INT64], [0], [(F["COUNT_ROWS"], -1, -1)])
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, np.arange(10, dtype=np.int64)))], 10)
+    assert a.emit_ready().n == 0
+    assert a.finish().n == 10
+    a.close()
