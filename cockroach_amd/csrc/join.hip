@@ -435,6 +435,21 @@ __global__ __launch_bounds__(1024) void key0_filter_kernel(DCol c0, long long lo
     __syncthreads();
   }
 }
+// How many of `samples` evenly spaced probe rows pass the bitmap: the full pass is only worth it if most do not.
+__global__ __launch_bounds__(256) void key0_sample_kernel(DCol c0, long long lo, unsigned long long range, int64_t n, int64_t samples,
+                                                          const uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ hits) {
+  const int64_t k = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  bool hit = false;
+  if (k < samples) {
+    const int64_t i = k * (n / samples);
+    if (!col_is_null(c0, i)) {
+      const uint64_t d = static_cast<uint64_t>(col_get_ival(c0, i)) - static_cast<uint64_t>(lo);
+      hit = d <= range && ((bitmap[d >> 5] >> (d & 31)) & 1u);
+    }
+  }
+  const uint64_t m = __ballot(hit);
+  if (lane_id() == 0 && m != 0) atomicAdd(hits, static_cast<unsigned long long>(popc64(m)));
+}
 __global__ __launch_bounds__(256) void widen_i32_i64_kernel(const int32_t *__restrict__ in, int64_t n, long long *__restrict__ out) {
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i];
@@ -949,6 +964,7 @@ struct crgpu_join : crgpu::Handle {
   long long key0_lo = 0;
   unsigned long long key0_range = 0;
   bool key0_on = false;
+  bool key0_pending = false;  // eligible, not built yet: the first probe chunk large enough to be filtered builds it
   OutCol pf_key[kMaxPackCols], pf_pay;
   DevBuf pf_rowid, pf_key0;
   DevBuf mcache;  // chained probe: first matches of every probe row (pass 1 -> pass 3)
@@ -1093,9 +1109,23 @@ static int64_t env_i64(const char *name, int64_t def) {
 }
 // INNER / LEFT SEMI joins through the radix tables: a bitmap over the first key column's values when their range is
 // small enough to be worth a pass over the probe side (<= 2^27 bits = 16 MiB; dense surrogate keys are far below).
-static crgpu_status build_key0_bitmap(crgpu_join *j, int64_t n) {
+// Planned when the table is built (the range is known then), built by the first probe chunk that would use it: a build
+// side of 15 M orders costs 0.7 ms of atomics that a probe side of 3 M rows never earns back.
+static void plan_key0_bitmap(crgpu_join *j, int64_t n) {
+  j->key0_on = false;
+  j->key0_pending = false;
   const char *env = std::getenv("CRGPU_JOIN_KEY0_BITMAP");  // "0": no first-key bitmap (tests, measurements)
-  if ((env != nullptr && env[0] == '0') || !(j->join_type == CRGPU_INNER || j->join_type == CRGPU_LEFT_SEMI)) return CRGPU_OK;
+  if ((env != nullptr && env[0] == '0') || !(j->join_type == CRGPU_INNER || j->join_type == CRGPU_LEFT_SEMI)) return;
+  unsigned long long range;
+  const DCol &c0 = j->kp.c[0];
+  if (j->kp.n > 1) range = j->kp.range[0];
+  else if (j->radix.direct.span != 0 && c0.type != CRGPU_FLOAT64) range = j->radix.direct.span - 1;
+  else return;
+  if (range >= (1ull << 27) || static_cast<unsigned long long>(n) * 2 > range) return;
+  j->key0_pending = true;
+}
+static crgpu_status build_key0_bitmap(crgpu_join *j, int64_t n) {
+  j->key0_pending = false;
   long long lo;
   unsigned long long range;
   const DCol &c0 = j->kp.c[0];
@@ -1107,6 +1137,9 @@ static crgpu_status build_key0_bitmap(crgpu_join *j, int64_t n) {
     return CRGPU_OK;
   }
   if (range >= (1ull << 27)) return CRGPU_OK;
+  // a build side that fills most of its own value range (a join on the build side's dense primary key, config J) leaves
+  // the bitmap nothing to reject but out-of-range keys: not worth the 2^27 atomics of building it
+  if (static_cast<unsigned long long>(n) * 2 > range) return CRGPU_OK;
   hipStream_t st = stream();
   const size_t bytes = static_cast<size_t>((range >> 5) + 1) * 4;
   CRGPU_TRY(j->key0_bits.ensure(bytes));
@@ -1316,8 +1349,8 @@ static crgpu_status crgpu_dev_join_build_impl(crgpu_join *j, const crgpu_dcol *r
         CRGPU_TRY(radix_build(j->radix, src, n, &ok));
       }
       j->use_radix = ok;
-      j->key0_on = false;
-      if (ok && n > 0) CRGPU_TRY(build_key0_bitmap(j, n));
+      j->key0_on = j->key0_pending = false;
+      if (ok && n > 0) plan_key0_bitmap(j, n);
     }
     if (!j->use_radix) {
       CRGPU_TRY(j->slots.ensure(j->cap * sizeof(Slot)));
@@ -1634,10 +1667,25 @@ static crgpu_status probe_radix(crgpu_join *j, const std::vector<DCol> &left, in
   // payload column (or the survivors' ORIGINAL row numbers as the payload: the pairs then name rows of `left`).
   bool nullable_key = false;
   for (int c = 0; c < pkp.n; c++) nullable_key = nullable_key || pkp.c[c].valid != nullptr;
-  if (j->key0_on && !j->use_radix_dup && !nullable_key && n >= env_i64("CRGPU_JOIN_PREFILTER_MIN", int64_t(1) << 21) &&
-      n >= 4 * j->n_build && n <= 0x7FFFFFF0ll) {
-    CRGPU_TRY(j->cand.ensure(static_cast<size_t>(n) * 4));
+  const bool prefilter_size = !j->use_radix_dup && !nullable_key && n >= env_i64("CRGPU_JOIN_PREFILTER_MIN", int64_t(1) << 21) &&
+                              n >= 4 * j->n_build && n <= 0x7FFFFFF0ll;
+  if (j->key0_pending && prefilter_size) CRGPU_TRY(build_key0_bitmap(j, j->n_build));
+  if (j->key0_on && prefilter_size) {
+    // 2^14 evenly spaced rows first (a probe side whose keys all exist in the build side -- a foreign key into a sparse
+    // table -- would pay a pass over the column and two written lists for nothing)
     CRGPU_TRY(j->counter.ensure(8));
+    CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
+    const int64_t samples = n < (int64_t(1) << 14) ? n : int64_t(1) << 14;
+    hipLaunchKernelGGL(key0_sample_kernel, dim3(grid_for(samples, 256)), dim3(256), 0, st, pkp.c[0], j->key0_lo, j->key0_range, n, samples,
+                       j->key0_bits.as<uint32_t>(), j->counter.as<unsigned long long>());
+    CRGPU_HIP(hipGetLastError());
+    unsigned long long sample_hits = 0;
+    CRGPU_HIP(hipMemcpyAsync(&sample_hits, j->counter.p, 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (sample_hits * 2 > static_cast<unsigned long long>(samples)) j->key0_on = false;
+  }
+  if (j->key0_on && prefilter_size) {
+    CRGPU_TRY(j->cand.ensure(static_cast<size_t>(n) * 4));
     CRGPU_HIP(hipMemsetAsync(j->counter.p, 0, 8, st));
     {
       ProfScope prof("join_probe");
