@@ -100,8 +100,11 @@ class OutCol(C.Structure):  # crgpu_out_col
 
 
 class OutBatch(C.Structure):  # crgpu_out_batch
-    _fields_ = [("capacity", C.c_int64), ("length", C.c_int64), ("ncols", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("capacity", C.c_int64), ("length", C.c_int64), ("ncols", C.c_int32), ("flags", C.c_int32),
                 ("cols", C.POINTER(OutCol))]
+
+
+OUT_BORROW = 1  # crgpu_out_batch.flags: fixed-width values are handed out in place (crgpu.h)
 
 
 # every symbol include/crgpu.h declares: (name, restype, argtypes)

@@ -1976,7 +1976,12 @@ struct BulkArgs {
   uint32_t g0;
   uint32_t gmax;                // groups a region may hold (sized to the LDS the planes need)
   uint32_t slots;               // LDS index size (power of two, > gmax)
+  // the all-distinct attempt (TRY): region q's groups are numbered from try_base[q] (prefix sums of the row counts: no
+  // group-id atomic); *try_failed is raised by a region with a repeated key -- the attempt is then void as a whole
+  const uint64_t *try_base;
+  unsigned int *try_failed;     // (a cache line of its own: it is read by every workgroup)
 };
+static constexpr int kBulkTryThreads = 512;
 template <bool WIDE>
 struct BulkRow;
 template <>
@@ -2040,8 +2045,15 @@ struct BulkRow<true> {
                    (static_cast<uint32_t>(h) & kIdxHashMask);
   }
 };
-template <bool WIDE>
-__global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
+// TRY (the sub form's first pass when a key sample held no repeated key): every region is expected to hold distinct keys
+// only, so region q's groups are rows q's rows and their ids are known beforehand -- try_base[q], the prefix sum of the
+// regions' row counts: no returning atomic on ONE group counter per region (131072 of them for 2^27 rows, serialised
+// at the counter's L2 channel: what held the all-distinct case at 1.8 TB/s), an LDS index only (no accumulator planes)
+// and THREADS < 1024, so many regions are in flight per CU.  A region with a repeated key raises *try_failed and the
+// whole attempt is void (its writes are overwritten by the general form, which then runs over every region); regions
+// that start after the flag is up exit at once.
+template <bool WIDE, int THREADS, bool TRY>
+__global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   typedef BulkRow<WIDE> R;
   typedef typename R::T Row;
   // dynamic LDS: [nwords][gmax + 1] accumulator words, [slots] slot -> representative row, [slots] slot -> local group
@@ -2050,11 +2062,25 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
   __shared__ uint32_t s_base, s_claims;
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t plane = a.gmax + 1;
-  uint32_t *idx = reinterpret_cast<uint32_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
+  uint32_t *idx = TRY ? reinterpret_cast<uint32_t *>(lds_words) : reinterpret_cast<uint32_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
   uint32_t *lid = idx + a.slots;
   uint32_t *rep = lid + a.slots;
   uint8_t *lds_seen = reinterpret_cast<uint8_t *>(rep + a.gmax);
   const int q = blockIdx.x;
+  // TRY: the first ~1024 rows of the region (what a region holds on average; its capacity is kBulkRows) are requested
+  // before the row count is known, and the flag and the region's first group id with them: one memory latency in
+  // front of the LDS phase instead of two
+  constexpr int kPre = TRY ? 1024 / THREADS : 1;
+  Row pre[kPre];
+  unsigned int flag_seen = 0;
+  uint64_t try_first = 0;
+  if (TRY) {
+    const Row *rq = static_cast<const Row *>(a.rows) + static_cast<int64_t>(q) * kBulkRows;
+#pragma unroll
+    for (int k = 0; k < kPre; k++) pre[k] = rq[k * THREADS + threadIdx.x];
+    if (threadIdx.x == 0) flag_seen = __hip_atomic_load(a.try_failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    try_first = a.try_base[q];
+  }
   const uint32_t n = a.counts[q];
   if (n == 0) return;
   const Row *rows = static_cast<const Row *>(a.rows) + (a.starts != nullptr ? static_cast<int64_t>(a.starts[q]) : static_cast<int64_t>(q) * kBulkRows);
@@ -2075,10 +2101,10 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
     for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
   };
   for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) idx[i] = kNone;
-  if (!single) init_planes();
+  if (!TRY && !single) init_planes();
   if (threadIdx.x == 0) s_claims = 0;
   __syncthreads();
-  constexpr int kRows = kBulkRows / 1024;  // rows per thread and tile at 1024 threads
+  constexpr int kRows = kBulkRows / THREADS;  // rows per thread and tile
   for (uint32_t t0 = 0; t0 < n; t0 += kBulkRows) {
     // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key); the claimant
     //    numbers the group
@@ -2093,7 +2119,7 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
       val2[k] = 0;
       bool claimed = false;
       if (i < n) {
-        const Row r = rr[k] = rows[i];
+        const Row r = rr[k] = (TRY && k < kPre) ? pre[k < kPre ? k : 0] : rows[i];
         val[k] = R::value(r);
         val2[k] = R::value2(r);
         uint32_t sl = R::slot_hash(a, r) & smask;
@@ -2125,24 +2151,31 @@ __global__ __launch_bounds__(1024) void agg_bulk_kernel(BulkArgs a) {
         uint32_t wb = 0;
         if (lane_id() == static_cast<uint32_t>(lead)) wb = atomicAdd(&s_claims, static_cast<uint32_t>(popc64(cm)));
         wb = __shfl(wb, lead, 64);
-        if (claimed) {
+        if (!TRY && claimed) {
           const uint32_t l = wb + rank_in_mask(cm);
           lid[slot_of[k]] = l;  // read after the barrier below
           if (l < a.gmax) rep[l] = i;
         }
       }
     }
+    if (TRY && threadIdx.x == 0 && flag_seen != 0) atomicAdd(&s_claims, kBulkRows + 1);  // void already: not worth writing
     __syncthreads();
-    if (s_claims > a.gmax) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
+    if (TRY && s_claims != n) {  // some key repeats (or the index overflowed, or the attempt is void)
+      if (threadIdx.x == 0 && flag_seen == 0) atomicOr(a.try_failed, 1u);
+      return;
+    }
+    if (!TRY && s_claims > a.gmax) {  // more groups than the accumulator planes hold: the whole bulk attempt is abandoned
       if (threadIdx.x == 0) atomicOr(a.failed, 1u);
       return;
     }
-    if (single && s_claims == n) {
+    if (TRY || (single && s_claims == n)) {
       // every key of the region is distinct: row i of the region is group i (consecutive lanes write consecutive
       // groups); its accumulators are its value
-      if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, n);
-      __syncthreads();
-      const uint32_t base = a.g0 + s_base;
+      if (!TRY) {
+        if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, n);
+        __syncthreads();
+      }
+      const uint32_t base = a.g0 + (TRY ? static_cast<uint32_t>(try_first) : s_base);
 #pragma unroll
       for (int k = 0; k < kRows; k++) {
         if (slot_of[k] == kNone) continue;
@@ -3003,6 +3036,8 @@ struct crgpu_agg : crgpu::Handle {
   RadixTable radix;
   bool index_valid = true;
   bool dense16 = false;  // every group came from the wide bulk path with a 16-byte key: group g's key is b_buf[16 g, 16 g + 16)
+  bool one_row_groups = false;  // every group is ONE input row (the all-distinct bulk attempt succeeded and nothing followed): an
+                                // integer sum cannot have left the int64 range, finish skips the pass that checks
   DevBuf bulk_count;
   // gid-partitioned accumulation
   DevBuf p_gid_res, p_hist, p_offsets, p_gid, p_flags, p_wgs, p_starts;
@@ -3396,9 +3431,9 @@ static crgpu_status agg_create_impl(const crgpu_agg_spec *spec, int32_t n_virtua
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_accum_kernel<false, true, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
-    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel<false>),
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel<false, 1024, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
-    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel<true>),
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_bulk_kernel<true, 1024, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax - 64)));
     CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&agg_part_accum_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsMax)));
@@ -3425,6 +3460,7 @@ extern "C" crgpu_status crgpu_dev_agg_reset(crgpu_agg *a) {
   a->new_ratio = 1.0;
   a->index_valid = true;
   a->dense16 = false;
+  a->one_row_groups = false;
   for (auto &k : a->ks) k.tail = 0;
   for (auto &o : a->ops) o.any_tail = 0;
   for (auto &d : a->dsets) CRGPU_TRY(crgpu_dev_distinct_reset(d->h));
@@ -4601,17 +4637,46 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.gmax = static_cast<uint32_t>(gmax);
   b.slots = static_cast<uint32_t>(slots);
   const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) << a->radix.sub_bits : static_cast<unsigned>(kRadixP1);
-  {
+  // sub form, no repeated key among the 8192 sampled: first the all-distinct attempt (see agg_bulk_kernel)
+  static const bool try_on = getenv("CRGPU_BULK_TRY") == nullptr || getenv("CRGPU_BULK_TRY")[0] != '0';
+  bool tried_ok = false;
+  unsigned int try_groups = 0;
+  if (sub_form && try_on && distinct == kBigSample) {
+    CRGPU_TRY(a->p_offsets.ensure(static_cast<size_t>(nregions + 1) * 8));
+    CRGPU_TRY(a->p_flags.ensure(256));
+    CRGPU_HIP(hipMemsetAsync(a->p_flags.p, 0, 256, st));
+    uint64_t total_rows = 0;
+    CRGPU_TRY(exclusive_scan_u32(b.counts, nregions, a->p_offsets.as<uint64_t>(), a->scratch, &total_rows));
+    BulkArgs bt = b;
+    bt.slots = 4096;
+    bt.try_base = a->p_offsets.as<uint64_t>();
+    bt.try_failed = a->p_flags.as<unsigned int>();
+    {
+      ProfScope prof("agg_bulk_distinct");
+      // (512 threads: 1.59 ms; 256 threads, eight workgroups per CU: 1.71 ms)
+      if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, kBulkTryThreads, true>), dim3(nregions), dim3(kBulkTryThreads), bt.slots * 4, st, bt);
+      else hipLaunchKernelGGL((agg_bulk_kernel<false, kBulkTryThreads, true>), dim3(nregions), dim3(kBulkTryThreads), bt.slots * 4, st, bt);
+      CRGPU_HIP(hipGetLastError());
+    }
+    unsigned int failed_try = 0;
+    CRGPU_HIP(hipMemcpyAsync(&failed_try, bt.try_failed, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (failed_try == 0) {  // every region held distinct keys: group ids 0 .. rows - 1 are written
+      tried_ok = true;
+      try_groups = static_cast<unsigned int>(total_rows);
+    }
+  }
+  if (!tried_ok) {
     ProfScope prof(sub_form ? "agg_bulk" : "agg_bulk_part");
-    if (wide) hipLaunchKernelGGL(agg_bulk_kernel<true>, dim3(nregions), dim3(1024), lds, st, b);
-    else hipLaunchKernelGGL(agg_bulk_kernel<false>, dim3(nregions), dim3(1024), lds, st, b);
+    if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, 1024, false>), dim3(nregions), dim3(1024), lds, st, b);
+    else hipLaunchKernelGGL((agg_bulk_kernel<false, 1024, false>), dim3(nregions), dim3(1024), lds, st, b);
     CRGPU_HIP(hipGetLastError());
   }
   unsigned int tf[4] = {0, 0, 0, 0};
   CRGPU_HIP(hipMemcpyAsync(tf, a->bulk_count.p, 16, hipMemcpyDeviceToHost, st));
   CRGPU_HIP(hipStreamSynchronize(st));
   if (tf[1]) return CRGPU_OK;  // nothing was committed: the groups written so far lie beyond ngroups == 0
-  const unsigned int total = tf[0];
+  const unsigned int total = tried_ok ? try_groups : tf[0];
   if (key_type == CRGPU_BYTES) {  // the key bytes of group g lie at 16 g: later appends (find-or-insert) continue behind them
     a->ks[0].tail = static_cast<uint64_t>(total) * 16u;
     CRGPU_HIP(hipMemcpyAsync(a->tails_dev.p, &a->ks[0].tail, 8, hipMemcpyHostToDevice, st));
@@ -4620,6 +4685,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     a->dense16 = tf[2] == 0;
   }
   a->ngroups = total;
+  a->one_row_groups = tried_ok;
   a->seq = static_cast<unsigned long long>(n);
   a->new_ratio = static_cast<double>(total) / static_cast<double>(n);
   a->index_valid = false;  // the groups exist, their index entries do not
@@ -4703,6 +4769,7 @@ static crgpu_status crgpu_dev_agg_consume_impl(crgpu_agg *a, const crgpu_dcol *c
     }
     for (auto &dsp : a->dsets) in.push_back(DCol{CRGPU_BOOL, 0, dsp->mask.p, nullptr, nullptr});
   }
+  a->one_row_groups = false;
   {
     bool done = false;
     CRGPU_TRY(try_bulk(a, in, n, &done));
@@ -4900,7 +4967,7 @@ static crgpu_status crgpu_dev_agg_finish_impl(crgpu_agg *a, crgpu_dev_result *re
     } else if (ng >= kAliasMinGroups && type_width(op.out_type) == 8 && alias_source(a, op, ops[f], &alias[f], &alias_present)) {
       // the per-group array already IS the output column (group g is row g): hand it out in place and only build the
       // validity bitmap; values under a NULL are unspecified (as in the reference's vectors)
-      if (op.kind == ACC_SUM_I128) {
+      if (op.kind == ACC_SUM_I128 && !a->one_row_groups) {
         hipLaunchKernelGGL(agg_sum_check_kernel, dim3(grid_for(ng, 256)), dim3(256), 0, st, ops[f].w0, ops[f].w1, ops[f].seen, ng,
                            a->err_dev.as<unsigned int>());
         CRGPU_HIP(hipGetLastError());

@@ -383,6 +383,7 @@ static crgpu_status emit_rows(HostResult &src, crgpu_out_batch *out, bool *emitt
   if (out->capacity <= 0) return fail(CRGPU_ERR_INVALID, "output batch without capacity");
   const int64_t k = std::min<int64_t>(out->capacity, src.n - src.cursor);
   if (k <= 0) return CRGPU_OK;
+  const bool borrow = (out->flags & CRGPU_OUT_BORROW) != 0;
   // pass 1: BYTES spill requirements
   bool fits = true;
   for (size_t c = 0; c < src.cols.size(); c++) {
@@ -403,7 +404,7 @@ static crgpu_status emit_rows(HostResult &src, crgpu_out_batch *out, bool *emitt
   for (size_t c = 0; c < src.cols.size(); c++) {
     crgpu_out_col &o = out->cols[c];
     const HostCol &h = src.cols[c];
-    if (o.data == nullptr) return fail(CRGPU_ERR_INVALID, "output column without data buffer");
+    if (o.data == nullptr && !(borrow && h.type != CRGPU_BYTES)) return fail(CRGPU_ERR_INVALID, "output column without data buffer");
     o.has_nulls = 0;
     if (o.nulls != nullptr) std::memset(o.nulls, 0xFF, static_cast<size_t>((out->capacity + 7) / 8));
     for (int64_t r = 0; h.any_null && r < k; r++) {
@@ -435,7 +436,10 @@ static crgpu_status emit_rows(HostResult &src, crgpu_out_batch *out, bool *emitt
       }
     } else {
       const int w = type_width(h.type);
-      std::memcpy(o.data, h.data.data() + static_cast<size_t>(src.cursor) * w, static_cast<size_t>(k) * w);
+      if (borrow)  // the values stay where the transfer put them (pinned, library-owned, alive until the next output call)
+        o.data = const_cast<uint8_t *>(h.data.data()) + static_cast<size_t>(src.cursor) * w;
+      else
+        std::memcpy(o.data, h.data.data() + static_cast<size_t>(src.cursor) * w, static_cast<size_t>(k) * w);
     }
   }
   src.cursor += k;

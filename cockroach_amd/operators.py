@@ -97,12 +97,16 @@ def _marshal_batch(batch: cd.Batch):
     return b, keep
 
 
+BORROW_OUTPUT = False  # default of _OutBatch(borrow=): the shells ask for CRGPU_OUT_BORROW output batches
+
+
 class _OutBatch:
     """Caller-owned output batch (what allocator.ResetMaybeReallocate gives the Go shell)."""
 
-    def __init__(self, types, capacity, bytes_cap=0):
+    def __init__(self, types, capacity, bytes_cap=0, borrow=None):
         self.types = list(types)
         self.capacity = capacity
+        self.borrow = BORROW_OUTPUT if borrow is None else borrow  # CRGPU_OUT_BORROW: fixed-width values are read where the library left them
         self.cols = (_lib.OutCol * max(len(types), 1))()
         self.bufs = []
         for i, t in enumerate(types):
@@ -119,6 +123,7 @@ class _OutBatch:
         self.b = _lib.OutBatch()
         self.b.capacity = capacity
         self.b.ncols = len(types)
+        self.b.flags = _lib.OUT_BORROW if self.borrow else 0
         self.b.cols = self.cols
         self.grow_retries = 0
 
@@ -150,6 +155,10 @@ class _OutBatch:
                 valid[-1] |= (0xFF << (n % 8)) & 0xFF
             if t == cd.BYTES:
                 vecs.append(cd.elements_to_bytes(data, spill, n, valid))
+            elif self.borrow:  # the library's buffer is only valid until the next call: copy out of it here
+                raw = np.frombuffer(C.string_at(self.cols[i].data, n * cd.WIDTH[t]), dtype=cd.NP_DTYPE[t]) if n else np.zeros(0, cd.NP_DTYPE[t])
+                assert n == 0 or self.cols[i].data != data.ctypes.data, "CRGPU_OUT_BORROW left the caller's buffer in place"
+                vecs.append(cd.Vec(t, raw.copy(), valid))
             else:
                 vecs.append(cd.Vec(t, data[: n * cd.WIDTH[t]].view(cd.NP_DTYPE[t]).copy(), valid))
         return cd.Batch(vecs, n)

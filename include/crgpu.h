@@ -573,11 +573,19 @@ typedef struct crgpu_out_col {
   int64_t bytes_buf_len; /* out */
 } crgpu_out_col;
 
+/* crgpu_out_batch.flags.  CRGPU_OUT_BORROW: the values of fixed-width columns are not copied into the caller's `data`
+ * buffers; instead `data` is SET to point at them inside the library's pinned result buffer (`data` may be NULL on
+ * entry for such columns).  The pointers stay valid until the next output call on the same handle (a router: on the
+ * same output), its reset or its free -- the lifetime coldata.Batch promises a consumer anyway (colexecop/operator.go:
+ * "the batch is only valid until the next call to Next"), so a Go shell can wrap them with unsafe.Slice as the Vec's
+ * backing array and saves the second host copy of every output byte.  Null bitmaps and BYTES columns are written to
+ * the caller's buffers as without the flag. */
+enum { CRGPU_OUT_BORROW = 1 };
 typedef struct crgpu_out_batch {
   int64_t capacity; /* <= coldata.BatchSize() typically */
   int64_t length;   /* out; 0 = no more output (EOF of this phase) */
   int32_t ncols;
-  int32_t _pad;
+  int32_t flags;    /* CRGPU_OUT_*; 0: every value is copied into the caller's buffers */
   crgpu_out_col *cols;
 } crgpu_out_batch;
 

@@ -56,7 +56,7 @@ def run(name, cols, types, group_cols, aggs, n, alg_bytes, reps=5, expect=None):
         raise SystemExit(f"{name}: {ngroups} groups, expected {expect}")
     kern = {}
     for k in ("agg_fused_lds", "agg_fused_sumfam", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
-              "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_part", "radix_build_hist",
+              "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_distinct", "agg_bulk_part", "radix_build_hist",
               "radix_build_scatter", "radix_build_split"):
         ms, cnt = dev.prof_get(k)
         if cnt:

@@ -257,7 +257,7 @@ def bench_router(lg, reps, dv, g, outputs):
 
 
 AGG_KERNELS = ["agg_fused_lds", "agg_fused_sumfam", "agg_fused_hbm", "agg_resolve", "agg_fixup", "agg_accum_lds", "agg_accum_hbm", "agg_reindex",
-               "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_part", "radix_build_hist",
+               "agg_any_fixup", "agg_part_hist", "agg_part_scatter", "agg_part_accum", "agg_bulk", "agg_bulk_distinct", "agg_bulk_part", "radix_build_hist",
                "radix_build_scatter", "radix_build_split"]
 
 

@@ -27,6 +27,11 @@ def _canon(vecs):
     return G.rows_as_sorted_array(vecs)
 
 
+def _bulk_launches(dev):
+    """Launches of the bulk path's sub form: the all-distinct attempt and / or the general form."""
+    return dev.prof_get("agg_bulk")[1] + dev.prof_get("agg_bulk_distinct")[1]
+
+
 @pytest.mark.parametrize("ngroups", [1, 4, 50, 3000, 200_000])
 def test_agg_random_int_exact_vs_oracle(oracle, ngroups):
     rng = np.random.default_rng(ngroups)
@@ -334,7 +339,7 @@ def test_agg_bulk_path_then_more_input_vs_oracle(oracle):
     dev.prof_enable(True)
     dev.prof_reset()
     a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k1)), dev.upload(cd.Vec.from_numpy(cd.INT64, x[:n1]))], n1)
-    assert dev.prof_get("agg_bulk")[1] == 1, "the bulk path did not run"
+    assert _bulk_launches(dev) >= 1, "the bulk path did not run"
     a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k2)), dev.upload(cd.Vec.from_numpy(cd.INT64, x[n1:]))], n2)
     dev.prof_enable(False)
     got = dev.result_to_vecs(a.finish())
@@ -416,7 +421,7 @@ def test_agg_bulk_wide_bytes_keys_vs_oracle(oracle):
     dev.prof_enable(True)
     dev.prof_reset()
     a.consume([dev.upload(k1), dev.upload(cd.Vec.from_numpy(cd.INT64, x[:n1]))], n1)
-    assert dev.prof_get("agg_bulk")[1] == 1, "the wide form of the bulk path did not run"
+    assert _bulk_launches(dev) >= 1, "the wide form of the bulk path did not run"
     a.consume([dev.upload(k2), dev.upload(cd.Vec.from_numpy(cd.INT64, x[n1:]))], n2)
     dev.prof_enable(False)
     got = dev.result_to_vecs(a.finish())
@@ -458,7 +463,7 @@ def test_agg_bulk_wide_two_integer_keys_vs_oracle(oracle, t2):
     dev.prof_enable(True)
     dev.prof_reset()
     ag.consume([dev.upload(v.slice(0, n1)) for v in cols], n1)
-    assert dev.prof_get("agg_bulk")[1] == 1, "the wide form of the bulk path did not run"
+    assert _bulk_launches(dev) >= 1, "the wide form of the bulk path did not run"
     ag.consume([dev.upload(v.slice(n1, n1 + n2)) for v in cols], n2)
     dev.prof_enable(False)
     got = dev.result_to_vecs(ag.finish())
@@ -493,7 +498,7 @@ def test_agg_bulk_wide_one_key_two_value_columns_vs_oracle(oracle, tk):
     dev.prof_enable(True)
     dev.prof_reset()
     ag.consume([dev.upload(v.slice(0, n1)) for v in cols], n1)
-    assert dev.prof_get("agg_bulk")[1] == 1, "the wide form of the bulk path did not run"
+    assert _bulk_launches(dev) >= 1, "the wide form of the bulk path did not run"
     ag.consume([dev.upload(v.slice(n1, n1 + n2)) for v in cols], n2)
     dev.prof_enable(False)
     got = dev.result_to_vecs(ag.finish())
@@ -526,7 +531,7 @@ def test_agg_bulk_path_columns_with_validity_bitmaps(oracle):
         ag = dev.Agg([cd.INT64] * 3, [0], aggs)
         dev.prof_reset()
         ag.consume(dcols, n)
-        ran = dev.prof_get("agg_bulk")[1]
+        ran = _bulk_launches(dev)
         got = dev.result_to_vecs(ag.finish())
         ag.close()
         host = [cd.Vec.from_numpy(cd.INT64, k, pk), cd.Vec.from_numpy(cd.INT64, x, px), cd.Vec.from_numpy(cd.INT64, c, pc)]
@@ -535,12 +540,50 @@ def test_agg_bulk_path_columns_with_validity_bitmaps(oracle):
         return ran
 
     dev.prof_enable(True)
-    assert run(all_set, all_set, all_set) == 1, "all-set bitmaps kept the input off the bulk path"
+    assert run(all_set, all_set, all_set) >= 1, "all-set bitmaps kept the input off the bulk path"
     one_null = all_set.copy()
     one_null[n - 2] = False  # in the partly used last byte
     assert run(all_set, all_set, one_null) == 0
     assert run(one_null, all_set, all_set) == 0
     dev.prof_enable(False)
+
+
+@pytest.mark.parametrize("dups", [0, 3, 5_000])
+def test_agg_bulk_all_distinct_attempt_and_its_fallback(oracle, dups):
+    """The sub form's all-distinct attempt (agg_bulk_kernel<.., TRY>: group ids from the prefix sums of the regions' row
+    counts, no accumulator planes): keys the 8192-row sample sees as distinct.  dups = 0: the attempt is the result
+    (and SUM_INT skips its range check: one row per group).  dups > 0: a few keys repeat at rows the sample does not
+    visit -- the attempt is void and the general form runs over every region; either way the oracle's rows, also after
+    a second, small input."""
+    from cockroach_amd import _lib, device as dev
+    rng = np.random.default_rng(41 + dups)
+    n = 1 << 23
+    k = rng.permutation(n).astype(np.int64) * 1_000_003 - 11
+    stride = n // 8192
+    if dups:
+        src = rng.choice(np.arange(n)[np.arange(n) % stride == 5], dups, replace=False)
+        dst = src + 1  # never a sampled row (those are the multiples of the stride)
+        k[dst] = k[src]
+    x = rng.integers(-2**62, 2**62, size=n, dtype=np.int64)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64], [0], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k)), dev.upload(cd.Vec.from_numpy(cd.INT64, x))], n)
+    tried, general = dev.prof_get("agg_bulk_distinct")[1], dev.prof_get("agg_bulk")[1]
+    dev.prof_enable(False)
+    assert tried == 1 and general == (1 if dups else 0)
+    got = dev.result_to_vecs(a.finish())
+    want = oracle.hash_agg([cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.INT64, x)], [0], aggs)
+    assert np.array_equal(_canon(got), _canon(want))
+    # more input behind the bulk groups: sums may now leave the int64 range, and the check must be back
+    k2 = k[:1000].copy()
+    x2 = np.where(x[:1000] >= 0, np.iinfo(np.int64).max, np.iinfo(np.int64).min)
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k2)), dev.upload(cd.Vec.from_numpy(cd.INT64, x2))], 1000)
+    with pytest.raises(_lib.CrgpuError) as e:
+        a.finish()
+    assert e.value.code == _lib.ERR_INT_OUT_OF_RANGE
+    a.close()
 
 
 def test_agg_bulk_wide_abandoned_on_a_long_key(oracle):
@@ -560,7 +603,7 @@ def test_agg_bulk_wide_abandoned_on_a_long_key(oracle):
     dev.prof_enable(True)
     dev.prof_reset()
     got = G.gpu_agg([k, x], [0], aggs)
-    assert dev.prof_get("radix_build_hist")[1] == 1 and dev.prof_get("agg_bulk")[1] == 0, "expected an abandoned wide attempt"
+    assert dev.prof_get("radix_build_hist")[1] == 1 and _bulk_launches(dev) == 0, "expected an abandoned wide attempt"
     dev.prof_enable(False)
     want = oracle.hash_agg([k, x], [0], aggs)
     assert got[0].n == n
@@ -609,7 +652,7 @@ def test_agg_bulk_part_form_skew_and_overflow(oracle):
     dev.prof_enable(True)
     dev.prof_reset()
     got = G.gpu_agg(cols, [0], aggs)
-    assert dev.prof_get("agg_bulk_part")[1] == 0 and dev.prof_get("agg_bulk")[1] == 0
+    assert dev.prof_get("agg_bulk_part")[1] == 0 and _bulk_launches(dev) == 0
     assert np.array_equal(_canon(got), _canon(oracle.hash_agg(cols, [0], aggs)))
     k = np.where(np.arange(n) % 2 == 0, rng.integers(0, 30_000, size=n, dtype=np.int64), np.arange(n, dtype=np.int64) + 10**9)
     cols = [cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.INT64, x)]
@@ -631,7 +674,7 @@ def test_agg_bulk_path_float_values_and_fallback(oracle):
     dev.prof_enable(True)
     dev.prof_reset()
     got = G.gpu_agg(cols, [0], aggs)
-    assert dev.prof_get("agg_bulk")[1] == 1
+    assert _bulk_launches(dev) >= 1
     assert np.array_equal(_canon(got), _canon(oracle.hash_agg(cols, [0], aggs)))
     # a hot key hidden from the 8192-key sample (stride n / 8192) makes its sub-partition overflow after the sample
     # looked distinct: the bulk attempt is abandoned and the incremental path produces the result
@@ -641,7 +684,7 @@ def test_agg_bulk_path_float_values_and_fallback(oracle):
     cols2 = [cd.Vec.from_numpy(cd.INT64, k2), cd.Vec.from_numpy(cd.FLOAT64, v)]
     dev.prof_reset()
     got2 = G.gpu_agg(cols2, [0], aggs)
-    assert dev.prof_get("radix_build_split")[1] == 1 and dev.prof_get("agg_bulk")[1] == 0, "expected an abandoned bulk attempt"
+    assert dev.prof_get("radix_build_split")[1] == 1 and _bulk_launches(dev) == 0, "expected an abandoned bulk attempt"
     dev.prof_enable(False)
     assert np.array_equal(_canon(got2), _canon(oracle.hash_agg(cols2, [0], aggs)))
 

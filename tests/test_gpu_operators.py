@@ -515,3 +515,23 @@ def test_hash_joiner_pipelined_probe_chunks(jt):
         assert np.array_equal(w, pw) and np.array_equal(k, pk)
         assert np.array_equal(v3, hit)
         assert np.array_equal(rk[hit], pk[hit]) and np.array_equal(rv[hit], pk[hit] * 3 + 1)
+
+
+# ---------------------------------------------------------------- CRGPU_OUT_BORROW (crgpu_out_batch.flags)
+@pytest.mark.parametrize("which", ["joiner", "joiner_pipelined", "aggregator", "router", "distinct"])
+def test_borrowed_output_batches_equal_copied_ones(oracle, which, monkeypatch):
+    """With CRGPU_OUT_BORROW the shells hand out fixed-width values where the transfer put them instead of copying
+    them into the caller's buffers (`data` is set to the place; null bitmaps and BYTES columns are written as ever):
+    the same rows as without the flag.  _OutBatch.to_batch asserts that the pointer it reads is not its own buffer."""
+    monkeypatch.setattr(ops, "BORROW_OUTPUT", True)
+    if which == "joiner":
+        test_hash_joiner_random_vs_oracle(oracle, "FULL_OUTER")
+        test_hash_joiner_random_vs_oracle(oracle, "INNER")
+    elif which == "joiner_pipelined":
+        test_hash_joiner_pipelined_probe_chunks("INNER")
+    elif which == "aggregator":
+        test_hash_aggregator_random_vs_oracle(oracle)
+    elif which == "router":
+        test_hash_router_vs_distributor(oracle, 4)
+    else:
+        test_unordered_distinct_random_vs_oracle(oracle)
