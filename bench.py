@@ -50,6 +50,11 @@ def parse(argv=None):
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the N > 1 code path (hash repartition -> crgpu_exchange over RCCL -> local join, then the "
                          "two-stage GROUP BY) even with one rank: a self-exchange through RCCL")
+    ap.add_argument("--probe-chunks", type=int, default=0,
+                    help="N > 1: pieces the probe side is repartitioned and exchanged in; piece c + 1 is partitioned and "
+                         "exchanged by a second thread while piece c is probed (1: one piece, no overlap; 0 = 4 with more "
+                         "than one rank, 1 for --force-distributed with one rank, where the 'exchange' is a device copy "
+                         "that competes with the probe for the same HBM: 27.0 ms against 25.4)")
     ap.add_argument("--log2-groupby", type=int, default=26, help="rows per GPU of the distributed GROUP BY leg (N > 1)")
     ap.add_argument("--no-q9", action="store_true", help="skip the distributed TPC-H Q9 leg of an N > 1 run")
     ap.add_argument("--q9-sf", type=float, default=0.0,
@@ -252,12 +257,18 @@ def main(argv=None):
 
     I64 = cd.INT64
     join = dev.Join(0, [I64, I64], [I64, I64], [0], [0], True, out_cols=[1, 3])  # INNER, output (w, v)
-    part_b = part_p = xch_b = xch_p = None
+    part_b = xch_b = None
+    parts_p, xchs_p = [], []
+    chunks = (args.probe_chunks if args.probe_chunks > 0 else (4 if world > 1 else 1)) if distributed else 1
     if distributed:
         part_b = dev.Partitioner([I64, I64], [0], world)
-        part_p = dev.Partitioner([I64, I64], [0], world)
-        # one exchange handle per join input: a result is owned by its handle until that handle's next call
-        xch_b, xch_p = xch, xch.clone()  # the same communicator, own stream and result buffers (crgpu_exchange_clone)
+        # one exchange handle per join input: a result is owned by its handle until that handle's next call; the probe
+        # side travels in `chunks` pieces through two (partitioner, exchange) pairs, so that piece c + 1 is partitioned
+        # and exchanged while piece c is probed (crgpu_exchange_clone: the same communicator, own stream and buffers)
+        xch_b = xch
+        for _ in range(min(2, chunks)):
+            parts_p.append(dev.Partitioner([I64, I64], [0], world))
+            xchs_p.append(xch.clone())
 
     def exchange(part, x, cols_t, n):
         """hash-repartition (crgpu_dev_partition) + RCCL all-to-all (crgpu_exchange_all_to_all); device columns."""
@@ -265,7 +276,54 @@ def main(argv=None):
         got, rc = x.all_to_all(dev.result_columns(res), counts)
         return dev.result_columns(got), int(rc.sum())
 
-    def step():
+    def probe_pipelined(check):
+        """The probe side in `chunks` pieces: a producer thread partitions and exchanges piece c + 1 (its own handles and
+        streams; the only thread that touches the communicator meanwhile) while this thread probes piece c.  Every call
+        of the library waits for its own stream before it returns, so a piece handed over is complete, and a slot is
+        only reused once the probe that read it has returned.  Returns (last result, output rows of all pieces)."""
+        import queue
+        import threading
+        nslots = len(parts_p)
+        bounds = [npr * c // chunks for c in range(chunks + 1)]
+        free = [threading.Semaphore(1) for _ in range(nslots)]
+        ready = queue.Queue()
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for c in range(chunks):
+                    s = c % nslots
+                    free[s].acquire()
+                    if stop.is_set():
+                        return
+                    lo, hi = bounds[c], bounds[c + 1]
+                    cols, n = exchange(parts_p[s], xchs_p[s], [pk[lo:hi], pw[lo:hi]], hi - lo)
+                    ready.put((s, cols, n, None))
+            except BaseException as e:  # noqa: BLE001 - handed to the consumer
+                ready.put((None, None, 0, e))
+
+        t = threading.Thread(target=produce, name="probe-side exchange")
+        t.start()
+        res, total = None, 0
+        try:
+            for _ in range(chunks):
+                s, cols, n, err = ready.get()
+                if err is not None:
+                    raise err
+                res = join.probe(cols, n)
+                total += int(res.n)
+                if check is not None:
+                    check(res)
+                free[s].release()
+        finally:
+            stop.set()
+            for f in free:
+                f.release()
+            t.join()
+        return res, total
+
+    def step(check=None):
+        """One pass; returns (result of the last probe call, output rows of the pass, columns kept alive)."""
         if not distributed:
             b_cols = [dev.from_torch(I64, t) for t in (bk, bv)]
             p_cols = [dev.from_torch(I64, t) for t in (pk, pw)]
@@ -274,10 +332,16 @@ def main(argv=None):
                 p_cols[0] = dev.from_torch(I64, pk, valid=pk_valid)
         else:
             b_cols, nbl = exchange(part_b, xch_b, [bk, bv], nb)
-            p_cols, npl = exchange(part_p, xch_p, [pk, pw], npr)
+            if chunks > 1:
+                join.build(b_cols, nbl)
+                res, total = probe_pipelined(check)
+                return res, total, b_cols, None
+            p_cols, npl = exchange(parts_p[0], xchs_p[0], [pk, pw], npr)
         join.build(b_cols, nbl)
         res = join.probe(p_cols, npl)
-        return res, b_cols, p_cols
+        if check is not None:
+            check(res)
+        return res, int(res.n), b_cols, p_cols
 
     def barrier():
         torch.cuda.synchronize()
@@ -286,22 +350,19 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        res, _b, _p = step()
+        res, out_rows, _b, _p = step()
     dev.prof_enable(True)
     dev.prof_reset()
     barrier()
     t0 = time.perf_counter()
     out_rows = 0
     for _ in range(args.steps):
-        res, _b, _p = step()
-        out_rows = int(res.n)
+        res, out_rows, _b, _p = step()
     barrier()
     dt = time.perf_counter() - t0
     dev.prof_enable(False)
 
     # result check outside the timed region (size-independent property: sum(v) == sum(3k+1) over probe keys)
-    w_out = _wrap(torch, res.cols[0].data, out_rows, device)
-    v_out = _wrap(torch, res.cols[1].data, out_rows, device)
     # The union of all ranks' build keys is a permutation of [0, nb * world) (rank r holds k * world + r), so a probe row
     # hits iff its key is below nb * world (and not NULL): what THIS rank's probe rows must contribute to the output of
     # the whole job -- rows, sum(v) = sum(3k + 1), sum(w) -- is known from its inputs, wherever the exchange sent them.
@@ -309,17 +370,38 @@ def main(argv=None):
     if args.variant == "null1":
         hit = hit & ~isnull
     want = torch.stack([hit.sum(), ((pk * 3 + 1) * hit).sum(), (pw * hit).sum()]).to(torch.int64)
-    got = torch.stack([torch.tensor(out_rows, device=device), v_out.sum(), w_out.sum()]).to(torch.int64)  # (int64 sums wrap alike)
-    # every output row must sit on the rank its key routes to: k = (v - 1) / 3, dest = rehash64(1, k) % world
-    misrouted = torch.zeros(1, dtype=torch.int64, device=device)
-    if distributed and out_rows:
-        ns = min(out_rows, 1 << 24)
-        k_out = ((v_out[:ns] - 1) // 3).contiguous()
-        dest = torch.empty(ns, dtype=torch.int64, device=device)
-        torch.cuda.synchronize()
-        _lib.check(_lib.load().crgpu_dev_hash_cols(dev.dcol_array([dev.from_torch(I64, k_out)]), 1, ns, 1, 64, world, dest.data_ptr()))
-        _lib.check(_lib.load().crgpu_dev_synchronize())
-        misrouted = (dest != rank).sum().reshape(1)
+    acc = {"rows": 0, "v": torch.zeros((), dtype=torch.int64, device=device), "w": torch.zeros((), dtype=torch.int64, device=device),
+           "misrouted": torch.zeros(1, dtype=torch.int64, device=device)}
+
+    def check_result(r):
+        """Adds one probe result's row count, sum(v), sum(w) (int64 sums wrap alike) and its misrouted rows: every output
+        row must sit on the rank its key routes to -- k = (v - 1) / 3, dest = rehash64(1, k) % world."""
+        n_out = int(r.n)
+        if n_out == 0:
+            return
+        w_o = _wrap(torch, r.cols[0].data, n_out, device)
+        v_o = _wrap(torch, r.cols[1].data, n_out, device)
+        acc["rows"] += n_out
+        acc["v"] += v_o.sum()
+        acc["w"] += w_o.sum()
+        if distributed:
+            ns = min(n_out, 1 << 24)
+            k_out = ((v_o[:ns] - 1) // 3).contiguous()
+            dest = torch.empty(ns, dtype=torch.int64, device=device)
+            torch.cuda.synchronize()
+            _lib.check(_lib.load().crgpu_dev_hash_cols(dev.dcol_array([dev.from_torch(I64, k_out)]), 1, ns, 1, 64, world, dest.data_ptr()))
+            _lib.check(_lib.load().crgpu_dev_synchronize())
+            acc["misrouted"] += (dest != rank).sum().reshape(1)
+        torch.cuda.synchronize()  # the result's buffers go back to the join with its next call
+
+    if chunks > 1:
+        # a piece's result lives until the next probe call: one more pass, untimed, checks every piece as it comes out
+        res, out_rows, _b, _p = step(check=check_result)
+    else:
+        check_result(res)
+    got = torch.stack([torch.tensor(acc["rows"], device=device), acc["v"], acc["w"]]).to(torch.int64)
+    misrouted = acc["misrouted"]
+    ok_rows = acc["rows"] == out_rows
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -327,7 +409,7 @@ def main(argv=None):
         both = torch.cat([want, got, misrouted])
         dist.all_reduce(both, op=dist.ReduceOp.SUM)
         want, got, misrouted = both[:3], both[3:6], both[6:]
-    ok = bool((want == got).all().item()) and int(misrouted.item()) == 0
+    ok = bool((want == got).all().item()) and int(misrouted.item()) == 0 and ok_rows
     # per-kernel HIP-event times recorded on the library stream (crgpu_prof_*); algorithmic bytes per row
     # of each kernel's own input/output
     kern_rows = {"join_build": (nb, 16.0), "join_probe": (npr, 32.0),
@@ -380,10 +462,11 @@ def main(argv=None):
     join.close()
     if distributed:
         gb = distributed_group_by(args, torch, dist, dev, cd, _lib, xch_b, world, rank, device)
-        for h in (part_b, part_p, xch_p):
+        for h in [part_b] + parts_p + xchs_p:
             h.close()
-        part_b = part_p = xch_p = None
-        del bk, bv, pk, pk_base, pw, res, _b, _p, w_out, v_out, hit
+        part_b = None
+        parts_p, xchs_p = [], []
+        del bk, bv, pk, pk_base, pw, res, _b, _p, hit
         torch.cuda.empty_cache()
         _lib.load().crgpu_mem_trim()
         q9 = None
@@ -399,7 +482,7 @@ def main(argv=None):
             # the other rows of the hot path, measured in the same run (not part of `value`): DESIGN.md 4.3 / 4.4
             line["other_paths"] = other_paths(local_rank)
         print(json.dumps(line), flush=True)
-    for h in (part_b, part_p, xch_p, xch_b):
+    for h in [part_b] + parts_p + xchs_p + [xch_b]:
         if h is not None:
             h.close()
     if world > 1:
