@@ -302,12 +302,16 @@ def main(argv=None):
             except BaseException as e:  # noqa: BLE001 - handed to the consumer
                 ready.put((None, None, 0, e))
 
-        t = threading.Thread(target=produce, name="probe-side exchange")
+        t = threading.Thread(target=produce, name="probe-side exchange", daemon=True)
         t.start()
         res, total = None, 0
         try:
             for _ in range(chunks):
-                s, cols, n, err = ready.get()
+                try:
+                    s, cols, n, err = ready.get(timeout=300)
+                except queue.Empty:  # a peer died or the collectives went out of step: fail, do not hang the job
+                    sys.stderr.write(f"rank {rank}: no probe piece arrived within 300 s; giving up\n")
+                    os._exit(4)
                 if err is not None:
                     raise err
                 res = join.probe(cols, n)
@@ -319,7 +323,10 @@ def main(argv=None):
             stop.set()
             for f in free:
                 f.release()
-            t.join()
+            t.join(timeout=300)
+            if t.is_alive():
+                sys.stderr.write(f"rank {rank}: the probe-side exchange thread did not finish; giving up\n")
+                os._exit(4)
         return res, total
 
     def step(check=None):
