@@ -74,6 +74,19 @@ def test_bench_distributed_path_with_one_rank(capsys):
     assert "exchange" in line["kernels_ms_per_step"] and "partition" in line["kernels_ms_per_step"]
 
 
+@pytest.mark.parametrize("chunks", [2, 5])
+def test_bench_distributed_probe_side_in_pieces(capsys, chunks):
+    """The pipelined form of the N > 1 step (the default with more than one rank): the probe side is partitioned and
+    exchanged in pieces by a second thread while the previous piece is probed; bench.py's extra pass checks every piece's
+    rows, sums and routing.  Pieces of unequal size (2^20 rows in 5) included."""
+    import json
+    import bench
+    bench.main(["--force-distributed", "--log2-build", "18", "--log2-probe", "20", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline", "--no-other-paths", "--log2-groupby", "16", "--no-q9", "--probe-chunks", str(chunks)])
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["config"]["result_check"] == "ok"
+
+
 def test_self_exchange_two_gib_columns(xch):
     """2^28 rows of two int64 columns: 2 GiB per column and destination.  A single ncclSend / ncclRecv of that size
     delivered wrong data on this RCCL; the exchange moves a region in pieces of 256 MiB."""
