@@ -4430,9 +4430,14 @@ __global__ __launch_bounds__(256) void agg_bitmap_has_null_kernel(const uint8_t 
 
 // Bulk path (see agg_bulk_kernel).  *done = true when the whole input was aggregated; otherwise nothing was changed
 // and the caller continues with the incremental path.
-static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
+// `append`: the table already holds groups, all of them from earlier bulk calls, and the caller vouches that no key of
+// this input is among them (try_bulk_huge: the pieces of one input split by key hash): the new groups are numbered
+// behind the old ones and nothing else changes -- the hash index is not in use yet.
+static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done, bool append = false) {
   *done = false;
-  if (a->ngroups != 0 || a->seq != 0 || n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
+  if (!append && (a->ngroups != 0 || a->seq != 0)) return CRGPU_OK;
+  if (append && a->index_valid && a->ngroups != 0) return CRGPU_OK;  // (groups that live in the index: not this path)
+  if (n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
   if (a->group_cols.size() != 1 && a->group_cols.size() != 2) return CRGPU_OK;
   const int key_type = a->types[a->group_cols[0]];
   // One INT64 key travels as 16-byte {key, value} rows; one BYTES key of at most 16 bytes, or two integer keys, as
@@ -4458,14 +4463,16 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   if (two_vals && (two_ints || key_type != CRGPU_INT64)) return CRGPU_OK;
   const bool wide = two_ints || two_vals || key_type == CRGPU_BYTES;
   if (key_type != CRGPU_INT64 && !wide) return CRGPU_OK;
+  if (append && wide) return CRGPU_OK;
   static const bool wide_on = getenv("CRGPU_BULK_WIDE") == nullptr || getenv("CRGPU_BULK_WIDE")[0] != '0';
   if (wide && !wide_on) return CRGPU_OK;
   DCol key = cols[a->group_cols[0]];
   DCol key2;
   std::memset(&key2, 0, sizeof(key2));
   if (two_ints) key2 = cols[a->group_cols[1]];
-  if (!wide && (reinterpret_cast<uintptr_t>(key.data) & 15u) != 0) return CRGPU_OK;
-  if (vcol >= 0 && !wide && (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) != 0) return CRGPU_OK;
+  // (16-byte vector loads of two rows; a piece of a hash-split input may start at an odd row: the row-wise form then)
+  bool aligned16 = (reinterpret_cast<uintptr_t>(key.data) & 15u) == 0 && (vcol < 0 || (reinterpret_cast<uintptr_t>(cols[vcol].data) & 15u) == 0);
+  if (!wide && !aligned16 && !append) return CRGPU_OK;
   hipStream_t st = stream();
   {
     // Columns that carry a validity bitmap without a NULL in it (the partial rows of a distributed GROUP BY arrive like
@@ -4573,7 +4580,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   src.kp.range[0] = ~0ull;
   src.pay = vcol >= 0 ? static_cast<const uint8_t *>(cols[vcol].data) : nullptr;
   src.pay_width = vcol >= 0 ? 8 : 0;
-  src.fast = vcol >= 0 ? 1 : 0;
+  src.fast = vcol >= 0 && aligned16 ? 1 : 0;
   if (wide) {
     WideSrc ws;
     ws.key = key;
@@ -4591,7 +4598,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   } else {
     CRGPU_TRY(radix_partition_level1(a->radix, src, n));
   }
-  CRGPU_TRY(ensure_groups(a, static_cast<size_t>(n)));
+  const uint32_t g0 = static_cast<uint32_t>(a->ngroups);
+  CRGPU_TRY(ensure_groups(a, static_cast<size_t>(g0) + static_cast<size_t>(n)));
   CRGPU_TRY(upload_descriptors(a, &cols));
   CRGPU_TRY(a->bulk_count.ensure(16));
   CRGPU_HIP(hipMemsetAsync(a->bulk_count.p, 0, 16, st));
@@ -4633,7 +4641,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.failed = a->bulk_count.as<unsigned int>() + 1;
   b.not16 = a->bulk_count.as<unsigned int>() + 2;
   b.wmask = two_vals ? 0ull : ~0ull;
-  b.g0 = 0;
+  b.g0 = g0;
   b.gmax = static_cast<uint32_t>(gmax);
   b.slots = static_cast<uint32_t>(slots);
   const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) << a->radix.sub_bits : static_cast<unsigned>(kRadixP1);
@@ -4684,11 +4692,92 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     a->descriptors_dirty = true;
     a->dense16 = tf[2] == 0;
   }
-  a->ngroups = total;
-  a->one_row_groups = tried_ok;
-  a->seq = static_cast<unsigned long long>(n);
+  if (static_cast<uint64_t>(g0) + total > (kMaxCap >> 1)) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_agg_consume: more than 2^29 groups per GPU");
+  a->ngroups = static_cast<int64_t>(g0) + total;
+  a->one_row_groups = tried_ok && (g0 == 0 || a->one_row_groups);
+  a->seq += static_cast<unsigned long long>(n);
   a->new_ratio = static_cast<double>(total) / static_cast<double>(n);
   a->index_valid = false;  // the groups exist, their index entries do not
+  *done = true;
+  return CRGPU_OK;
+}
+
+// A first input of more than 2^27 rows (the bulk path's regions are sized for that): the (key, value) rows are split by
+// key hash into pieces of ~2^26 rows with the router's partition kernels (crgpu_dev_partition: rehash64 % pieces,
+// independent of the radix bits) and every piece goes through the bulk path by itself -- equal keys share a piece, so a
+// piece's groups are final and are appended behind those of the pieces before it; nothing is merged and the hash index
+// is still not touched.  One INT64 key, at most one 8-byte value column, no validity bitmaps.  A piece the bulk path
+// declines (few groups, a hot key, an overflowing region) and every piece after it take the incremental path.
+// *pos = rows consumed through pieces (all or nothing per piece; the pieces are consumed in full either way).
+static crgpu_status crgpu_consume_rows(crgpu_agg *a, std::vector<DCol> &in, int64_t n);
+static crgpu_status try_bulk_huge(crgpu_agg *a, const std::vector<DCol> &cols, int64_t n, bool *done) {
+  *done = false;
+  const char *hm = getenv("CRGPU_BULK_HUGE_MIN");  // (read per call: tests lower it)
+  const int64_t huge_min = hm != nullptr && *hm ? atoll(hm) : (int64_t(1) << 27) + 1;
+  if (a->ngroups != 0 || a->seq != 0 || n < huge_min || n < 2 * kBulkMinRows || n > 0x7FFFFFF0ll || a->need_any_fix || a->has_computed || !a->dsets.empty())
+    return CRGPU_OK;
+  if (a->group_cols.size() != 1 || a->types[a->group_cols[0]] != CRGPU_INT64) return CRGPU_OK;
+  int vcol = -1;
+  for (const AggOpHost &h : a->ops) {
+    if (h.kind == ACC_ANY_KEY) continue;
+    if (h.filter_col >= 0) return CRGPU_OK;
+    if (h.kind != ACC_COUNT_ROWS) {
+      if (h.in_type != CRGPU_INT64 && h.in_type != CRGPU_FLOAT64) return CRGPU_OK;
+      if (vcol >= 0 && vcol != h.col) return CRGPU_OK;
+      vcol = h.col;
+    }
+  }
+  const int kcol = a->group_cols[0];
+  if (cols[kcol].valid != nullptr || (vcol >= 0 && cols[vcol].valid != nullptr) || vcol == kcol) return CRGPU_OK;
+  int pieces = 2;
+  while (n / pieces > (int64_t(1) << 26)) pieces *= 2;
+  if (n / pieces < kBulkMinRows) return CRGPU_OK;
+  std::vector<int32_t> ptypes = {CRGPU_INT64};
+  std::vector<crgpu_dcol> pcols(1);
+  std::memset(pcols.data(), 0, sizeof(crgpu_dcol));
+  pcols[0].type = CRGPU_INT64;
+  pcols[0].data = cols[kcol].data;
+  if (vcol >= 0) {
+    crgpu_dcol v;
+    std::memset(&v, 0, sizeof(v));
+    v.type = a->types[vcol];
+    v.data = cols[vcol].data;
+    ptypes.push_back(v.type);
+    pcols.push_back(v);
+  }
+  const int32_t hash_col = 0;
+  crgpu_partitioner *part = nullptr;
+  CRGPU_TRY(crgpu_dev_partitioner_create(ptypes.data(), static_cast<int32_t>(ptypes.size()), &hash_col, 1, 0x9E3779B97F4A7C15ull, pieces, &part));
+  struct Guard {
+    crgpu_partitioner *p;
+    ~Guard() { crgpu_dev_partitioner_destroy(p); }
+  } guard{part};
+  std::vector<int64_t> counts(static_cast<size_t>(pieces), 0);
+  crgpu_dev_result pr;
+  CRGPU_TRY(crgpu_dev_partition(part, pcols.data(), n, &pr, counts.data()));
+  // (one allocation, not one per piece; a piece's rows are written before its groups are counted, so room for one
+  // piece beyond the 2^29 groups a table may hold)
+  const int64_t room = (int64_t(1) << 29) + (int64_t(1) << 27);
+  CRGPU_TRY(ensure_groups(a, static_cast<size_t>(n < room ? n : room)));
+  bool incremental = false;
+  int64_t off = 0;
+  for (int s = 0; s < pieces; s++) {
+    const int64_t m = counts[static_cast<size_t>(s)];
+    if (m == 0) continue;
+    std::vector<DCol> piece(cols.size());
+    for (auto &d : piece) std::memset(&d, 0, sizeof(d));
+    for (size_t c = 0; c < cols.size(); c++) piece[c].type = cols[c].type;
+    piece[static_cast<size_t>(kcol)].data = static_cast<const uint8_t *>(pr.cols[0].data) + off * 8;
+    if (vcol >= 0) piece[static_cast<size_t>(vcol)].data = static_cast<const uint8_t *>(pr.cols[1].data) + off * 8;
+    // (columns the aggregations do not read stay null: neither path touches them -- ANY_NOT_NULL of the key reads the key store)
+    bool piece_done = false;
+    if (!incremental) CRGPU_TRY(try_bulk(a, piece, m, &piece_done, true));
+    if (!piece_done) {
+      incremental = true;
+      CRGPU_TRY(crgpu_consume_rows(a, piece, m));
+    }
+    off += m;
+  }
   *done = true;
   return CRGPU_OK;
 }
@@ -4772,9 +4861,17 @@ static crgpu_status crgpu_dev_agg_consume_impl(crgpu_agg *a, const crgpu_dcol *c
   a->one_row_groups = false;
   {
     bool done = false;
+    CRGPU_TRY(try_bulk_huge(a, in, n, &done));
+    if (done) return CRGPU_OK;
     CRGPU_TRY(try_bulk(a, in, n, &done));
     if (done) return CRGPU_OK;
   }
+  return crgpu_consume_rows(a, in, n);
+}
+
+// The incremental path: find-or-insert through the hash index, chunk by chunk.
+static crgpu_status crgpu_consume_rows(crgpu_agg *a, std::vector<DCol> &in, int64_t n) {
+  a->one_row_groups = false;
   a->dense16 = false;
   if (!a->index_valid) {  // groups appended by the bulk path: give them index entries before looking anything up
     const uint64_t want = next_pow2((static_cast<uint64_t>(a->ngroups) + 1) * 2);

@@ -586,6 +586,47 @@ def test_agg_bulk_all_distinct_attempt_and_its_fallback(oracle, dups):
     a.close()
 
 
+@pytest.mark.parametrize("shape", ["distinct", "twice", "few_groups_in_a_piece"])
+def test_agg_bulk_input_split_into_pieces_vs_oracle(oracle, shape, monkeypatch):
+    """A first input beyond the bulk path's 2^27 rows is split by key hash into pieces that go through the bulk path one
+    after the other, each appending its groups behind the previous pieces' (try_bulk_huge).  Here with the threshold
+    lowered to 2^24 rows (two pieces of ~2^23): all keys distinct, every key twice, and an input whose keys are mostly
+    one hot key apart from distinct ones -- the bulk path declines such pieces and they take the incremental path
+    behind the bulk groups.  Against the oracle; then a second, small input that meets old and new keys."""
+    from cockroach_amd import device as dev
+    monkeypatch.setenv("CRGPU_BULK_HUGE_MIN", str(1 << 24))
+    rng = np.random.default_rng({"distinct": 51, "twice": 52, "few_groups_in_a_piece": 53}[shape])
+    n = (1 << 24) + 12345
+    if shape == "distinct":
+        k = rng.permutation(n).astype(np.int64) * 1_000_003 - 5
+    elif shape == "twice":
+        half = rng.permutation(n // 2 + 1).astype(np.int64) * 1_000_003 - 5
+        k = np.concatenate([half, half])[:n]
+        rng.shuffle(k)
+    else:
+        k = rng.permutation(n).astype(np.int64) * 1_000_003 - 5
+        k[rng.random(n) < 0.3] = 424242  # a hot key: the sample sees it, its piece is declined
+    x = rng.integers(-10**9, 10**9, size=n, dtype=np.int64)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["MIN"], 1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64], [0], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k)), dev.upload(cd.Vec.from_numpy(cd.INT64, x))], n)
+    pieces_bulk = _bulk_launches(dev) + dev.prof_get("agg_bulk_part")[1]
+    parts = dev.prof_get("partition")[1]
+    dev.prof_enable(False)
+    assert parts == 1, "the input was not split"
+    if shape != "few_groups_in_a_piece":
+        assert pieces_bulk >= 2, "the pieces did not take the bulk path"
+    k2 = np.concatenate([k[:5000], np.arange(5000, dtype=np.int64) * 1_000_003 + 1])
+    x2 = rng.integers(-10**9, 10**9, size=len(k2), dtype=np.int64)
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k2)), dev.upload(cd.Vec.from_numpy(cd.INT64, x2))], len(k2))
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    want = oracle.hash_agg([cd.Vec.from_numpy(cd.INT64, np.concatenate([k, k2])), cd.Vec.from_numpy(cd.INT64, np.concatenate([x, x2]))], [0], aggs)
+    assert np.array_equal(_canon(got), _canon(want))
+
+
 def test_agg_bulk_wide_abandoned_on_a_long_key(oracle):
     """One 17-byte key that the 8192-row sample does not see: the histogram pass of the wide form reports it, the
     attempt is abandoned before anything is committed, and the incremental path gives the oracle's result."""
@@ -824,6 +865,60 @@ def test_agg_two_to_the_thirty_rows_in_one_call():
         s = float(x[m].sum().item())  # integers below 2^53: exact in any order
         assert got[g][0] == cnt and got[g][1] == s and got[g][2] == s / cnt
     assert got[6][0] == 9
+
+
+def test_agg_two_to_the_thirty_rows_and_half_as_many_groups():
+    """BASELINE.json configs[4] at the size ONE GPU holds: 2^30 rows over 2^29 distinct int64 keys (the most groups a
+    table takes: 32-bit group ids, 2^30 index entries), every key twice at scattered rows, SUM_INT + COUNT_ROWS, in one
+    consume() call -- split by key hash into 16 pieces that go through the bulk path one after the other
+    (try_bulk_huge), no hash index built.  Size-independent checks: 2^29 groups, every count is 2, the sums of the keys and
+    of their squares (mod 2^64) are those of the 2^29 distinct keys, the grand total of the values is the input's."""
+    import time
+    import torch
+    from cockroach_amd import _lib, device as dev
+    from tests import gpu_util as GU
+    _lib.check(_lib.load().crgpu_init(0))
+    n, ng = 1 << 30, 1 << 29
+    MIX = 0x9E3779B97F4A7C15 - (1 << 64)  # odd: g -> g * MIX is a bijection of the int64 values
+    j = (torch.arange(n, device="cuda", dtype=torch.int64) * 0x9E3779B1) & (n - 1)  # a permutation of the row numbers
+    k = (j >> 1) * MIX
+    x = j & 1023
+    del j
+    gk = torch.arange(ng, device="cuda", dtype=torch.int64) * MIX
+    want_k, want_k2, want_x = int(gk.sum().item()), int((gk * gk).sum().item()), int(x.sum().item())
+    del gk
+    torch.cuda.synchronize()
+    a = dev.Agg([cd.INT64, cd.INT64], [0], [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1)])
+    try:
+        for attempt in ("cold", "warm"):  # (the first pass pays ~100 GB of first-time device allocations)
+            a.reset()
+            dev.prof_enable(True)
+            dev.prof_reset()
+            t0 = time.perf_counter()
+            a.consume([dev.from_torch(cd.INT64, k), dev.from_torch(cd.INT64, x)], n)
+            res = a.finish()
+            _lib.check(_lib.load().crgpu_dev_synchronize())
+            dt = time.perf_counter() - t0
+            pieces = _bulk_launches(dev)
+            resolved = dev.prof_get("agg_resolve")[1]
+            kern = {f: round(dev.prof_get(f)[0], 2) for f in ("partition", "radix_build_hist", "radix_build_scatter", "radix_build_split",
+                                                               "agg_bulk", "agg_bulk_distinct")}
+            dev.prof_enable(False)
+            print(f"2^30 rows / 2^29 groups ({attempt}): {dt * 1e3:.1f} ms, {n / dt:.3g} rows/s, {pieces} bulk launches, kernels ms {kern}")
+        assert int(res.n) == ng
+        assert pieces >= 16 and resolved == 0, "the pieces did not all take the bulk path"
+        d = torch.device("cuda", 0)
+        ko = GU.wrap_torch_ptr(res.cols[0].data, ng, torch.int64, d)
+        so = GU.wrap_torch_ptr(res.cols[1].data, ng, torch.int64, d)
+        co = GU.wrap_torch_ptr(res.cols[2].data, ng, torch.int64, d)
+        assert int(co.min().item()) == 2 and int(co.max().item()) == 2
+        assert int(ko.sum().item()) == want_k and int((ko * ko).sum().item()) == want_k2
+        assert int(so.sum().item()) == want_x
+    finally:
+        a.close()
+        del k, x
+        torch.cuda.empty_cache()
+        _lib.load().crgpu_mem_trim()
 
 
 @pytest.mark.parametrize("xtype", [cd.INT64, cd.FLOAT64, cd.BYTES])
