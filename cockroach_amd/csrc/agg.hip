@@ -4437,7 +4437,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   *done = false;
   if (!append && (a->ngroups != 0 || a->seq != 0)) return CRGPU_OK;
   if (append && a->index_valid && a->ngroups != 0) return CRGPU_OK;  // (groups that live in the index: not this path)
-  if (n < kBulkMinRows || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
+  // (a piece of a split input may fall a little short of the size a first input needs to be worth the partitioning)
+  if (n < (append ? kBulkMinRows / 2 : kBulkMinRows) || n > (int64_t(1) << 27) || a->need_any_fix || a->has_computed) return CRGPU_OK;
   if (a->group_cols.size() != 1 && a->group_cols.size() != 2) return CRGPU_OK;
   const int key_type = a->types[a->group_cols[0]];
   // One INT64 key travels as 16-byte {key, value} rows; one BYTES key of at most 16 bytes, or two integer keys, as

@@ -627,6 +627,37 @@ def test_agg_bulk_input_split_into_pieces_vs_oracle(oracle, shape, monkeypatch):
     assert np.array_equal(_canon(got), _canon(want))
 
 
+@pytest.mark.parametrize("value", ["float", "none"])
+def test_agg_bulk_input_split_into_pieces_other_value_shapes(oracle, value, monkeypatch):
+    """try_bulk_huge with a FLOAT64 value column (SUM / MIN / MAX / AVG) and with no value column at all (COUNT_ROWS
+    only), unused input columns beside them (the pieces carry only the key and the value column)."""
+    from cockroach_amd import device as dev
+    monkeypatch.setenv("CRGPU_BULK_HUGE_MIN", str(1 << 24))
+    rng = np.random.default_rng(61 if value == "float" else 62)
+    n = (1 << 24) + 77
+    half = rng.permutation(n // 2 + 1).astype(np.int64) * 7919 + 3
+    k = np.concatenate([half, half])[:n]
+    rng.shuffle(k)
+    unused = cd.Vec.from_numpy(cd.INT32, np.zeros(n, dtype=np.int32))
+    if value == "float":
+        x = rng.integers(-2**20, 2**20, size=n).astype(np.float64) / 8.0  # exact in any order
+        cols = [unused, cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.FLOAT64, x)]
+        aggs = [(F["ANY_NOT_NULL"], 1, -1), (F["SUM"], 2, -1), (F["MIN"], 2, -1), (F["MAX"], 2, -1), (F["AVG"], 2, -1), (F["COUNT_ROWS"], -1, -1)]
+    else:
+        cols = [unused, cd.Vec.from_numpy(cd.INT64, k)]
+        aggs = [(F["ANY_NOT_NULL"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    a = dev.Agg([v.type for v in cols], [1], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(v) for v in cols], n)
+    assert dev.prof_get("partition")[1] == 1 and _bulk_launches(dev) >= 2
+    dev.prof_enable(False)
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    want = oracle.hash_agg(cols, [1], aggs)
+    assert np.array_equal(_canon(got), _canon(want))
+
+
 def test_agg_bulk_wide_abandoned_on_a_long_key(oracle):
     """One 17-byte key that the 8192-row sample does not see: the histogram pass of the wide form reports it, the
     attempt is abandoned before anything is committed, and the incremental path gives the oracle's result."""

@@ -131,6 +131,26 @@ def test_ordered_agg_random_vs_oracle(oracle, kind):
         assert early > 0.9 * len(rows), "groups of completed runs must be handed out before the input ends"
 
 
+def test_ordered_agg_with_distinct_and_filter_aggregations(oracle):
+    """The ordered form wraps an ordinary aggregator, so DISTINCT and FILTER aggregations come along: per run of the
+    ordered column, COUNT(DISTINCT x), SUM(DISTINCT x) FILTER (WHERE f), COUNT_ROWS FILTER (WHERE f) -- the DISTINCT
+    tables are reset with every piece, which is right because a group never spans two pieces."""
+    rng = np.random.default_rng(9)
+    n = 60_000
+    run = np.sort(rng.integers(0, 400, size=n))
+    o0 = cd.Vec.from_numpy(cd.INT64, run * 3)
+    g = cd.Vec.from_numpy(cd.INT32, rng.integers(0, 4, size=n).astype(np.int32))
+    x = cd.Vec.from_numpy(cd.INT64, rng.integers(0, 12, size=n, dtype=np.int64), rng.random(n) > 0.1)
+    f = cd.Vec.from_numpy(cd.BOOL, rng.integers(0, 2, size=n).astype(np.uint8), rng.random(n) > 0.05)
+    cols = [o0, g, x, f]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 1, -1), (F["COUNT"], 2, -1, True), (F["SUM_INT"], 2, 3, True),
+            (F["COUNT_ROWS"], -1, 3), (F["SUM_INT"], 2, -1)]
+    want = _oracle_in_run_order(oracle, cols, [0, 1], [0], aggs)
+    for bounds in ([0, n], [0, 5, 8191, 30_001, n], list(range(0, n, 2048)) + [n]):
+        rows, early = run_ordered(cols, [0, 1], [0], aggs, bounds)
+        H.assert_partial_order(rows, want, [0], f"{len(bounds) - 1} calls")
+
+
 def test_ordered_agg_one_long_run_and_reset(oracle):
     """No change of the ordered column at all: nothing is ready before finish; a second use after reset gives the same."""
     rng = np.random.default_rng(5)
