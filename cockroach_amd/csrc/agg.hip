@@ -5414,7 +5414,7 @@ extern "C" crgpu_status crgpu_dev_agg_emit_ready(crgpu_agg *a, crgpu_dev_result 
   CRGPU_CHECK_CANCEL(a);
   if (!a->ord) {  // unordered input: nothing is complete before the input ends
     res->n = 0;
-    res->ncols = static_cast<int32_t>(a->ops.size());
+    res->ncols = 0;  // (no column descriptors to look at)
     res->_pad = 0;
     res->cols = nullptr;
     return CRGPU_OK;
