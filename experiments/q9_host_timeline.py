@@ -45,7 +45,7 @@ def main():
             t0 = time.perf_counter()
             tabs = {k: ex.table(v) for k, v in t.items()}
             t1 = time.perf_counter()
-            P.q9(ex, tabs)
+            (P.q3 if (len(sys.argv) > 2 and sys.argv[2] == "q3") else P.q9)(ex, tabs)
             lib.crgpu_dev_synchronize()
             t2 = time.perf_counter()
             ex.close()

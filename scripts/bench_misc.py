@@ -29,12 +29,20 @@ def _timed(fn, reps):
     _sync()  # inputs are produced on torch's stream, the library runs on its own: offsets read early are garbage
     fn()
     _sync()
-    dev.prof_enable(True); dev.prof_reset()
+    # wall time with the library's profiling hooks off (two events per kernel family and launch); the per-family kernel
+    # times come from `reps` more passes with them on (_kernels divides by reps)
+    dev.prof_enable(False)
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
     _lib.load().crgpu_dev_synchronize()
-    return (time.perf_counter() - t0) / reps
+    dt = (time.perf_counter() - t0) / reps
+    dev.prof_enable(True); dev.prof_reset()
+    for _ in range(reps):
+        fn()
+    _lib.load().crgpu_dev_synchronize()
+    dev.prof_enable(False)
+    return dt
 
 
 def _kernels(names, reps):
