@@ -141,6 +141,7 @@ SYMBOLS = [
     ("crgpu_dev_agg_consume", _I32, [_VP, C.POINTER(DCol), _I64]),
     ("crgpu_dev_agg_finish", _I32, [_VP, C.POINTER(DevResult)]),
     ("crgpu_dev_agg_emit_ready", _I32, [_VP, C.POINTER(DevResult)]),
+    ("crgpu_dev_agg_pending_rows", _I32, [_VP, C.POINTER(C.c_int64)]),
     ("crgpu_dev_agg_reset", _I32, [_VP]),
     ("crgpu_dev_agg_destroy", None, [_VP]),
     ("crgpu_dev_partitioner_create", _I32, [C.POINTER(_I32), _I32, C.POINTER(_I32), _I32, _U64, _I32, C.POINTER(_VP)]),

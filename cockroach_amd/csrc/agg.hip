@@ -5148,43 +5148,47 @@ __global__ __launch_bounds__(256) void ord_last_change_kernel(const uint64_t *__
   }
   if ((threadIdx.x & 63) == 0 && mine >= 0) atomicMax(last, mine);
 }
+// (grid_for caps the grid: every kernel below walks its rows with a grid-stride loop)
 __global__ __launch_bounds__(256) void ord_iota_kernel(long long base, int64_t n, long long *__restrict__ out) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = base + i;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = base + i;
 }
 // dst bit j = src bit (bit_off + j), j < n (dst bytes beyond are zero-filled up to the last one written)
 __global__ __launch_bounds__(256) void ord_bitmap_shift_kernel(const uint8_t *__restrict__ src, int64_t bit_off, int64_t n, uint8_t *__restrict__ dst) {
-  const int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
   const int64_t nbytes = (n + 7) >> 3;
-  if (j >= nbytes) return;
-  const int64_t b0 = (bit_off >> 3) + j;
   const int s = static_cast<int>(bit_off & 7);
   const int64_t last_src = (bit_off + n - 1) >> 3;
-  unsigned v = src[b0] >> s;
-  if (s != 0 && b0 + 1 <= last_src) v |= static_cast<unsigned>(src[b0 + 1]) << (8 - s);
-  dst[j] = static_cast<uint8_t>(v);
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; j < nbytes; j += stride) {
+    const int64_t b0 = (bit_off >> 3) + j;
+    unsigned v = src[b0] >> s;
+    if (s != 0 && b0 + 1 <= last_src) v |= static_cast<unsigned>(src[b0 + 1]) << (8 - s);
+    dst[j] = static_cast<uint8_t>(v);
+  }
 }
 __global__ __launch_bounds__(256) void ord_mark_kernel(const long long *__restrict__ first, int64_t ng, int64_t span, uint8_t *__restrict__ flags,
                                                        unsigned int *__restrict__ bad) {
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g >= ng) return;
-  const long long r = first[g];
-  if (r < 0 || r >= span) { atomicOr(bad, 1u); return; }
-  flags[r] = 1;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ng; g += stride) {
+    const long long r = first[g];
+    if (r < 0 || r >= span) atomicOr(bad, 1u);
+    else flags[r] = 1;
+  }
 }
 // pos[0..ng) = the marked row numbers in ascending order; group g goes to the place of its first row
 __global__ __launch_bounds__(256) void ord_rank_kernel(const long long *__restrict__ first, const int32_t *__restrict__ pos, int64_t ng,
                                                        int32_t *__restrict__ perm) {
-  const int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (g >= ng) return;
-  const int32_t want = static_cast<int32_t>(first[g]);
-  int64_t lo = 0, hi = ng - 1;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (pos[mid] < want) lo = mid + 1;
-    else hi = mid;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < ng; g += stride) {
+    const int32_t want = static_cast<int32_t>(first[g]);
+    int64_t lo = 0, hi = ng - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (pos[mid] < want) lo = mid + 1;
+      else hi = mid;
+    }
+    perm[lo] = static_cast<int32_t>(g);
   }
-  perm[lo] = static_cast<int32_t>(g);
 }
 
 static constexpr int64_t kOrdSlice = int64_t(1) << 27;             // rows hashed / split per step (a multiple of 8)
@@ -5423,3 +5427,13 @@ extern "C" crgpu_status crgpu_dev_agg_emit_ready(crgpu_agg *a, crgpu_dev_result 
   if (s_ == CRGPU_OK) note_rows(a, 0, res->n);
   return s_;
 }
+
+// Rows consumed so far whose groups have not been handed out: with ordered grouping columns the rows behind the last
+// flush (the reference's hash aggregator drops exactly the others from its input tracking when it has emitted a run's
+// groups: resetBucketsAndTrackingState, hash_aggregator_tmpl.go:355-378); without, every row since the last reset.
+extern "C" crgpu_status crgpu_dev_agg_pending_rows(crgpu_agg *a, int64_t *rows) {
+  if (a == nullptr || rows == nullptr) return fail(CRGPU_ERR_INVALID, "crgpu_dev_agg_pending_rows: null argument");
+  *rows = a->ord ? a->ord->rows_since_flush : static_cast<int64_t>(a->seq);
+  return CRGPU_OK;
+}
+

@@ -477,6 +477,27 @@ static void append_cols(std::vector<HostCol> &dst, const std::vector<HostCol> &s
   }
 }
 
+// drop all but the newest `keep` rows
+static void keep_newest(std::vector<HostCol> &cols, int64_t keep) {
+  for (HostCol &c : cols) {
+    if (keep >= c.n) continue;
+    const int64_t drop = c.n - keep;
+    if (c.type == CRGPU_BYTES) {
+      const uint32_t base = c.offsets[static_cast<size_t>(drop)];
+      c.data.erase(c.data.begin(), c.data.begin() + base);
+      c.offsets.erase(c.offsets.begin(), c.offsets.begin() + drop);
+      for (auto &o : c.offsets) o -= base;
+    } else {
+      c.data.erase(c.data.begin(), c.data.begin() + static_cast<size_t>(drop) * type_width(c.type));
+    }
+    if (!c.present.empty()) {
+      const size_t d = std::min(c.present.size(), static_cast<size_t>(drop));
+      c.present.erase(c.present.begin(), c.present.begin() + d);
+    }
+    c.n = keep;
+  }
+}
+
 static void init_cols(std::vector<HostCol> &cols, const std::vector<int> &types) {
   cols.resize(types.size());
   for (size_t i = 0; i < types.size(); i++) cols[i].init(types[i]);
@@ -780,6 +801,13 @@ static crgpu_status ha_flush(crgpu_ha *h) {
   st = crgpu_dev_agg_consume(h->dev, h->staged_dev.cols.data(), n);
   clear_cols(h->stage);  // (tracked rows keep the batch when tracking is on)
   if (st == CRGPU_OK && h->ordered) st = ha_pull_ready(h);
+  if (st == CRGPU_OK && h->ordered && h->track) {
+    // the groups of completed runs are out: only the rows behind the last change of the ordered columns are still
+    // needed for ExportBuffered (hashAggregator.resetBucketsAndTrackingState, hash_aggregator_tmpl.go:355-378)
+    int64_t pending = 0;
+    st = crgpu_dev_agg_pending_rows(h->dev, &pending);
+    if (st == CRGPU_OK) keep_newest(h->tracked, pending);
+  }
   return st;
 }
 
@@ -841,6 +869,13 @@ extern "C" crgpu_status crgpu_agg_append(crgpu_ha *h, const crgpu_batch *in) {
   if (h->types.empty()) {
     // no input columns at all (COUNT_ROWS only): nothing to stage but the row count matters
     return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_agg_append: aggregation without input columns");
+  }
+  // Ordered grouping columns: completed groups are read (crgpu_agg_next_output) before more input goes in, as the
+  // reference's state machine does (hashAggregatorOutputting runs dry before hashAggregatorBuffering resumes); the
+  // tracked input can then never hold rows of groups that were queued for output but not handed out.
+  if (h->ordered) {
+    while (!h->outq.empty() && h->outq.front()->cursor >= h->outq.front()->n) h->outq.pop_front();
+    if (!h->outq.empty()) return fail(CRGPU_ERR_STATE, "crgpu_agg_append: ordered aggregation has completed groups to read first (crgpu_agg_next_output until length 0)");
   }
   CRGPU_TRY(stage_batch(h->stage, in));
   if (h->stage[0].n >= kFlushRows) CRGPU_TRY(ha_flush(h));

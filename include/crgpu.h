@@ -247,6 +247,11 @@ crgpu_status crgpu_dev_agg_finish(crgpu_agg *a, crgpu_dev_result *out);
  * calls crgpu_dev_agg_emit_ready until out->n == 0.  Without ordered columns every call returns n == 0.  Limits: no
  * computed columns; at most 2^31 rows between two changes of the ordered columns (CRGPU_ERR_UNSUPPORTED). */
 crgpu_status crgpu_dev_agg_emit_ready(crgpu_agg *a, crgpu_dev_result *out);
+/* Rows consumed so far whose groups have not been handed out yet: with ordered grouping columns the rows behind the last
+ * completed run (the reference's aggregator drops the others from its input tracking once a run's groups are emitted:
+ * resetBucketsAndTrackingState, hash_aggregator_tmpl.go:355-378 -- a shell that keeps the input for ExportBuffered
+ * keeps this many of the newest rows); without ordered columns every row since the last reset. */
+crgpu_status crgpu_dev_agg_pending_rows(crgpu_agg *a, int64_t *rows);
 crgpu_status crgpu_dev_agg_reset(crgpu_agg *a);
 void crgpu_dev_agg_destroy(crgpu_agg *a);
 

@@ -191,3 +191,73 @@ def test_ordered_agg_spec_errors():
     assert a.emit_ready().n == 0
     assert a.finish().n == 10
     a.close()
+
+
+def test_ordered_agg_input_tracking_drops_emitted_runs(oracle):
+    """Planned under a disk spiller (crgpu_agg_track_input) the shell keeps the input for ExportBuffered; with ordered
+    grouping columns the reference drops the tuples of a run from that tracking once the run's groups have been emitted
+    (resetBucketsAndTrackingState, hash_aggregator_tmpl.go:355-378).  Here: 1.3 M rows in runs of 1000; after the first
+    device round trip (2^20 staged rows) the completed runs' groups are read, then ExportBuffered must hand out exactly
+    the rows that belong to no emitted group -- a contiguous tail of what was appended -- and emitted groups + the
+    aggregation of that tail must be the aggregation of everything appended.  Appending while completed groups are
+    unread is a state error."""
+    import ctypes as C
+    from tests.test_gpu_operators import _export_all
+    rng = np.random.default_rng(77)
+    n, bs = 1_300_000, 4096
+    o0 = cd.Vec.from_numpy(cd.INT64, (np.arange(n) // 1000).astype(np.int64))
+    g = cd.Vec.from_numpy(cd.INT32, rng.integers(0, 3, size=n).astype(np.int32))
+    x = cd.Vec.from_numpy(cd.INT64, rng.integers(-1000, 1000, size=n, dtype=np.int64))
+    cols, types = [o0, g, x], [cd.INT64, cd.INT32, cd.INT64]
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["ANY_NOT_NULL"], 1, -1), (F["SUM_INT"], 2, -1), (F["COUNT_ROWS"], -1, -1)]
+    batches = [cd.Batch([v.slice(s, min(n, s + bs)) for v in cols], min(n, s + bs) - s) for s in range(0, n, bs)]
+    ha = ops.HashAggregator(types, [0, 1], aggs, ops.BatchSource(batches, types), capacity=1024, track_input=True, ordered_cols=[0])
+    ha.init()
+    fed = 0
+    emitted = []
+    for b in batches:
+        mb, _keep = ops._marshal_batch(b)
+        _lib.check(ha.lib.crgpu_agg_append(ha.h, C.byref(mb)))
+        fed += b.length
+        out = ha.out.call(ha.lib.crgpu_agg_next_output, ha.h)
+        if out.length > 0:  # the first device round trip has happened: completed runs are ready
+            emitted += H.vecs_to_tuples(out.cols, out.length)
+            nxt = batches[fed // bs]
+            mb2, _k2 = ops._marshal_batch(nxt)
+            with pytest.raises(_lib.CrgpuError) as e:
+                _lib.check(ha.lib.crgpu_agg_append(ha.h, C.byref(mb2)))
+            assert e.value.code == _lib.ERR_STATE
+            while True:
+                out = ha.out.call(ha.lib.crgpu_agg_next_output, ha.h)
+                if out.length == 0:
+                    break
+                emitted += H.vecs_to_tuples(out.cols, out.length)
+            break
+    assert emitted and fed >= (1 << 20)
+    ha.release_before_export()
+    tail = _export_all(ha)
+    all_rows = H.vecs_to_tuples(cols)
+    assert 0 < len(tail) < 5000, "only the rows behind the last completed run are still tracked"
+    assert tail == all_rows[fed - len(tail):fed]
+    assert max(r[0] for r in emitted) < min(r[0] for r in tail)
+    tail_cols = [v.slice(fed - len(tail), fed) for v in cols]
+    rest = H.vecs_to_tuples(oracle.hash_agg(tail_cols, [0, 1], aggs)) if tail else []
+    want = H.vecs_to_tuples(oracle.hash_agg([v.slice(0, fed) for v in cols], [0, 1], aggs))
+    H.assert_same_multiset(emitted + rest, want, "emitted groups + aggregation of the exported tail")
+    ha.release_after_export()
+    ha.close()
+
+
+def test_ordered_agg_large_single_call(oracle):
+    """1.5 M rows in ONE call, runs of two rows: 750 000 groups in one piece -- more rows and more groups than a capped
+    launch grid has threads, NULLs in the value column so that the second sub-batch needs a shifted validity bitmap."""
+    rng = np.random.default_rng(12)
+    n = 1_500_001
+    o0 = cd.Vec.from_numpy(cd.INT64, (np.arange(n) // 2).astype(np.int64) * 5 - 3)
+    x = cd.Vec.from_numpy(cd.INT64, rng.integers(-50, 50, size=n, dtype=np.int64), rng.random(n) > 0.2)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT"], 1, -1), (F["COUNT_ROWS"], -1, -1)]
+    want = H.vecs_to_tuples(oracle.hash_agg([o0, x], [0], aggs))
+    want.sort(key=lambda r: r[0])
+    rows, early = run_ordered([o0, x], [0], [0], aggs, [0, n])
+    assert rows == want  # (one group per run: the partial order is a total order here)
+    assert early == len(rows) - 1
