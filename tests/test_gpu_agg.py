@@ -993,3 +993,28 @@ def test_distinct_aggregations_vs_oracle(oracle, xtype, ngroups):
         H.assert_same_multiset(got, H.vecs_to_tuples(oracle.hash_agg([v.take(np.arange(0, 5000)) for v in cols], [0], aggs)))
     finally:
         a.close()
+
+
+def test_distinct_aggregations_three_million_rows(oracle):
+    """The DISTINCT composition beyond the size of a capped launch grid: 3 M rows in one call, 1000 groups, COUNT and
+    SUM_INT DISTINCT with a FILTER, against numpy."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(88)
+    n = 3_000_017
+    g = rng.integers(0, 1000, n, dtype=np.int64)
+    x = rng.integers(0, 500, n, dtype=np.int64)
+    f = rng.integers(0, 2, n).astype(np.uint8)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["COUNT"], 1, -1, True), (F["SUM_INT"], 1, 2, True), (F["COUNT_ROWS"], -1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64, cd.BOOL], [0], aggs)
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, g)), dev.upload(cd.Vec.from_numpy(cd.INT64, x)), dev.upload(cd.Vec.from_numpy(cd.BOOL, f))], n)
+    got = {r[0]: r[1:] for r in H.vecs_to_tuples(dev.result_to_vecs(a.finish()))}
+    a.close()
+    assert len(got) == 1000
+    pairs = np.unique(np.stack([g, x], 1), axis=0)
+    cnt = np.bincount(pairs[:, 0], minlength=1000)
+    fp = np.unique(np.stack([g[f != 0], x[f != 0]], 1), axis=0)
+    fsum = np.bincount(fp[:, 0], weights=fp[:, 1], minlength=1000)
+    rows = np.bincount(g, minlength=1000)
+    for k in range(1000):
+        assert got[k] == (int(cnt[k]), int(fsum[k]), int(rows[k])), k
+
