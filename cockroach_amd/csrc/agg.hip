@@ -3036,6 +3036,7 @@ struct crgpu_agg : crgpu::Handle {
   RadixTable radix;
   bool index_valid = true;
   bool dense16 = false;  // every group came from the wide bulk path with a 16-byte key: group g's key is b_buf[16 g, 16 g + 16)
+  bool try_voided = false;      // a piece of this input voided its all-distinct attempt: the later pieces (same keys' distribution) skip theirs
   bool one_row_groups = false;  // every group is ONE input row (the all-distinct bulk attempt succeeded and nothing followed): an
                                 // integer sum cannot have left the int64 range, finish skips the pass that checks
   DevBuf bulk_count;
@@ -4650,7 +4651,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   static const bool try_on = getenv("CRGPU_BULK_TRY") == nullptr || getenv("CRGPU_BULK_TRY")[0] != '0';
   bool tried_ok = false;
   unsigned int try_groups = 0;
-  if (sub_form && try_on && distinct == kBigSample) {
+  if (sub_form && try_on && distinct == kBigSample && !(append && a->try_voided)) {
     CRGPU_TRY(a->p_offsets.ensure(static_cast<size_t>(nregions + 1) * 8));
     CRGPU_TRY(a->p_flags.ensure(256));
     CRGPU_HIP(hipMemsetAsync(a->p_flags.p, 0, 256, st));
@@ -4673,6 +4674,8 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     if (failed_try == 0) {  // every region held distinct keys: group ids 0 .. rows - 1 are written
       tried_ok = true;
       try_groups = static_cast<unsigned int>(total_rows);
+    } else {
+      a->try_voided = true;
     }
   }
   if (!tried_ok) {
@@ -4756,6 +4759,7 @@ static crgpu_status try_bulk_huge(crgpu_agg *a, const std::vector<DCol> &cols, i
   std::vector<int64_t> counts(static_cast<size_t>(pieces), 0);
   crgpu_dev_result pr;
   CRGPU_TRY(crgpu_dev_partition(part, pcols.data(), n, &pr, counts.data()));
+  a->try_voided = false;
   // (one allocation, not one per piece; a piece's rows are written before its groups are counted, so room for one
   // piece beyond the 2^29 groups a table may hold)
   const int64_t room = (int64_t(1) << 29) + (int64_t(1) << 27);
