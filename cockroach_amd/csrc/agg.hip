@@ -1950,6 +1950,7 @@ static constexpr uint32_t kBulkRows = 2048;   // rows per tile = rows a sub-part
                                               // kernel 1.5x slower: 8 rows per thread and twice the region traffic)
 static constexpr uint32_t kBulkSubSlots = 2048;   // sub form: LDS index slots / groups a sub-partition may hold
 static constexpr uint32_t kBulkSubGroups = 1536;
+static constexpr uint32_t kBulkSlimGroups = 1280;  // groups a region may hold in the slim form of the general pass
 struct BulkArgs {
   const void *rows;             // {key, value} rows of 16 bytes, or (WIDE) {k0, k1, value, length} rows of 32 bytes
   const uint32_t *starts;       // part form: first row of region q (nullptr: q * kBulkRows)
@@ -2052,7 +2053,12 @@ struct BulkRow<true> {
 // and THREADS < 1024, so many regions are in flight per CU.  A region with a repeated key raises *try_failed and the
 // whole attempt is void (its writes are overwritten by the general form, which then runs over every region); regions
 // that start after the flag is up exit at once.
-template <bool WIDE, int THREADS, bool TRY>
+// SLIM (the sub form's general pass: one tile per region): no slot -> group and group -> row arrays in LDS -- after the
+// insert phase a slot's entry is overwritten with its group's local number (the claimant's row number is only needed
+// while rows are compared) and the claimants store their groups' keys from registers -- so that the planes for 1280
+// groups, the index and the seen bytes fit 44 KiB: three 512-thread workgroups per CU instead of two of 1024 threads
+// (16-bit index entries, which make room for a fourth, gain nothing: 2.56 against 2.51 ms on config G's 4 x input).
+template <bool WIDE, int THREADS, bool TRY, bool SLIM = false>
 __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   typedef BulkRow<WIDE> R;
   typedef typename R::T Row;
@@ -2065,7 +2071,7 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   uint32_t *idx = TRY ? reinterpret_cast<uint32_t *>(lds_words) : reinterpret_cast<uint32_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
   uint32_t *lid = idx + a.slots;
   uint32_t *rep = lid + a.slots;
-  uint8_t *lds_seen = reinterpret_cast<uint8_t *>(rep + a.gmax);
+  uint8_t *lds_seen = SLIM ? reinterpret_cast<uint8_t *>(idx + a.slots) : reinterpret_cast<uint8_t *>(rep + a.gmax);
   const int q = blockIdx.x;
   // TRY: the first ~1024 rows of the region (what a region holds on average; its capacity is kBulkRows) are requested
   // before the row count is known, and the flag and the region's first group id with them: one memory latency in
@@ -2105,16 +2111,20 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   if (threadIdx.x == 0) s_claims = 0;
   __syncthreads();
   constexpr int kRows = kBulkRows / THREADS;  // rows per thread and tile
+  Row keep_rr[SLIM ? kRows : 1];        // SLIM: the claimants' rows and local group numbers, for the key stores at the end
+  uint32_t keep_l[SLIM ? kRows : 1];
   for (uint32_t t0 = 0; t0 < n; t0 += kBulkRows) {
     // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key); the claimant
     //    numbers the group
     uint32_t slot_of[kRows];
+    uint32_t my_l[kRows];  // SLIM: the local group number a claimant gave its group (kNone: not a claimant)
     unsigned long long val[kRows], val2[kRows];
     Row rr[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
       const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
       slot_of[k] = kNone;
+      my_l[k] = kNone;
       val[k] = 0;
       val2[k] = 0;
       bool claimed = false;
@@ -2153,8 +2163,12 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
         wb = __shfl(wb, lead, 64);
         if (!TRY && claimed) {
           const uint32_t l = wb + rank_in_mask(cm);
-          lid[slot_of[k]] = l;  // read after the barrier below
-          if (l < a.gmax) rep[l] = i;
+          if (SLIM) {
+            my_l[k] = l;
+          } else {
+            lid[slot_of[k]] = l;  // read after the barrier below
+            if (l < a.gmax) rep[l] = i;
+          }
         }
       }
     }
@@ -2204,8 +2218,15 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
       }
       return;
     }
+    if (SLIM) {  // every compare is done: the claimants' slots now name their groups
+#pragma unroll
+      for (int k = 0; k < kRows; k++)
+        if (my_l[k] != kNone) idx[slot_of[k]] = my_l[k];
+    }
     if (single) {
       init_planes();
+      __syncthreads();
+    } else if (SLIM) {
       __syncthreads();
     }
     // 2. accumulate in LDS (apply_rows_lds: straight-line updates; rows past the end go to the trash group)
@@ -2214,7 +2235,7 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
     uint32_t takem = 0;
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
-      gr[k] = slot_of[k] != kNone ? lid[slot_of[k]] : a.gmax;
+      gr[k] = slot_of[k] != kNone ? (SLIM ? idx[slot_of[k]] : lid[slot_of[k]]) : a.gmax;
       if (gr[k] > a.gmax) gr[k] = a.gmax;  // only while a faster wave has already overflowed the planes (attempt abandoned)
       rowi[k] = 0;
       takem |= (slot_of[k] != kNone ? 1u : 0u) << k;
@@ -2229,6 +2250,13 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
     }
     // no barrier needed before the next tile's inserts: they touch idx / lid / rep / s_claims, the updates above touch
     // the planes; lid entries read above were written before the barrier and are never rewritten
+    if (SLIM) {
+#pragma unroll
+      for (int k = 0; k < kRows; k++) {
+        keep_rr[SLIM ? k : 0] = rr[k];
+        keep_l[SLIM ? k : 0] = my_l[k];
+      }
+    }
   }
   __syncthreads();
   if (s_claims > a.gmax) {  // a wave that was ahead overflowed after the others had passed the check above
@@ -2240,9 +2268,14 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   if (threadIdx.x == 0) s_base = atomicAdd(a.ngroups, ngrp);
   __syncthreads();
   const uint32_t base = a.g0 + s_base;
+  if (SLIM) {  // (one tile: the claimants still hold their rows; consecutive claimants of a wave own consecutive groups)
+#pragma unroll
+    for (int k = 0; k < kRows; k++)
+      if (keep_l[SLIM ? k : 0] != kNone) R::store_key(a, base + keep_l[SLIM ? k : 0], keep_rr[SLIM ? k : 0]);
+  }
   for (uint32_t l = threadIdx.x; l < ngrp; l += blockDim.x) {
     const uint32_t gid = base + l;
-    R::store_key(a, gid, rows[rep[l]]);
+    if (!SLIM) R::store_key(a, gid, rows[rep[l]]);
     for (int f = 0; f < a.naggs; f++) {
       const OpK &op = a.ops[f];
       op.w0[gid] = lds_words[static_cast<size_t>(op.lw0) * plane + l];
@@ -4392,6 +4425,43 @@ __global__ void agg_sample_keys_kernel(const long long *__restrict__ keys, int64
   if (i < nsample) out[i] = keys[static_cast<int64_t>(i) * stride];
 }
 
+// Does a larger sample (65536 keys at a fixed stride) hold a repeated key?  The 8192-key sample that picks the form
+// cannot tell "every key 2-4 times" from "all distinct" (0.2-0.8 expected pairs in 2^27 rows); this one has tens of
+// pairs then, so the all-distinct attempt is only made when it will stand.  Keys are inserted into a 2^17-slot table
+// in global memory with a CAS each; `wide`: 64-bit hashes of the keys are used (a collision only costs the attempt).
+static constexpr int kDupSample = 1 << 16;
+__global__ __launch_bounds__(256) void agg_sample_dups_kernel(DCol key, DCol key2, int wide, int64_t stride, unsigned long long *__restrict__ table,
+                                                              unsigned int *__restrict__ dups) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kDupSample) return;
+  const int64_t r = static_cast<int64_t>(i) * stride;
+  unsigned long long k;
+  if (!wide) {
+    k = static_cast<unsigned long long>(static_cast<const long long *>(key.data)[r]);
+  } else if (key.type != CRGPU_BYTES) {
+    const uint64_t k1 = key2.data != nullptr ? static_cast<uint64_t>(col_get_int(key2, r)) : 0ull;
+    k = fmix64(hash_step(hash_step(0x9E3779B97F4A7C15ull, static_cast<uint64_t>(col_get_int(key, r))), k1));
+  } else {
+    const uint32_t b = key.offsets[r], len = key.offsets[r + 1] - b;
+    uint64_t h = 0x9E3779B97F4A7C15ull + len;
+    const uint8_t *p = static_cast<const uint8_t *>(key.data) + b;
+    for (uint32_t j = 0; j < len && j < 64; j++) h = hash_step(h, p[j]);
+    k = fmix64(h);
+  }
+  constexpr unsigned long long kEmpty = ~0ull;
+  if (k == kEmpty) return;
+  uint32_t sl = static_cast<uint32_t>(fmix64(k ^ 0xD6E8FEB86659FD93ull)) & (2 * kDupSample - 1);
+  for (int probes = 0; probes < 2 * kDupSample; probes++) {
+    const unsigned long long old = atomicCAS(&table[sl], kEmpty, k);
+    if (old == kEmpty) return;
+    if (old == k) {
+      atomicAdd(dups, 1u);
+      return;
+    }
+    sl = (sl + 1) & (2 * kDupSample - 1);
+  }
+}
+
 // BYTES keys: the sample holds a 64-bit hash of each sampled key; out[nsample] is set when a sampled key is longer than
 // the 16 bytes a wide row holds
 __global__ void agg_sample_wide_kernel(DCol key, DCol key2, int64_t stride, int nsample, long long *__restrict__ out) {
@@ -4651,7 +4721,21 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   static const bool try_on = getenv("CRGPU_BULK_TRY") == nullptr || getenv("CRGPU_BULK_TRY")[0] != '0';
   bool tried_ok = false;
   unsigned int try_groups = 0;
-  if (sub_form && try_on && distinct == kBigSample && !(append && a->try_voided)) {
+  bool try_it = sub_form && try_on && distinct == kBigSample && !(append && a->try_voided);
+  if (try_it && n >= 4 * static_cast<int64_t>(kDupSample)) {
+    CRGPU_TRY(a->p_gid.ensure(static_cast<size_t>(2 * kDupSample) * 8 + 16));
+    CRGPU_HIP(hipMemsetAsync(a->p_gid.p, 0xFF, static_cast<size_t>(2 * kDupSample) * 8, st));
+    unsigned int *dups_dev = reinterpret_cast<unsigned int *>(a->p_gid.as<unsigned long long>() + 2 * kDupSample);
+    CRGPU_HIP(hipMemsetAsync(dups_dev, 0, 4, st));
+    hipLaunchKernelGGL(agg_sample_dups_kernel, dim3(kDupSample / 256), dim3(256), 0, st, key, key2, wide ? 1 : 0, n / kDupSample,
+                       a->p_gid.as<unsigned long long>(), dups_dev);
+    CRGPU_HIP(hipGetLastError());
+    unsigned int dups = 0;
+    CRGPU_HIP(hipMemcpyAsync(&dups, dups_dev, 4, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipStreamSynchronize(st));
+    if (dups != 0) try_it = false;
+  }
+  if (try_it) {
     CRGPU_TRY(a->p_offsets.ensure(static_cast<size_t>(nregions + 1) * 8));
     CRGPU_TRY(a->p_flags.ensure(256));
     CRGPU_HIP(hipMemsetAsync(a->p_flags.p, 0, 256, st));
@@ -4680,7 +4764,18 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   }
   if (!tried_ok) {
     ProfScope prof(sub_form ? "agg_bulk" : "agg_bulk_part");
-    if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, 1024, false>), dim3(nregions), dim3(1024), lds, st, b);
+    static const bool slim_on = getenv("CRGPU_BULK_SLIM") == nullptr || getenv("CRGPU_BULK_SLIM")[0] != '0';
+    // the slim form's LDS: planes for kBulkSlimGroups groups (mean 1024 + 8 sigma for distinct keys: a region with more
+    // abandons the attempt, as one beyond gmax does in the other form), a 2048-slot index, the seen bytes
+    const size_t slim_lds = (static_cast<size_t>(a->lds_words) * 8 * (kBulkSlimGroups + 1) + kBulkSubSlots * 4 +
+                             static_cast<size_t>(a->lds_seen) * (kBulkSlimGroups + 1) + 15) & ~size_t(15);
+    if (sub_form && slim_on && slim_lds <= 52 * 1024) {
+      BulkArgs bs = b;
+      bs.gmax = kBulkSlimGroups;
+      bs.slots = kBulkSubSlots;
+      if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, 512, false, true>), dim3(nregions), dim3(512), slim_lds, st, bs);
+      else hipLaunchKernelGGL((agg_bulk_kernel<false, 512, false, true>), dim3(nregions), dim3(512), slim_lds, st, bs);
+    } else if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, 1024, false>), dim3(nregions), dim3(1024), lds, st, b);
     else hipLaunchKernelGGL((agg_bulk_kernel<false, 1024, false>), dim3(nregions), dim3(1024), lds, st, b);
     CRGPU_HIP(hipGetLastError());
   }
