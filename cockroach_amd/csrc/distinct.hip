@@ -103,54 +103,109 @@ struct DResolveArgs {
   uint8_t *flags;     // [n] preset for rows that bypass the table
   unsigned long long *gword;  // [base + i] hash word of every row (kDEmpty: never indexed); see the mark kernel
 };
-__global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < a.n; i += stride) {
-    const DHash h = distinct_hash(a.keys, i);
-    uint32_t slot = kDNone;
-    uint8_t flag = 0;
-    unsigned long long word = (static_cast<unsigned long long>(h.upper) << 32) | h.idx;
-    if (a.nulls_are_distinct && (h.upper & 0xFFu) != 0) {
-      flag = 1;  // never equal to anything, never looked up
-      word = kDEmpty;
-    } else {
-      const uint32_t me = a.base + static_cast<uint32_t>(i);
-      const unsigned long long claim = (static_cast<unsigned long long>(h.upper) << 32) | me;
-      uint32_t idx = h.idx & a.mask;
-      for (;;) {  // ends: the index is at most half full (ensured by the host before the launch)
-        unsigned long long e = __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (e == kDEmpty) e = atomicCAS(&a.meta[idx], kDEmpty, claim);
-        if (e == kDEmpty) {
-          slot = idx;
-          break;
-        }
-        const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
-        if (up == h.upper) {
-          if (lo >= a.base) {  // claimed in this batch
-            if (keys_equal(a.keys, i, a.keys, static_cast<int64_t>(lo - a.base), true)) {
-              // same upper word: the smallest position wins.  An entry only ever decreases, so a row behind the
-              // position it just read has nothing to do (with few distinct keys nearly every row: without this test
-              // 2^27 rows over 1024 keys took 26.7 ms in contended atomics)
-              if (me < lo) {
-                atomicMin(&a.meta[idx], claim);
-                slot = idx;
-              } else {
-                slot = kDLost;
-                word = kDEmpty;
-              }
-              break;
-            }
-          } else if (row_equals_store(a.keys, i, a.store, lo, h.upper & 0xFFu)) {
-            word = kDEmpty;
-            break;  // seen in an earlier batch
-          }
-        }
-        idx = (idx + 1) & a.mask;
+// one row through the index: see distinct_resolve_kernel
+__device__ __forceinline__ void distinct_resolve_row(const DResolveArgs &a, int64_t i, uint32_t *slot_out, uint8_t *flag_out,
+                                                     unsigned long long *word_out) {
+  const DHash h = distinct_hash(a.keys, i);
+  uint32_t slot = kDNone;
+  uint8_t flag = 0;
+  unsigned long long word = (static_cast<unsigned long long>(h.upper) << 32) | h.idx;
+  if (a.nulls_are_distinct && (h.upper & 0xFFu) != 0) {
+    flag = 1;  // never equal to anything, never looked up
+    word = kDEmpty;
+  } else {
+    const uint32_t me = a.base + static_cast<uint32_t>(i);
+    const unsigned long long claim = (static_cast<unsigned long long>(h.upper) << 32) | me;
+    uint32_t idx = h.idx & a.mask;
+    for (;;) {  // ends: the index is at most half full (ensured by the host before the launch)
+      unsigned long long e = __hip_atomic_load(&a.meta[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (e == kDEmpty) e = atomicCAS(&a.meta[idx], kDEmpty, claim);
+      if (e == kDEmpty) {
+        slot = idx;
+        break;
       }
+      const uint32_t up = static_cast<uint32_t>(e >> 32), lo = static_cast<uint32_t>(e);
+      if (up == h.upper) {
+        if (lo >= a.base) {  // claimed in this batch
+          if (keys_equal(a.keys, i, a.keys, static_cast<int64_t>(lo - a.base), true)) {
+            // same upper word: the smallest position wins.  An entry only ever decreases, so a row behind the
+            // position it just read has nothing to do (with few distinct keys nearly every row: without this test
+            // 2^27 rows over 1024 keys took 26.7 ms in contended atomics)
+            if (me < lo) {
+              atomicMin(&a.meta[idx], claim);
+              slot = idx;
+            } else {
+              slot = kDLost;
+              word = kDEmpty;
+            }
+            break;
+          }
+        } else if (row_equals_store(a.keys, i, a.store, lo, h.upper & 0xFFu)) {
+          word = kDEmpty;
+          break;  // seen in an earlier batch
+        }
+      }
+      idx = (idx + 1) & a.mask;
     }
-    if (a.write_words) a.gword[a.base + i] = word;
-    a.slot_of[i] = slot;
-    a.flags[i] = flag;
+  }
+  *slot_out = slot;
+  *flag_out = flag;
+  *word_out = word;
+}
+// LDSF (one INT64 distinct column without NULLs): the workgroup remembers in LDS the keys it has sent through the index.
+// It walks its tiles in ascending order, so a key it remembers from an EARLIER tile belongs to a smaller row: a row that
+// finds its key there cannot be a first occurrence and is dropped without touching the index (two dependent divergent
+// global loads and a compare).  With few distinct keys that is nearly every row and the pass becomes a stream over the
+// key column.  The table (2048 sets of two keys; a set's victim alternates with the tile) is read by the whole tile
+// before any of the tile's rows writes it: two barriers per 2048 rows.
+template <bool LDSF>
+__global__ __launch_bounds__(256) void distinct_resolve_kernel(DResolveArgs a) {
+  constexpr int RPT = LDSF ? 8 : 1, kTile = 256 * RPT, kSets = 2048;
+  constexpr unsigned long long kNoKey = 0x8000000000000001ull;  // (a row holding this very value is never remembered)
+  __shared__ ulonglong2 s_keys[LDSF ? kSets : 1];
+  if (LDSF) {
+    for (int j = threadIdx.x; j < kSets; j += 256) s_keys[j] = make_ulonglong2(kNoKey, kNoKey);
+    __syncthreads();
+  }
+  const int64_t ntiles = (a.n + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x, round = 0; tile < ntiles; tile += gridDim.x, round++) {
+    unsigned long long key[RPT];
+    bool drop[RPT];
+    if (LDSF) {
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const int64_t i = tile * kTile + k * 256 + threadIdx.x;
+        key[k] = i < a.n ? static_cast<const unsigned long long *>(a.keys.c[0].data)[i] : kNoKey;
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const ulonglong2 e = s_keys[static_cast<uint32_t>(fmix64(key[k])) & (kSets - 1)];
+        drop[k] = key[k] != kNoKey && (e.x == key[k] || e.y == key[k]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int64_t i = tile * kTile + k * 256 + threadIdx.x;
+      if (i >= a.n) continue;
+      uint32_t slot = kDLost;
+      uint8_t flag = 0;
+      unsigned long long word = kDEmpty;
+      if (!(LDSF && drop[k])) {
+        distinct_resolve_row(a, i, &slot, &flag, &word);
+        if (LDSF && key[k] != kNoKey) {
+          // (two rows of the tile may pick the same place: one of them is forgotten, which only costs a later lookup)
+          unsigned long long *set = reinterpret_cast<unsigned long long *>(&s_keys[static_cast<uint32_t>(fmix64(key[k])) & (kSets - 1)]);
+          const unsigned long long e0 = set[0], e1 = set[1];
+          const int way = (e0 == kNoKey || e0 == key[k]) ? 0 : (e1 == kNoKey || e1 == key[k]) ? 1 : static_cast<int>(round & 1);
+          set[way] = key[k];
+        }
+      }
+      if (a.write_words) a.gword[a.base + i] = word;
+      a.slot_of[i] = slot;
+      a.flags[i] = flag;
+    }
+    if (LDSF) __syncthreads();
   }
 }
 
@@ -606,7 +661,10 @@ static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crg
     a.flags = d->flags.as<uint8_t>();
     {
       ProfScope prof("distinct_resolve");
-      hipLaunchKernelGGL(distinct_resolve_kernel, dim3(dgrid(n)), dim3(256), 0, st, a);
+      static const bool ldsf_on = getenv("CRGPU_DISTINCT_LDS") == nullptr || getenv("CRGPU_DISTINCT_LDS")[0] != '0';
+      const bool ldsf = ldsf_on && a.keys.n == 1 && a.keys.c[0].type == CRGPU_INT64 && a.keys.c[0].valid == nullptr && n >= (int64_t(1) << 16);
+      if (ldsf) hipLaunchKernelGGL(distinct_resolve_kernel<true>, dim3(dgrid(n)), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(distinct_resolve_kernel<false>, dim3(dgrid(n)), dim3(256), 0, st, a);
       CRGPU_HIP(hipGetLastError());
       hipLaunchKernelGGL(distinct_mark_kernel, dim3(dgrid(n)), dim3(256), 0, st, d->meta.as<unsigned long long>(),
                          d->slot_of.as<uint32_t>(), n, d->ngroups, d->flags.as<uint8_t>(),

@@ -250,3 +250,20 @@ def test_distinct_bytes_keys_whole_batch_append_with_offset_base(oracle):
                 want_rows.append((v, p))
     d.close()
     assert got_rows == want_rows
+
+
+@pytest.mark.parametrize("nkeys", [30, 5000, 150_000])
+def test_distinct_lds_filter_vs_oracle(oracle, nkeys):
+    """One INT64 distinct column without NULLs, batches of >= 2^16 rows: the resolve kernel's LDS filter
+    (distinct.hip, distinct_resolve_kernel<LDSF>) drops rows whose key the workgroup has already sent through the index
+    in an earlier tile.  Output order and first occurrences against the oracle, in one call and in three (the later
+    calls meet keys of the store); the filter's own "no key" value is among the keys."""
+    rng = np.random.default_rng(nkeys)
+    n = 400_000
+    a = rng.integers(0, nkeys, size=n, dtype=np.int64) * 1_000_003 - 17
+    a[rng.integers(0, n, 50)] = np.int64(-0x7FFFFFFFFFFFFFFF)  # = 0x8000000000000001: never remembered, still distinct-ed
+    cols = [cd.Vec.from_numpy(cd.INT64, a), cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64))]
+    want, _ = oracle.unordered_distinct(cols, [0], False)
+    want = H.vecs_to_tuples(want)
+    for chunks in (1, 3):
+        ordered_equal(gpu_distinct(cols, [0], False, chunks), want, f"chunks={chunks}")
