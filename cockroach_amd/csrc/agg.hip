@@ -4645,6 +4645,17 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   }
   const size_t lds = (static_cast<size_t>(a->lds_words) * 8 * (gmax + 1) + slots * 8 + gmax * 4 +
                       static_cast<size_t>(a->lds_seen) * (gmax + 1) + 15) & ~size_t(15);
+  // sub form: one region per ~1024 rows, whatever the row count -- the kernel's time follows the number of regions (one
+  // workgroup each, bound by its chain of latencies), and a power-of-two count made an input just above 2^26 rows cost
+  // what 2^27 rows do
+  static const int64_t region_rows = getenv("CRGPU_BULK_REGION_ROWS") ? atoll(getenv("CRGPU_BULK_REGION_ROWS")) : 1024;
+  uint32_t any_nsub = 0;
+  if (sub_form && region_rows > 0) {
+    const int64_t per = static_cast<int64_t>(kRadixP1) * region_rows;
+    const int64_t want = (n + per - 1) / per;
+    any_nsub = static_cast<uint32_t>(want < 1 ? 1 : (want > 128 ? 128 : want));
+    if ((any_nsub & (any_nsub - 1)) == 0) any_nsub = 0;  // a power of two: the split by hash bits gives the same count
+  }
   RadixSrc src;
   std::memset(&src, 0, sizeof(src));
   src.kp.n = 1;
@@ -4660,12 +4671,12 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     ws.val = vcol >= 0 ? static_cast<const unsigned long long *>(cols[vcol].data) : nullptr;
     ws.val2 = two_vals ? static_cast<const unsigned long long *>(cols[vcol2].data) : nullptr;
     bool ok = false;
-    CRGPU_TRY(radix_partition_split_wide(a->radix, ws, n, &ok, kBulkRows, 10, 7));
+    CRGPU_TRY(radix_partition_split_wide(a->radix, ws, n, &ok, kBulkRows, 10, 7, any_nsub));
     if (!ok) return CRGPU_OK;  // a sub-partition overflowed, or a key is longer than 16 bytes
     if (key_type == CRGPU_BYTES) CRGPU_TRY(a->ks[0].b_buf.ensure(static_cast<size_t>(n) * 16 + 16));
   } else if (sub_form) {
     bool ok = false;
-    CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7));  // ~1024 rows per sub-partition
+    CRGPU_TRY(radix_partition_split(a->radix, src, n, &ok, kBulkRows, 10, 7, any_nsub));  // ~1024 rows per sub-partition
     if (!ok) return CRGPU_OK;  // a sub-partition overflowed: many rows per key after all
   } else {
     CRGPU_TRY(radix_partition_level1(a->radix, src, n));
@@ -4716,7 +4727,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.g0 = g0;
   b.gmax = static_cast<uint32_t>(gmax);
   b.slots = static_cast<uint32_t>(slots);
-  const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) << a->radix.sub_bits : static_cast<unsigned>(kRadixP1);
+  const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) * a->radix.nsub : static_cast<unsigned>(kRadixP1);
   // sub form, no repeated key among the 8192 sampled: first the all-distinct attempt (see agg_bulk_kernel)
   static const bool try_on = getenv("CRGPU_BULK_TRY") == nullptr || getenv("CRGPU_BULK_TRY")[0] != '0';
   bool tried_ok = false;

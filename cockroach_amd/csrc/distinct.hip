@@ -576,11 +576,15 @@ static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol>
   src.fast = (reinterpret_cast<uintptr_t>(key.data) & 15u) == 0 ? 1 : 0;
   if (sub_form) {
     bool ok = false;
-    CRGPU_TRY(radix_partition_split(d->radix, src, n, &ok, kDBulkRows, 10, 7));
+    // one region per ~1024 rows whatever the row count (the kernel's time follows the number of regions; see try_bulk in agg.hip)
+    int64_t want = (n + (int64_t(kRadixP1) << 10) - 1) / (int64_t(kRadixP1) << 10);
+    if (want > 128) want = 128;
+    if ((want & (want - 1)) == 0) want = 0;  // a power of two: the split by hash bits gives the same count
+    CRGPU_TRY(radix_partition_split(d->radix, src, n, &ok, kDBulkRows, 10, 7, static_cast<uint32_t>(want)));
     if (!ok) return CRGPU_OK;  // a region overflowed: many rows per key after all
     CRGPU_HIP(hipMemsetAsync(d->flags.p, 1, static_cast<size_t>(n), st));
     ProfScope prof("distinct_bulk");
-    hipLaunchKernelGGL(distinct_bulk_kernel, dim3(static_cast<unsigned>(kRadixP1) << d->radix.sub_bits), dim3(1024), 0, st,
+    hipLaunchKernelGGL(distinct_bulk_kernel, dim3(static_cast<unsigned>(kRadixP1) * d->radix.nsub), dim3(1024), 0, st,
                        d->radix.rows_b.as<ulonglong2>(), d->radix.sub_count.as<uint32_t>(), d->flags.as<uint8_t>());
     CRGPU_HIP(hipGetLastError());
   } else {

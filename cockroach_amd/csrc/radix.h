@@ -78,6 +78,7 @@ struct RadixTable {
   DevBuf pay_sorted;      // dup: the build payloads grouped by key, sub-partition by sub-partition
   DevBuf vals, counters;  // dup probe: every probe row's slot value (count pass -> emit pass); {output rows, rows seen}
   int sub_bits = 0;
+  uint32_t nsub = 1;  // sub-partitions per partition of the last split: 2^sub_bits, or the any_nsub it was asked for
   int64_t n = 0;
   DevBuf rows_a, rows_b;  // level-1 output; level-2 output (kRadixSubCap rows reserved per sub-partition)
   DevBuf table, special;  // kRadixSlots slots per sub-partition
@@ -97,8 +98,11 @@ crgpu_status radix_partition_level1(RadixTable &t, const RadixSrc &src, int64_t 
 // sub-partition q in [q * subcap, q * subcap + sub_count[q]), q < kRadixP1 << t.sub_bits.
 // *ok = false when a sub-partition overflowed its region of `subcap` rows.
 // About 2^log2_rows_per_sub rows per sub-partition, at most 2^max_sub_bits (<= 7) sub-partitions per partition.
+// any_nsub != 0: exactly that many sub-partitions per partition instead (any number up to 128, chosen by a multiply-shift
+// of hash bits the partition does not use; t.nsub says how many, q < kRadixP1 * t.nsub) -- for callers that never look a
+// sub-partition up by hash afterwards.
 crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,
-                                   int max_sub_bits);
+                                   int max_sub_bits, uint32_t any_nsub = 0);
 // Hash aggregation over a BYTES key column whose values are at most 16 bytes long -- or over two integer key columns --:
 // 32-byte rows {k0, k1, value, length} (the key's bytes little-endian in two zero-padded words) through the same two
 // partition levels.
@@ -114,7 +118,7 @@ __device__ __forceinline__ uint64_t wide_key_hash(uint64_t k0, uint64_t k1, uint
 }
 // (wmask: all ones when the fourth word belongs to the key -- the length --, zero when it carries a second value)
 crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64_t n, bool *ok, uint32_t subcap,
-                                        int log2_rows_per_sub, int max_sub_bits);
+                                        int log2_rows_per_sub, int max_sub_bits, uint32_t any_nsub = 0);
 // Builds the CSR table; *ok = false (and ready = false) when a sub-partition overflows
 // kRadixSubCap, i.e. the build keys are not (nearly) unique: the caller falls back.
 // check_dup: the table kernels also verify that the build keys are unique and report it in t.has_dup_keys (the join

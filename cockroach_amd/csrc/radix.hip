@@ -24,6 +24,9 @@ typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t rpart(uint64_t h) { return static_cast<uint32_t>(h >> 54); }
 __device__ __forceinline__ uint32_t rsub(uint64_t h, uint32_t smask) { return static_cast<uint32_t>(h >> 47) & smask; }
+// Sub-partition among ANY number of them (not only a power of two), from 32 hash bits below the partition's: the
+// aggregation's regions, which nothing probes by hash afterwards, so their number follows the row count
+__device__ __forceinline__ uint32_t rsub_any(uint64_t h, uint32_t nsub) { return __umulhi(static_cast<uint32_t>(h >> 16), nsub); }
 // The three candidate slots of a key inside its sub-partition's table (3-way cuckoo hashing):
 // 32-bit hash fields scaled to [0, kRadixSlots).
 __device__ __forceinline__ uint32_t rscale(uint32_t x) {
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(512) void radix_cell_prefix_kernel(const uint32_t *
 // sub-partition in LDS and written out as runs (~64 rows = 1 KiB per run, coalesced).
 // sub_count[p][s] = rows written; a region that would overflow raises the flag (the caller
 // falls back to the classic table) and the excess rows are dropped.
-template <bool DIRECT>
+template <bool DIRECT, bool ANY = false>
 __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__restrict__ in,
                                                            const uint32_t *__restrict__ starts,
                                                            const uint32_t *__restrict__ totals, uint32_t smask,
@@ -365,7 +368,8 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
       sp[j] = 0xFFFFFFFFu;
       if (i < n) {
         row[j] = in[s0 + i];
-        sp[j] = DIRECT ? static_cast<uint32_t>(row[j].x >> kRadixDirectBits) & smask : rsub(fmix64(row[j].x), smask);
+        sp[j] = DIRECT ? static_cast<uint32_t>(row[j].x >> kRadixDirectBits) & smask
+                       : (ANY ? rsub_any(fmix64(row[j].x), nsub) : rsub(fmix64(row[j].x), smask));
         rk[j] = atomicAdd(&tcnt[sp[j]], 1u);
       }
     }
@@ -386,7 +390,8 @@ __global__ __launch_bounds__(1024) void radix_split_kernel(const ulonglong2 *__r
     const uint32_t tile_rows = n - t0 < static_cast<uint32_t>(TILE) ? n - t0 : TILE;
     for (uint32_t i = threadIdx.x; i < tile_rows; i += THREADS) {
       const ulonglong2 r = stage[i];
-      const uint32_t s = DIRECT ? static_cast<uint32_t>(r.x >> kRadixDirectBits) & smask : rsub(fmix64(r.x), smask);
+      const uint32_t s = DIRECT ? static_cast<uint32_t>(r.x >> kRadixDirectBits) & smask
+                                : (ANY ? rsub_any(fmix64(r.x), nsub) : rsub(fmix64(r.x), smask));
       const uint32_t pos = cur[s] + (i - tstart[s]);
       if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
     }
@@ -545,6 +550,7 @@ __global__ __launch_bounds__(1024) void wide_scatter_kernel(WideSrc src, int64_t
 }
 
 // radix_split_kernel for 32-byte rows (tiles of 2048 rows: the same 64 KiB of staging)
+template <bool ANY>
 __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__restrict__ in, const uint32_t *__restrict__ starts,
                                                           const uint32_t *__restrict__ totals, uint32_t smask,
                                                           ulonglong4 *__restrict__ out, uint32_t *__restrict__ sub_count,
@@ -568,7 +574,8 @@ __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__re
       sp[j] = 0xFFFFFFFFu;
       if (i < n) {
         row[j] = in[s0 + i];
-        sp[j] = rsub(wide_key_hash(row[j].x, row[j].y, row[j].w & wmask), smask);
+        sp[j] = ANY ? rsub_any(wide_key_hash(row[j].x, row[j].y, row[j].w & wmask), nsub)
+                    : rsub(wide_key_hash(row[j].x, row[j].y, row[j].w & wmask), smask);
         rk[j] = atomicAdd(&tcnt[sp[j]], 1u);
       }
     }
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(1024) void wide_split_kernel(const ulonglong4 *__re
     const uint32_t tile_rows = n - t0 < static_cast<uint32_t>(TILE) ? n - t0 : TILE;
     for (uint32_t i = threadIdx.x; i < tile_rows; i += THREADS) {
       const ulonglong4 r = stage[i];
-      const uint32_t s = rsub(wide_key_hash(r.x, r.y, r.w & wmask), smask);
+      const uint32_t s = ANY ? rsub_any(wide_key_hash(r.x, r.y, r.w & wmask), nsub) : rsub(wide_key_hash(r.x, r.y, r.w & wmask), smask);
       const uint32_t pos = cur[s] + (i - tstart[s]);
       if (pos < subcap) obase[static_cast<int64_t>(s) * subcap + pos] = r;
     }
@@ -1733,7 +1740,7 @@ crgpu_status radix_partition_level1(RadixTable &t, const RadixSrc &src, int64_t 
 // Levels 1 and 2: t.rows_b holds the rows of sub-partition q in [q * subcap, q * subcap + sub_count[q]).
 // *ok = false when a sub-partition overflowed its region (too many rows share hash bits: duplicate-heavy input).
 crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n, bool *ok, uint32_t subcap, int log2_rows_per_sub,
-                                   int max_sub_bits) {
+                                   int max_sub_bits, uint32_t any_nsub) {
   hipStream_t st = stream();
   *ok = false;
   t.ready = false;
@@ -1745,8 +1752,10 @@ crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n
   if (sb > max_sub_bits) sb = max_sub_bits;
   const bool direct = src.direct.span != 0;
   if (direct) sb = static_cast<int>(src.direct.sub_bits);  // the key range decides, not the row count
-  t.sub_bits = sb;
-  const uint32_t nsub = 1u << sb;
+  if (any_nsub != 0 && (direct || any_nsub > 128u)) return fail(CRGPU_ERR_INVALID, "radix_partition_split: sub-partition count");
+  t.sub_bits = any_nsub != 0 ? 0 : sb;  // (any_nsub: nothing may derive the sub-partition from hash bits afterwards)
+  const uint32_t nsub = any_nsub != 0 ? any_nsub : 1u << sb;
+  t.nsub = nsub;
   CRGPU_TRY(radix_partition(src, n, t.hist, t.totals, t.starts, t.rows_a, 0, "radix_build_hist", "radix_build_scatter"));
   CRGPU_TRY(t.rows_b.ensure(static_cast<size_t>(kRadixP1) * nsub * subcap * 16));
   CRGPU_TRY(t.sub_count.ensure(static_cast<size_t>(kRadixP1) * nsub * 4));
@@ -1756,6 +1765,10 @@ crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n
     ProfScope prof("radix_build_split");
     if (direct)
       hipLaunchKernelGGL(radix_split_kernel<true>, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
+                         t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
+                         t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>(), subcap);
+    else if (any_nsub != 0)
+      hipLaunchKernelGGL((radix_split_kernel<false, true>), dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong2>(),
                          t.starts.as<uint32_t>(), t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong2>(),
                          t.sub_count.as<uint32_t>(), t.flag.as<uint32_t>(), subcap);
     else
@@ -1775,7 +1788,7 @@ crgpu_status radix_partition_split(RadixTable &t, const RadixSrc &src, int64_t n
 // sub-partition q in [q * subcap, q * subcap + sub_count[q]).  *ok = false when a sub-partition overflowed its region or
 // a key is longer than 16 bytes.
 crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64_t n, bool *ok, uint32_t subcap,
-                                        int log2_rows_per_sub, int max_sub_bits) {
+                                        int log2_rows_per_sub, int max_sub_bits, uint32_t any_nsub) {
   hipStream_t st = stream();
   *ok = false;
   t.ready = false;
@@ -1785,8 +1798,10 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
   int sb = lg - 10 - log2_rows_per_sub;
   if (sb < 0) sb = 0;
   if (sb > max_sub_bits) sb = max_sub_bits;
-  t.sub_bits = sb;
-  const uint32_t nsub = 1u << sb;
+  if (any_nsub > 128u) return fail(CRGPU_ERR_INVALID, "radix_partition_split_wide: sub-partition count");
+  t.sub_bits = any_nsub != 0 ? 0 : sb;
+  const uint32_t nsub = any_nsub != 0 ? any_nsub : 1u << sb;
+  t.nsub = nsub;
   int nchunks;
   int64_t chunk_rows;
   chunking(n, &nchunks, &chunk_rows);
@@ -1818,9 +1833,14 @@ crgpu_status radix_partition_split_wide(RadixTable &t, const WideSrc &src, int64
   }
   {
     ProfScope prof("radix_build_split");
-    hipLaunchKernelGGL(wide_split_kernel, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong4>(), t.starts.as<uint32_t>(),
-                       t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong4>(), t.sub_count.as<uint32_t>(),
-                       t.flag.as<uint32_t>(), subcap, src.val2 != nullptr ? 0ull : ~0ull);
+    if (any_nsub != 0)
+      hipLaunchKernelGGL(wide_split_kernel<true>, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong4>(), t.starts.as<uint32_t>(),
+                         t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong4>(), t.sub_count.as<uint32_t>(),
+                         t.flag.as<uint32_t>(), subcap, src.val2 != nullptr ? 0ull : ~0ull);
+    else
+      hipLaunchKernelGGL(wide_split_kernel<false>, dim3(kRadixP1), dim3(1024), 0, st, t.rows_a.as<ulonglong4>(), t.starts.as<uint32_t>(),
+                         t.totals.as<uint32_t>(), nsub - 1, t.rows_b.as<ulonglong4>(), t.sub_count.as<uint32_t>(),
+                         t.flag.as<uint32_t>(), subcap, src.val2 != nullptr ? 0ull : ~0ull);
     CRGPU_HIP(hipGetLastError());
   }
   uint32_t flag = 0;

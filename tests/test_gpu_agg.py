@@ -586,6 +586,31 @@ def test_agg_bulk_all_distinct_attempt_and_its_fallback(oracle, dups):
     a.close()
 
 
+@pytest.mark.parametrize("n,keys_per", [((1 << 23) + 1, 1), (10_000_000, 1), (3 * (1 << 22) + 777, 2), (11_111_111, 3)])
+def test_agg_bulk_region_count_follows_the_row_count(oracle, n, keys_per):
+    """The sub form splits every radix partition into ceil(n / 2^20) regions, any number of them (9, 10, 13 and 11 here),
+    by a multiply-shift of hash bits (radix_split_kernel<.., ANY>): row counts that are no power of two, all keys
+    distinct (the all-distinct attempt) and every key two or three times (the general form), against the oracle."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(n % 1000 + keys_per)
+    g = (n + keys_per - 1) // keys_per
+    k = np.tile(rng.permutation(g).astype(np.int64) * 1_000_003 - 11, keys_per)[:n]
+    rng.shuffle(k)
+    x = rng.integers(-2**40, 2**40, size=n, dtype=np.int64)
+    aggs = [(F["ANY_NOT_NULL"], 0, -1), (F["SUM_INT"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["MIN"], 1, -1)]
+    a = dev.Agg([cd.INT64, cd.INT64], [0], aggs)
+    dev.prof_enable(True)
+    dev.prof_reset()
+    a.consume([dev.upload(cd.Vec.from_numpy(cd.INT64, k)), dev.upload(cd.Vec.from_numpy(cd.INT64, x))], n)
+    launches, incremental = _bulk_launches(dev), dev.prof_get("agg_resolve")[1]
+    dev.prof_enable(False)
+    assert launches >= 1 and incremental == 0, "the bulk path did not take the input"
+    got = dev.result_to_vecs(a.finish())
+    a.close()
+    want = oracle.hash_agg([cd.Vec.from_numpy(cd.INT64, k), cd.Vec.from_numpy(cd.INT64, x)], [0], aggs)
+    assert np.array_equal(_canon(got), _canon(want))
+
+
 @pytest.mark.parametrize("shape", ["distinct", "twice", "few_groups_in_a_piece"])
 def test_agg_bulk_input_split_into_pieces_vs_oracle(oracle, shape, monkeypatch):
     """A first input beyond the bulk path's 2^27 rows is split by key hash into pieces that go through the bulk path one

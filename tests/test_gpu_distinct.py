@@ -138,6 +138,28 @@ def test_distinct_bulk_path_vs_oracle(oracle):
         assert np.array_equal(got, want[c].data)
 
 
+def test_distinct_bulk_path_row_count_no_power_of_two(oracle):
+    """10^7 rows: ten regions per radix partition (ceil(n / 2^20), any number: a multiply-shift of hash bits
+    picks the region), three quarters of the keys distinct; ordered comparison with the oracle."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(43)
+    n = 10_000_000
+    base = rng.permutation(n).astype(np.int64)[: n * 3 // 4] * 1_000_003 - 11
+    keys = np.concatenate([base, rng.choice(base, n - base.size)])
+    rng.shuffle(keys)
+    cols = [cd.Vec.from_numpy(cd.INT64, keys), cd.Vec.from_numpy(cd.INT64, np.arange(n, dtype=np.int64))]
+    d = dev.Distinct([cd.INT64, cd.INT64], [0])
+    dev.prof_enable(True)
+    dev.prof_reset()
+    out = dev.result_to_vecs(d.consume([dev.upload(v) for v in cols], n))
+    assert dev.prof_get("distinct_bulk")[1] == 1, "the bulk path did not run"
+    dev.prof_enable(False)
+    d.close()
+    want, _ = oracle.unordered_distinct(cols, [0], False)
+    for c in range(2):
+        assert np.array_equal(out[c].data, want[c].data)
+
+
 @pytest.mark.parametrize("nkeys", [30_000, 150_000])
 def test_distinct_bulk_part_form_vs_oracle(oracle, nkeys):
     """Mid cardinality (tens to thousands of keys per radix partition): the bulk path without the level-2 split; only the
