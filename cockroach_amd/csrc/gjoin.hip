@@ -4,7 +4,9 @@
 // naive implementation ... simply uses the hash joiner and the hash aggregator directly.  TODO: add optimized
 // implementation", for the plan shape its spec defines (execinfrapb.HashGroupJoinerSpec, processors_sql.proto:1035-1072):
 // "the join's equality columns are exactly the same as the aggregation's grouping columns", here with one INT64
-// equality column, unique build keys (the planner's right-side-is-key case) and an INNER join.  Everything else keeps
+// equality column, unique build keys (the planner's right-side-is-key case) and an INNER join -- or an outer join that
+// keeps the BUILD side (CRGPU_RIGHT_OUTER: every build row is a group, also without a probe row; TPC-H Q13's
+// customer LEFT OUTER JOIN orders GROUP BY c_custkey with customer as the build side).  Everything else keeps
 // the composition crgpu_dev_join_probe -> crgpu_dev_agg_consume, which stays device-resident.
 //
 // Why not atomics from the join's probe kernel: random HBM atomics run at ~24 G/s on this part (experiments/atomics.hip)
@@ -23,6 +25,7 @@
 // one row per group; the composition writes the joined rows, reads them, partitions them again for the aggregation.
 //
 // Roofline: HBM streaming (the three probe-side passes).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -36,13 +39,13 @@ static constexpr int kGjMaxAggs = 8;
 static constexpr int kGjMaxPlanes = 4;            // 48 KiB table + 4 x 24 KiB planes fit the 160 KiB of LDS
 static constexpr int kGjSlots = kRadixSlots + 1;  // + the build key equal to the empty marker (RadixSpecial)
 enum { GJ_IN_KEY = 0, GJ_IN_PROBE = 1, GJ_IN_BUILD = 2 };
-enum { GJ_COUNT_ROWS = 0, GJ_SUM_F64, GJ_AVG_F64, GJ_SUM_INT, GJ_MIN_I64, GJ_MAX_I64, GJ_MIN_F64, GJ_MAX_F64, GJ_ANY };
+enum { GJ_COUNT_ROWS = 0, GJ_SUM_F64, GJ_AVG_F64, GJ_SUM_INT, GJ_MIN_I64, GJ_MAX_I64, GJ_MIN_F64, GJ_MAX_F64, GJ_ANY, GJ_COUNT_PROBE };
 
 struct GjOp {
   int8_t kind, input, plane, plane2;  // plane2: SUM_INT's high word
   int8_t owner, _p[3];                // owner: this aggregation updates `plane` (SUM and AVG of the column share one)
   uint8_t *out;        // [group]
-  uint8_t *out_valid;  // unused: every emitted group has at least one row and inputs carry no NULLs
+  uint8_t *out_valid;  // OUTER, aggregations over the probe side: one byte per group, 0 = NULL (no probe row); else nullptr
 };
 struct GjArgs {
   const ulonglong2 *prows;
@@ -76,6 +79,9 @@ __device__ __forceinline__ void gj_slots(uint64_t h, uint32_t *s) {  // = radix.
   s[2] = static_cast<uint32_t>((static_cast<uint64_t>(static_cast<uint32_t>(g >> 32)) * kRadixSlots) >> 32);
 }
 
+// OUTER: the join keeps the build side -- every build row is emitted; without a probe row its COUNT_ROWS is 1 (the one
+// joined row, NULL on the probe side), COUNT over the probe side 0 and the other probe-side aggregations NULL.
+template <bool OUTER>
 __global__ __launch_bounds__(1024) void gjoin_fused_kernel(GjArgs a) {
   constexpr int THREADS = 1024, RPT = 4;
   extern __shared__ __align__(16) unsigned char gj_lds[];
@@ -84,7 +90,12 @@ __global__ __launch_bounds__(1024) void gjoin_fused_kernel(GjArgs a) {
   __shared__ uint32_t s_emit, s_base_lo, s_base_hi;
   const uint32_t q = blockIdx.x;
   const uint32_t n = a.pcount[q];
-  if (n == 0) return;  // no probe row reached this sub-partition: none of its groups exists (INNER)
+  if (!OUTER && n == 0) return;  // no probe row reached this sub-partition: none of its groups exists (INNER)
+  // OUTER: the build row whose key equals the empty marker lives in a side slot; the sub-partition its key hashes to emits it
+  const uint32_t nsub = gridDim.x / static_cast<uint32_t>(kRadixP1);
+  const uint64_t he = fmix64(kRadixEmpty);
+  const bool special_here = OUTER && a.special->present != 0 &&
+                            q == static_cast<uint32_t>(he >> 54) * nsub + (static_cast<uint32_t>(he >> 47) & (nsub - 1));
   const ulonglong2 *img = a.table + static_cast<int64_t>(q) * kRadixSlots;
   for (int i = threadIdx.x; i < kRadixSlots; i += THREADS) tab[i] = img[i];
   // plane 0 = rows per slot; the others start at what their aggregation needs
@@ -170,7 +181,8 @@ __global__ __launch_bounds__(1024) void gjoin_fused_kernel(GjArgs a) {
   uint32_t mine[(kGjSlots + THREADS - 1) / THREADS], nmine = 0, local[(kGjSlots + THREADS - 1) / THREADS];
   for (int i = threadIdx.x, t = 0; i < kGjSlots; i += THREADS, t++) {
     mine[t] = 0xFFFFFFFFu;
-    if (planes[i] != 0ull) {
+    const bool emit = OUTER ? (i < kRadixSlots ? tab[i].x != kRadixEmpty : special_here) : planes[i] != 0ull;
+    if (emit) {
       mine[t] = static_cast<uint32_t>(i);
       local[t] = atomicAdd(&s_emit, 1u);
     }
@@ -196,11 +208,12 @@ __global__ __launch_bounds__(1024) void gjoin_fused_kernel(GjArgs a) {
       unsigned long long v = 0;
       const unsigned long long w = op.plane > 0 ? planes[op.plane * kGjSlots + s] : 0ull;
       switch (op.kind) {
-        case GJ_COUNT_ROWS: v = cnt; break;
+        case GJ_COUNT_ROWS: v = OUTER && cnt == 0 ? 1ull : cnt; break;
+        case GJ_COUNT_PROBE: v = cnt; break;
         case GJ_ANY: v = op.input == GJ_IN_KEY ? key : bval; break;
         case GJ_SUM_F64: v = w; break;
         case GJ_AVG_F64:
-          v = static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(w)) / static_cast<double>(cnt)));
+          v = cnt == 0 ? 0ull : static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(w)) / static_cast<double>(cnt)));
           break;
         case GJ_SUM_INT: {
           const unsigned long long hi = planes[op.plane2 * kGjSlots + s];
@@ -212,8 +225,23 @@ __global__ __launch_bounds__(1024) void gjoin_fused_kernel(GjArgs a) {
         case GJ_MAX_F64: v = static_cast<unsigned long long>(__double_as_longlong(gj_ordered_f64(w))); break;
         default: v = w; break;  // MIN / MAX over INT64
       }
+      if (OUTER && op.out_valid != nullptr) {
+        op.out_valid[pos] = cnt != 0;
+        if (cnt == 0) v = 0;
+      }
       reinterpret_cast<unsigned long long *>(op.out)[pos] = v;
     }
+  }
+}
+
+// validity bytes (one per group, written in emission order) -> bitmap; one thread per output byte
+__global__ __launch_bounds__(256) void gjoin_pack_valid_kernel(const uint8_t *__restrict__ bytes, int64_t n, uint8_t *__restrict__ bitmap) {
+  const int64_t nb = (n + 7) >> 3;
+  for (int64_t b = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; b < nb; b += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    uint32_t m = 0;
+    for (int j = 0; j < 8; j++)
+      if (b * 8 + j < n && bytes[b * 8 + j] != 0) m |= 1u << j;
+    bitmap[b] = static_cast<uint8_t>(m);
   }
 }
 
@@ -224,6 +252,9 @@ using namespace crgpu;
 struct crgpu_gjoin : crgpu::Handle {
   int probe_type = 0, build_type = 0;  // payload column types (0: none)
   int naggs = 0, nplanes = 1;
+  bool outer = false;             // CRGPU_RIGHT_OUTER: the build side is kept
+  bool nullable[kGjMaxAggs] = {};  // outer: aggregations over the probe side (NULL for a build row without a probe row)
+  DevBuf valid_bytes[kGjMaxAggs];
   GjOp ops[kGjMaxAggs];
   int out_type[kGjMaxAggs];
   RadixTable tb, tp;
@@ -238,7 +269,7 @@ extern "C" crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crg
   CRGPU_TRY(ensure_init());
   if (spec == nullptr || out == nullptr || (spec->n_aggs > 0 && spec->aggs == nullptr)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_gjoin_create: null argument");
   const char *compose = "crgpu_dev_gjoin_create: outside the fused form (compose crgpu_dev_join_probe -> crgpu_dev_agg_consume)";
-  if (spec->join_type != CRGPU_INNER || spec->key_type != CRGPU_INT64) return fail(CRGPU_ERR_UNSUPPORTED, compose);
+  if ((spec->join_type != CRGPU_INNER && spec->join_type != CRGPU_RIGHT_OUTER) || spec->key_type != CRGPU_INT64) return fail(CRGPU_ERR_UNSUPPORTED, compose);
   if (spec->n_aggs < 1 || spec->n_aggs > kGjMaxAggs) return fail(CRGPU_ERR_UNSUPPORTED, compose);
   for (int t : {spec->probe_payload_type, spec->build_payload_type})
     if (t != 0 && t != CRGPU_INT64 && t != CRGPU_FLOAT64) return fail(CRGPU_ERR_UNSUPPORTED, compose);
@@ -247,6 +278,7 @@ extern "C" crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crg
   g->probe_type = spec->probe_payload_type;
   g->build_type = spec->build_payload_type;
   g->naggs = spec->n_aggs;
+  g->outer = spec->join_type == CRGPU_RIGHT_OUTER;
   for (int f = 0; f < spec->n_aggs; f++) {
     const crgpu_gjoin_agg &d = spec->aggs[f];
     GjOp &op = g->ops[f];
@@ -258,8 +290,11 @@ extern "C" crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crg
     if (d.func != CRGPU_COUNT_ROWS && (in_t <= 0)) return fail(CRGPU_ERR_INVALID, "crgpu_dev_gjoin_create: aggregation over a column the spec does not have");
     bool needs_plane = false;
     switch (d.func) {
-      case CRGPU_COUNT_ROWS:
-      case CRGPU_COUNT: op.kind = GJ_COUNT_ROWS; g->out_type[f] = CRGPU_INT64; break;  // no NULL inputs: COUNT(col) = the rows
+      case CRGPU_COUNT_ROWS: op.kind = GJ_COUNT_ROWS; g->out_type[f] = CRGPU_INT64; break;
+      case CRGPU_COUNT:  // no NULL inputs: COUNT(col) = the rows -- but the probe side's columns of an unmatched build row are NULL
+        op.kind = g->outer && d.input == GJ_IN_PROBE ? GJ_COUNT_PROBE : GJ_COUNT_ROWS;
+        g->out_type[f] = CRGPU_INT64;
+        break;
       case CRGPU_ANY_NOT_NULL:
         if (d.input == GJ_IN_PROBE) return fail(CRGPU_ERR_UNSUPPORTED, compose);  // "first in arrival order" has no meaning here
         op.kind = GJ_ANY; g->out_type[f] = in_t; break;
@@ -278,6 +313,7 @@ extern "C" crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crg
         g->out_type[f] = in_t; needs_plane = true; break;
       default: return fail(CRGPU_ERR_UNSUPPORTED, compose);
     }
+    g->nullable[f] = g->outer && needs_plane;  // (every aggregation with a plane is one over the probe side)
     if (needs_plane) {
       // SUM and AVG of the same column share a plane
       int share = -1;
@@ -299,7 +335,9 @@ extern "C" crgpu_status crgpu_dev_gjoin_create(const crgpu_gjoin_spec *spec, crg
   CRGPU_TRY(g->err.ensure(4));
   static DeviceOnce attr_set;
   if (attr_set.need()) {
-    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gjoin_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gjoin_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kRadixSlots * 16 + kGjMaxPlanes * kGjSlots * 8));
+    CRGPU_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gjoin_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kRadixSlots * 16 + kGjMaxPlanes * kGjSlots * 8));
     attr_set.mark();
   }
@@ -337,6 +375,8 @@ extern "C" crgpu_status crgpu_dev_gjoin_build(crgpu_gjoin *g, const crgpu_dcol *
   if (n < 1 || n > (int64_t(1) << 30)) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_build: between 1 and 2^30 build rows");
   RadixSrc src;
   CRGPU_TRY(gj_src(key, payload, g->build_type, n, &src));
+  // (a build row with a NULL key joins nothing, but an outer join that keeps the build side still owes it a group)
+  if (g->outer && key->valid != nullptr) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_build: RIGHT OUTER with a nullable build key (compose join -> aggregate)");
   bool ok = false;
   g->built = false;
   CRGPU_TRY(radix_build(g->tb, src, n, &ok, /*check_dup=*/true));
@@ -360,29 +400,44 @@ extern "C" crgpu_status crgpu_dev_gjoin_probe(crgpu_gjoin *g, const crgpu_dcol *
   for (int f = 0; f < g->naggs; f++) {
     OutCol &o = g->out[f];
     o.type = g->out_type[f];
-    o.nullable = false;
+    o.nullable = g->nullable[f];
     CRGPU_TRY(o.data.ensure(static_cast<size_t>(cap) * 8));
     g->ops[f].out = o.data.as<uint8_t>();
+    g->ops[f].out_valid = nullptr;
+    if (g->nullable[f]) {
+      CRGPU_TRY(g->valid_bytes[f].ensure(static_cast<size_t>(cap)));
+      CRGPU_TRY(o.valid.ensure(static_cast<size_t>((cap + 7) / 8 + 1)));
+      g->ops[f].out_valid = g->valid_bytes[f].as<uint8_t>();
+    }
   }
   uint64_t ngroups = 0;
-  if (n > 0) {
-    RadixSrc src;
-    CRGPU_TRY(gj_src(key, payload, g->probe_type, n, &src));
-    // the probe rows through the build side's two partition levels
+  if (n > 0 || g->outer) {
     const int sb = g->tb.sub_bits;
-    int lg = 0;
-    while ((int64_t(1) << lg) < n) lg++;
-    int l2rps = lg - 10 - sb;
-    if (l2rps < 0) l2rps = 0;
-    const double mean = static_cast<double>(n) / static_cast<double>(int64_t(kRadixP1) << sb);
-    // regions of twice the mean: probe keys repeat, so a sub-partition's row count varies far more than a Poisson count
-    uint32_t subcap = static_cast<uint32_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 64.0);
-    subcap = (subcap + 7u) & ~7u;
-    bool ok = false;
-    CRGPU_TRY(radix_partition_split(g->tp, src, n, &ok, subcap, l2rps, sb));
-    if (g->tp.sub_bits != sb)
-      return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_probe: the probe side is too small for the build side's partitioning (compose join -> aggregate)");
-    if (!ok) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_probe: skewed probe keys overflow a sub-partition (compose join -> aggregate)");
+    uint32_t subcap = 8;
+    if (n == 0) {  // outer, no probe row: every region is empty
+      CRGPU_TRY(g->tp.rows_b.ensure(16));
+      CRGPU_TRY(g->tp.sub_count.ensure((static_cast<size_t>(kRadixP1) << sb) * 4));
+      CRGPU_HIP(hipMemsetAsync(g->tp.sub_count.p, 0, (static_cast<size_t>(kRadixP1) << sb) * 4, st));
+    } else {
+      RadixSrc src;
+      CRGPU_TRY(gj_src(key, payload, g->probe_type, n, &src));
+      // the probe rows through the build side's two partition levels
+      int lg = 0;
+      while ((int64_t(1) << lg) < n) lg++;
+      int l2rps = lg - 10 - sb;
+      // (a probe side much smaller than the build side: INNER leaves it to the composition, which touches only the
+      // matching groups; the outer form emits every build row anyway and takes it, its regions nearly empty)
+      if (l2rps < 0 && !g->outer) l2rps = 0;
+      const double mean = static_cast<double>(n) / static_cast<double>(int64_t(kRadixP1) << sb);
+      // regions of twice the mean: probe keys repeat, so a sub-partition's row count varies far more than a Poisson count
+      subcap = static_cast<uint32_t>(mean * 2.0 + 8.0 * std::sqrt(mean) + 64.0);
+      subcap = (subcap + 7u) & ~7u;
+      bool ok = false;
+      CRGPU_TRY(radix_partition_split(g->tp, src, n, &ok, subcap, l2rps, sb));
+      if (g->tp.sub_bits != sb)
+        return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_probe: the probe side is too small for the build side's partitioning (compose join -> aggregate)");
+      if (!ok) return fail(CRGPU_ERR_UNSUPPORTED, "crgpu_dev_gjoin_probe: skewed probe keys overflow a sub-partition (compose join -> aggregate)");
+    }
     CRGPU_HIP(hipMemsetAsync(g->counter.p, 0, 8, st));
     CRGPU_HIP(hipMemsetAsync(g->err.p, 0, 4, st));
     GjArgs a;
@@ -400,7 +455,16 @@ extern "C" crgpu_status crgpu_dev_gjoin_probe(crgpu_gjoin *g, const crgpu_dcol *
     const size_t lds = static_cast<size_t>(kRadixSlots) * 16 + static_cast<size_t>(g->nplanes) * kGjSlots * 8;
     {
       ProfScope prof("gjoin_fused");
-      hipLaunchKernelGGL(gjoin_fused_kernel, dim3(static_cast<unsigned int>(kRadixP1) << sb), dim3(1024), lds, st, a);
+      if (g->outer) hipLaunchKernelGGL(gjoin_fused_kernel<true>, dim3(static_cast<unsigned int>(kRadixP1) << sb), dim3(1024), lds, st, a);
+      else hipLaunchKernelGGL(gjoin_fused_kernel<false>, dim3(static_cast<unsigned int>(kRadixP1) << sb), dim3(1024), lds, st, a);
+      CRGPU_HIP(hipGetLastError());
+      // (the kernel strides: any grid will do)
+      const unsigned pack_grid = static_cast<unsigned>(std::min<int64_t>(((cap + 7) / 8 + 255) / 256, static_cast<int64_t>(num_cus()) * 8));
+      if (g->outer)  // (the number of groups is known: every build row)
+        for (int f = 0; f < g->naggs; f++)
+          if (g->nullable[f])
+            hipLaunchKernelGGL(gjoin_pack_valid_kernel, dim3(pack_grid), dim3(256), 0, st, g->valid_bytes[f].as<uint8_t>(), cap,
+                               g->out[f].valid.as<uint8_t>());
       CRGPU_HIP(hipGetLastError());
     }
     unsigned int err = 0;
@@ -408,6 +472,7 @@ extern "C" crgpu_status crgpu_dev_gjoin_probe(crgpu_gjoin *g, const crgpu_dcol *
     CRGPU_HIP(hipMemcpyAsync(&err, g->err.p, 4, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
     if (err) return fail(CRGPU_ERR_INT_OUT_OF_RANGE, "integer out of range");
+    if (g->outer && ngroups != static_cast<uint64_t>(cap)) return fail(CRGPU_ERR_HIP, "crgpu_dev_gjoin_probe: build rows and emitted groups differ (internal error)");
   }
   for (int f = 0; f < g->naggs; f++) g->views[f] = g->out[f].view();
   res->n = static_cast<int64_t>(ngroups);

@@ -422,13 +422,18 @@ void crgpu_dev_deselector_destroy(crgpu_deselector *d);
  * ANY_NOT_NULL of the key or the build payload, within four accumulator words per group.  Anything else =>
  * CRGPU_ERR_UNSUPPORTED: the caller composes crgpu_dev_join_probe -> crgpu_dev_agg_consume (device-resident too).
  * One probe call takes the whole probe side and returns one row per group that has a match (arbitrary order):
- * column f = aggregation f. */
+ * column f = aggregation f.
+ * CRGPU_RIGHT_OUTER (the build side is the join's right input, as in the reference's hash joiner, and is KEPT; a plan
+ * whose kept side is the left one with unique keys -- TPC-H Q13's customer LEFT OUTER JOIN orders GROUP BY c_custkey --
+ * swaps its inputs): one row per BUILD row, also without a probe row -- then COUNT_ROWS = 1 (the one joined row),
+ * COUNT over the probe payload = 0 and SUM / AVG / SUM_INT / MIN / MAX over it NULL (those columns carry a validity
+ * bitmap); the build key column must not be nullable; one probe call per build, an empty probe side included. */
 typedef struct crgpu_gjoin_agg {
   int32_t func;  /* crgpu_agg_func */
   int32_t input; /* 0 the key, 1 the probe side's payload column, 2 the build side's payload column */
 } crgpu_gjoin_agg;
 typedef struct crgpu_gjoin_spec {
-  int32_t join_type;          /* CRGPU_INNER */
+  int32_t join_type;          /* CRGPU_INNER, or CRGPU_RIGHT_OUTER: groups for every build row */
   int32_t key_type;           /* CRGPU_INT64 */
   int32_t probe_payload_type; /* 0: none */
   int32_t build_payload_type; /* 0: none */

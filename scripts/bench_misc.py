@@ -149,15 +149,27 @@ def bench_general_join(reps, dv, g, lg_b=24, lg_p=26, dup=4, two_cols=False):
     return r
 
 
-def bench_group_join_fused(reps, dv, g, lg_b=24, lg_p=27):
+def wrap_torch_bitmap(col, n, dv):
+    """bool tensor of a device column's validity bitmap (bit = 1: present); all True without one."""
+    if not col.valid_ptr:
+        return torch.ones(n, dtype=torch.bool, device=dv)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import wrap_torch_ptr
+    by = wrap_torch_ptr(col.valid_ptr, (n + 7) // 8, torch.uint8, dv)
+    bits = (by.unsqueeze(1) >> torch.arange(8, device=dv, dtype=torch.uint8)) & 1
+    return bits.reshape(-1)[:n].to(torch.bool)
+
+
+def bench_group_join_fused(reps, dv, g, lg_b=24, lg_p=27, outer=False):
     """The same group-join through the fused form (crgpu_dev_gjoin_*: aggregate while probing, no joined row is
-    materialised), same inputs and the same torch check as bench_join_then_agg."""
+    materialised), same inputs and the same torch check as bench_join_then_agg.  outer: the join keeps the build side
+    (CRGPU_RIGHT_OUTER): a group per built order, SUM NULL and COUNT_ROWS 1 where no lineitem matches."""
     nb, npr = 1 << lg_b, 1 << lg_p
     okeys = torch.randperm(nb, generator=g, device=dv, dtype=torch.int64)[: nb // 2].contiguous() * 7 + 3
     lkey = torch.randint(0, nb, (npr,), generator=g, device=dv, dtype=torch.int64) * 7 + 3
     price = torch.randint(1, 100000, (npr,), generator=g, device=dv, dtype=torch.int64).to(torch.float64) / 100.0
     bk, pk, pv = dev.from_torch(cd.INT64, okeys), dev.from_torch(cd.INT64, lkey), dev.from_torch(cd.FLOAT64, price)
-    gj = dev.GroupJoin([(0, 0), (10, 1), (14, 0)], probe_payload_type=cd.FLOAT64)
+    gj = dev.GroupJoin([(0, 0), (10, 1), (14, 0)], probe_payload_type=cd.FLOAT64, join_type=2 if outer else 0)
     out = {}
 
     def go():
@@ -178,12 +190,23 @@ def bench_group_join_fused(reps, dv, g, lg_b=24, lg_p=27):
     want_s = torch.zeros(uk.numel(), device=dv, dtype=torch.float64).index_add_(0, inv, price[hit])
     want_c = torch.bincount(inv, minlength=uk.numel())
     order = torch.argsort(gk)
-    ok = ng == uk.numel() and torch.equal(gk[order], uk) and torch.equal(gc[order], want_c) and \
-        bool(torch.allclose(gs[order], want_s, rtol=1e-9, atol=1e-6))
+    if outer:
+        # every built order is a group; the matched ones carry the sums and counts above, the others NULL and 1
+        valid = wrap_torch_bitmap(rc[1], ng, dv)
+        sk = gk[order]
+        pos = torch.searchsorted(sk, uk)
+        matched = torch.zeros(ng, dtype=torch.bool, device=dv)
+        matched[pos] = True
+        ok = ng == nb // 2 and torch.equal(sk, torch.sort(okeys).values) and torch.equal(valid[order], matched) and \
+            torch.equal(gc[order][pos], want_c) and bool((gc[order][~matched] == 1).all()) and \
+            bool(torch.allclose(gs[order][pos], want_s, rtol=1e-9, atol=1e-6))
+    else:
+        ok = ng == uk.numel() and torch.equal(gk[order], uk) and torch.equal(gc[order], want_c) and \
+            bool(torch.allclose(gs[order], want_s, rtol=1e-9, atol=1e-6))
     if not ok:
         raise SystemExit("fused group-join: result check failed")
     gj.close()
-    r = _line(f"hash group-join, FUSED (aggregate while probing): 2^{lg_b - 1} built orders x 2^{lg_p} lineitems -> GROUP BY key: SUM + COUNT_ROWS, {ng} groups",
+    r = _line(f"hash group-join, FUSED{', build side kept (RIGHT OUTER)' if outer else ''} (aggregate while probing): 2^{lg_b - 1} built orders x 2^{lg_p} lineitems -> GROUP BY key: SUM + COUNT_ROWS, {ng} groups",
               nb // 2 + npr, dt, 16.0 * (nb // 2) + 16.0 * npr + 24.0 * ng, kern, None)
     r["result_check"] = "ok"
     return r
@@ -365,6 +388,7 @@ def measure(only=None, reps=3, cpu_sample=None, device_index=0, lg_hash=29, lg_r
         yield bench_join_then_agg(reps, dv, g)
     if want("join_agg_fused"):
         yield bench_group_join_fused(reps, dv, g)
+        yield bench_group_join_fused(reps, dv, g, outer=True)
     if want("general_join"):
         yield bench_general_join(reps, dv, g)
     if want("general_join2"):

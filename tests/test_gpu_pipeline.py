@@ -75,6 +75,76 @@ def test_fused_group_join_float_payload_vs_oracle(oracle, nb, npr):
     assert 0 < ng < nb
 
 
+@pytest.mark.parametrize("nb,npr,empty_key_probed", [(50_000, 300_000, True), (300_000, 2_000_000, False), (200_000, 3_000, False)])
+def test_fused_group_join_keeps_the_build_side_vs_oracle(oracle, nb, npr, empty_key_probed):
+    """CRGPU_RIGHT_OUTER: every build row is a group, also without a probe row (COUNT_ROWS 1, COUNT over the probe side
+    0, its SUM / AVG / MIN / MAX NULL) -- against the reference's composition joiner (RIGHT OUTER) -> aggregator on the
+    oracle, grouped by the build key.  The build key ~0 (the tables' empty marker, kept in a side slot) with and without
+    probe rows; a probe side far smaller than the build side; then the same build probed by nothing at all."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(nb + 1)
+    keys = rng.permutation(nb * 3)[:nb].astype(np.int64)
+    keys[0] = -1
+    bk = cd.Vec.from_numpy(cd.INT64, keys)
+    bv = cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.random(nb) * 10, 2))
+    p = rng.integers(0, nb * 2, size=npr, dtype=np.int64)
+    if empty_key_probed:
+        p[rng.random(npr) < 0.001] = -1
+    pk = cd.Vec.from_numpy(cd.INT64, p, rng.random(npr) > 0.02)
+    pv = cd.Vec.from_numpy(cd.FLOAT64, np.round(rng.standard_normal(npr) * 100, 2))
+    fused = [(F["ANY_NOT_NULL"], 0), (F["ANY_NOT_NULL"], 2), (F["SUM"], 1), (F["AVG"], 1), (F["MIN"], 1), (F["MAX"], 1),
+             (F["COUNT_ROWS"], 0), (F["COUNT"], 1)]
+    ora = [(F["ANY_NOT_NULL"], 2, -1), (F["ANY_NOT_NULL"], 3, -1), (F["SUM"], 1, -1), (F["AVG"], 1, -1), (F["MIN"], 1, -1),
+           (F["MAX"], 1, -1), (F["COUNT_ROWS"], -1, -1), (F["COUNT"], 1, -1)]
+    gj = dev.GroupJoin(fused, probe_payload_type=pv.type, build_payload_type=bv.type, join_type=2)
+    gj.build(dev.upload(bk), dev.upload(bv))
+    got = dev.result_to_vecs(gj.probe(dev.upload(pk), dev.upload(pv)))
+    joined = oracle.hash_join(2, [pk, pv], [bk, bv], [0], [0], True)  # (pk, pv, bk, bv), unmatched build rows NULL-extended
+    want = oracle.hash_agg(joined, [2], ora)
+    assert len(got[0]) == nb
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "fused group-join, build side kept")
+    # nothing probes: one row per build row, every probe-side aggregate NULL
+    none_k = cd.Vec.from_numpy(cd.INT64, np.zeros(0, dtype=np.int64))
+    none_v = cd.Vec.from_numpy(cd.FLOAT64, np.zeros(0))
+    got = dev.result_to_vecs(gj.probe(dev.upload(none_k), dev.upload(none_v)))
+    gj.close()
+    want = oracle.hash_agg(oracle.hash_join(2, [none_k, none_v], [bk, bv], [0], [0], True), [2], ora)
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "fused group-join, build side kept, no probe row")
+
+
+def test_fused_group_join_build_side_kept_integer_payload(oracle):
+    """RIGHT OUTER with an INT64 probe payload: SUM_INT / MIN NULL for build rows nobody probes, COUNT_ROWS without a
+    payload at all; a nullable build key is left to the composition."""
+    from cockroach_amd import _lib
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(10)
+    nb, npr = 30_000, 200_000
+    bk = cd.Vec.from_numpy(cd.INT64, np.arange(nb, dtype=np.int64) * 7 - 100)
+    bv = cd.Vec.from_numpy(cd.INT64, rng.integers(-5, 5, nb, dtype=np.int64))
+    pk = cd.Vec.from_numpy(cd.INT64, rng.integers(0, nb // 2, npr, dtype=np.int64) * 7 - 100)  # half of the build keys
+    pv = cd.Vec.from_numpy(cd.INT64, rng.integers(-2**40, 2**40, npr, dtype=np.int64))
+    fused = [(F["ANY_NOT_NULL"], 0), (F["SUM_INT"], 1), (F["MIN"], 1), (F["ANY_NOT_NULL"], 2), (F["COUNT_ROWS"], 0), (F["COUNT"], 1)]
+    ora = [(F["ANY_NOT_NULL"], 2, -1), (F["SUM_INT"], 1, -1), (F["MIN"], 1, -1), (F["ANY_NOT_NULL"], 3, -1), (F["COUNT_ROWS"], -1, -1),
+           (F["COUNT"], 1, -1)]
+    gj = dev.GroupJoin(fused, probe_payload_type=cd.INT64, build_payload_type=cd.INT64, join_type=2)
+    gj.build(dev.upload(bk), dev.upload(bv))
+    got = dev.result_to_vecs(gj.probe(dev.upload(pk), dev.upload(pv)))
+    gj.close()
+    want = oracle.hash_agg(oracle.hash_join(2, [pk, pv], [bk, bv], [0], [0], True), [2], ora)
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "fused group-join, build side kept, INT64")
+    gj = dev.GroupJoin([(F["COUNT_ROWS"], 0)], join_type=2)
+    gj.build(dev.upload(bk))
+    got = dev.result_to_vecs(gj.probe(dev.upload(pk)))
+    want = oracle.hash_agg(oracle.hash_join(2, [pk], [bk], [0], [0], True), [1], [(F["COUNT_ROWS"], -1, -1)])
+    H.assert_same_multiset(H.vecs_to_tuples(got), H.vecs_to_tuples(want), "fused group-join, build side kept, COUNT_ROWS")
+    gj.close()
+    gj = dev.GroupJoin([(F["COUNT_ROWS"], 0)], join_type=2)
+    with pytest.raises(_lib.CrgpuError) as e:
+        gj.build(dev.upload(cd.Vec.from_numpy(cd.INT64, np.arange(1000, dtype=np.int64), rng.random(1000) > 0.1)))
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    gj.close()
+
+
 def test_fused_group_join_int_payload_overflow_and_unsupported(oracle):
     from cockroach_amd import _lib
     from cockroach_amd import device as dev
