@@ -208,8 +208,9 @@ size_t scan_scratch_words(int64_t n);
 crgpu_status exclusive_scan_u32_ws(const uint32_t *counts, int64_t n, uint64_t *offsets, uint64_t *tile_sums,
                                    uint64_t *total_host);
 // idx_out[k] = i for every i in [0,n) with flags[i] != 0 (stable order); *count_host = number selected.
+// skip_if_all: when every row is flagged idx_out is NOT written (the caller copies instead of gathering).
 crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, DevBuf &scratch,
-                            int64_t *count_host);
+                            int64_t *count_host, bool skip_if_all = false);
 // bytes-per-row -> bitmap packing (dst bit i = src[i] != 0)
 crgpu_status pack_bitmap(const uint8_t *bytes, int64_t n, uint8_t *bitmap);
 // hash rows (hash.hip): out32/out64 device arrays

@@ -411,6 +411,8 @@ struct crgpu_distinct : crgpu::Handle {
   DevBuf meta, gword, slot_of, flags, idx, scratch;
   RadixTable radix;          // partition buffers of the bulk path
   bool index_stale = false;  // the bulk path appended keys whose index entries do not exist yet (rebuilt from gword)
+  int64_t words_pending = 0;  // ... and the hash words of its first so many stored keys are not written either: only an
+                              // index rebuild reads them, and an input that came in one batch never causes one
   struct KS { DevBuf data, offsets; uint64_t tail = 0; };
   std::vector<std::unique_ptr<KS>> ks;
   std::vector<OutCol> out;
@@ -448,6 +450,16 @@ static crgpu_status distinct_ensure(crgpu_distinct *d, size_t need_groups, bool 
     CRGPU_HIP(hipMemsetAsync(d->meta.p, 0xFF, static_cast<size_t>(want) * 8, st));
     d->cap = static_cast<uint32_t>(want);
     d->index_stale = false;
+    if (d->words_pending > 0) {  // (the bulk path: one INT64 distinct column without NULLs, every stored row an emitted one)
+      KeyCols keys;
+      std::memset(&keys, 0, sizeof(keys));
+      keys.n = 1;
+      keys.c[0] = DCol{CRGPU_INT64, 0, d->ks[0]->data.p, nullptr, nullptr};
+      hipLaunchKernelGGL(distinct_bulk_words_kernel, dim3(dgrid(d->words_pending)), dim3(256), 0, st, keys, d->words_pending,
+                         static_cast<const uint8_t *>(nullptr), d->gword.as<unsigned long long>());
+      CRGPU_HIP(hipGetLastError());
+      d->words_pending = 0;
+    }
     if (d->ngroups > 0) {
       ProfScope prof("distinct_reindex");
       hipLaunchKernelGGL(distinct_reindex_kernel, dim3(dgrid(d->ngroups)), dim3(256), 0, st, d->gword.as<unsigned long long>(),
@@ -503,6 +515,7 @@ extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
   d->ngroups = 0;
   d->expect_new = true;
   d->index_stale = false;
+  d->words_pending = 0;
   for (auto &k : d->ks) k->tail = 0;
   CRGPU_HIP(hipStreamSynchronize(st));
   return CRGPU_OK;
@@ -639,8 +652,11 @@ static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crg
       CRGPU_TRY(distinct_try_bulk(d, in, n, &bulk));
     }
   }
+  // (every column fixed-width and without NULLs: a batch whose rows are all emitted is copied, not gathered)
+  bool plain_cols = true;
+  for (int c = 0; c < nc; c++) plain_cols = plain_cols && d->types[c] != CRGPU_BYTES && in[c].valid == nullptr;
   if (bulk) {
-    CRGPU_TRY(select_flagged(d->flags.as<uint8_t>(), n, d->idx.as<int32_t>(), d->scratch, &m));
+    CRGPU_TRY(select_flagged(d->flags.as<uint8_t>(), n, d->idx.as<int32_t>(), d->scratch, &m, plain_cols));
     whole = m * 2 > n;
     d->expect_new = whole;
     d->index_stale = true;
@@ -688,10 +704,27 @@ static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crg
       CRGPU_HIP(hipGetLastError());
     }
   }
-  // the output: every column of the emitted rows, in input order
+  // the output: every column of the emitted rows, in input order.  A fixed-width distinct column without NULLs is not
+  // gathered into a buffer of its own when the rows the key store takes are exactly the emitted ones (every batch but a
+  // mostly-new one with repeats inside): its values are written where the store wants them and handed out from there
+  // (valid until the next call on the handle, like every result: only a later call can move the store)
+  std::vector<void *> from_store(static_cast<size_t>(nc), nullptr);
   {
     ProfScope prof("distinct_gather");
     for (int c = 0; c < nc; c++) {
+      int kc = -1, times = 0;
+      for (size_t k = 0; k < d->dcols.size(); k++)
+        if (d->dcols[k] == c) kc = static_cast<int>(k), times++;
+      if (n > 0 && m > 0 && times == 1 && (!whole || m == n) && d->types[c] != CRGPU_BYTES && in[c].valid == nullptr) {
+        const size_t w = static_cast<size_t>(type_width(d->types[c]));
+        void *dst = d->ks[static_cast<size_t>(kc)]->data.as<uint8_t>() + static_cast<size_t>(d->ngroups) * w;
+        if (m == n) CRGPU_HIP(hipMemcpyAsync(dst, in[c].data, static_cast<size_t>(n) * w, hipMemcpyDeviceToDevice, st));
+        else CRGPU_TRY(gather_fixed(in[c], d->idx.as<int32_t>(), m, dst));
+        d->out[c].type = d->types[c];
+        d->out[c].nullable = false;
+        from_store[static_cast<size_t>(c)] = dst;
+        continue;
+      }
       if (n == 0 || m == 0) {
         OutCol &o = d->out[c];
         o.type = d->types[c];
@@ -701,12 +734,23 @@ static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crg
           CRGPU_TRY(o.offsets.ensure(4));
           CRGPU_HIP(hipMemsetAsync(o.offsets.p, 0, 4, st));
         }
+      } else if (m == n && d->types[c] != CRGPU_BYTES && in[c].valid == nullptr) {  // every row is emitted: a copy
+        OutCol &o = d->out[c];
+        o.type = d->types[c];
+        o.nullable = false;
+        const size_t bytes = static_cast<size_t>(n) * type_width(o.type);
+        CRGPU_TRY(o.data.ensure(bytes));
+        CRGPU_HIP(hipMemcpyAsync(o.data.p, in[c].data, bytes, hipMemcpyDeviceToDevice, st));
       } else {
         CRGPU_TRY(materialize(in[c], d->idx.as<int32_t>(), m, false, d->out[c], d->scratch));
       }
     }
   }
-  if (bulk) {  // hash words of the rows that join the store: the batch's (emitted rows only) or the output's
+  // hash words of the rows that join the store: the batch's (emitted rows only) or the output's.  When every stored row
+  // is an emitted one they are left for the index rebuild to write, from the store's keys -- if there ever is one
+  if (bulk && (!whole || m == n)) {
+    d->words_pending = whole ? n : m;
+  } else if (bulk) {
     KeyCols keys;
     std::memset(&keys, 0, sizeof(keys));
     keys.n = 1;
@@ -737,7 +781,7 @@ static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crg
                          static_cast<uint32_t>(s.tail), s.offsets.as<uint32_t>() + d->ngroups);
       CRGPU_HIP(hipGetLastError());
       s.tail += total;
-    } else {
+    } else if (from_store[static_cast<size_t>(d->dcols[k])] == nullptr) {
       const size_t w = static_cast<size_t>(type_width(o.type));
       CRGPU_HIP(hipMemcpyAsync(s.data.as<uint8_t>() + static_cast<size_t>(d->ngroups) * w, whole ? x.data : o.data.p,
                                static_cast<size_t>(rows) * w, hipMemcpyDeviceToDevice, st));
@@ -747,7 +791,10 @@ static crgpu_status crgpu_dev_distinct_consume_impl(crgpu_distinct *d, const crg
   else m_store = m;
   d->ngroups += static_cast<uint32_t>(m_store);
   CRGPU_HIP(hipStreamSynchronize(st));
-  for (int c = 0; c < nc; c++) d->views[c] = d->out[c].view();
+  for (int c = 0; c < nc; c++) {
+    d->views[c] = d->out[c].view();
+    if (from_store[static_cast<size_t>(c)] != nullptr) d->views[c].data = from_store[static_cast<size_t>(c)];
+  }
   res->n = m;
   res->ncols = nc;
   res->_pad = 0;

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kScanBlock) void select_apply_kernel(const uint8_t 
   }
 }
 
-crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, DevBuf &scratch, int64_t *count_host) {
+crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, DevBuf &scratch, int64_t *count_host, bool skip_if_all) {
   if (n <= 0) {
     if (count_host) *count_host = 0;
     return CRGPU_OK;
@@ -240,9 +240,18 @@ crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, D
   uint64_t *ts = scratch.as<uint64_t>();
   hipLaunchKernelGGL(tile_sum_kernel<uint8_t>, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts);
   hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream(), ts, ntiles);
+  uint64_t total = 0;
+  if (skip_if_all) {  // the count first: the positions of n flagged rows out of n are not worth writing
+    CRGPU_HIP(hipGetLastError());
+    CRGPU_HIP(hipMemcpyAsync(&total, ts + ntiles, 8, hipMemcpyDeviceToHost, stream()));
+    CRGPU_HIP(hipStreamSynchronize(stream()));
+    if (count_host) *count_host = static_cast<int64_t>(total);
+    if (total != static_cast<uint64_t>(n)) hipLaunchKernelGGL(select_apply_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
+    CRGPU_HIP(hipGetLastError());
+    return CRGPU_OK;
+  }
   hipLaunchKernelGGL(select_apply_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
   CRGPU_HIP(hipGetLastError());
-  uint64_t total = 0;
   CRGPU_HIP(hipMemcpyAsync(&total, ts + ntiles, 8, hipMemcpyDeviceToHost, stream()));
   CRGPU_HIP(hipStreamSynchronize(stream()));
   if (count_host) *count_host = static_cast<int64_t>(total);

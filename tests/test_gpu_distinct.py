@@ -138,6 +138,40 @@ def test_distinct_bulk_path_vs_oracle(oracle):
         assert np.array_equal(got, want[c].data)
 
 
+@pytest.mark.parametrize("first", ["all_distinct", "few_repeats"])
+def test_distinct_bulk_first_batch_handed_out_from_the_key_store(oracle, first):
+    """A first batch whose rows are all emitted (or nearly: fewer than half repeat, so only the emitted rows join the
+    store): the distinct column of the output is not a buffer of its own but the key store's new rows, and the hash
+    words of the stored keys are only written when the second batch forces the index to be built.  The second batch
+    repeats old keys and brings new ones; a third grows the store (its memory may move).  Ordered comparison with the
+    oracle, every result copied before the next call."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(47)
+    n1, n2, n3 = 1 << 23, 300_000, 1 << 23
+    k1 = rng.permutation(n1).astype(np.int64) * 1_000_003 - 11
+    if first == "few_repeats":
+        k1[rng.choice(n1, 2000, replace=False)] = k1[:2000]
+    k2 = np.concatenate([rng.choice(k1, n2 // 2), np.arange(n2 // 2, dtype=np.int64) * 1_000_003 + 5])
+    rng.shuffle(k2)
+    k3 = np.concatenate([rng.choice(k1, n3 // 2), np.arange(n3 // 2, dtype=np.int64) * 1_000_003 + 7])
+    rng.shuffle(k3)
+    keys = np.concatenate([k1, k2, k3])
+    cols = [cd.Vec.from_numpy(cd.INT64, np.arange(keys.size, dtype=np.int64)), cd.Vec.from_numpy(cd.INT64, keys)]
+    d = dev.Distinct([cd.INT64, cd.INT64], [1])
+    dev.prof_enable(True)
+    dev.prof_reset()
+    outs, lo = [], 0
+    for n in (n1, n2, n3):
+        outs.append(dev.result_to_vecs(d.consume([dev.upload(v.slice(lo, lo + n)) for v in cols], n)))
+        lo += n
+    assert dev.prof_get("distinct_bulk")[1] == 1 and dev.prof_get("distinct_reindex")[1] >= 1
+    dev.prof_enable(False)
+    d.close()
+    want, _ = oracle.unordered_distinct(cols, [1], False)
+    for c in range(2):
+        assert np.array_equal(np.concatenate([o[c].data for o in outs]), want[c].data)
+
+
 def test_distinct_bulk_path_row_count_no_power_of_two(oracle):
     """10^7 rows: ten regions per radix partition (ceil(n / 2^20), any number: a multiply-shift of hash bits
     picks the region), three quarters of the keys distinct; ordered comparison with the oracle."""
