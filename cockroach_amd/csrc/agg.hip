@@ -5180,7 +5180,7 @@ static crgpu_status crgpu_dev_agg_finish_impl(crgpu_agg *a, crgpu_dev_result *re
                            a->err_dev.as<unsigned int>());
         CRGPU_HIP(hipGetLastError());
       }
-      if (alias_present == nullptr) {
+      if (alias_present == nullptr || a->one_row_groups) {  // (one row per group, from inputs without a NULL: all present)
         CRGPU_HIP(hipMemsetAsync(o.valid.p, 0xFF, static_cast<size_t>((ng + 7) / 8), st));
       } else {
         CRGPU_TRY(pack_bitmap(alias_present, ng, o.valid.as<uint8_t>()));
