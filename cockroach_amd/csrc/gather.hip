@@ -140,19 +140,24 @@ __global__ __launch_bounds__(kScanBlock) void tile_sum_kernel(const In *__restri
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
-// single workgroup: in-place exclusive scan of tile sums; writes grand total to tile_sums[ntiles]
+// single workgroup: in-place exclusive scan of tile sums; writes grand total to tile_sums[ntiles].  Every thread owns a
+// contiguous run of the sums (summed, ONE block scan over the runs' totals, then written back): a block scan per 256
+// sums took 97 us for the 32768 tiles of 2^27 elements, two barriers apiece.
 __global__ __launch_bounds__(kScanBlock) void scan_tile_sums_kernel(uint64_t *__restrict__ tile_sums, int64_t ntiles) {
   __shared__ uint64_t lds[4];
-  uint64_t carry = 0;
-  for (int64_t start = 0; start < ntiles; start += kScanBlock) {
-    int64_t i = start + threadIdx.x;
-    uint64_t v = i < ntiles ? tile_sums[i] : 0;
-    uint64_t total;
-    uint64_t ex = block_excl_scan_u64(v, lds, &total);
-    if (i < ntiles) tile_sums[i] = carry + ex;
-    carry += total;
+  const int64_t per = (ntiles + kScanBlock - 1) / kScanBlock;
+  const int64_t lo = static_cast<int64_t>(threadIdx.x) * per;
+  const int64_t hi = lo + per < ntiles ? lo + per : ntiles;
+  uint64_t s = 0;
+  for (int64_t i = lo; i < hi; i++) s += tile_sums[i];
+  uint64_t total;
+  uint64_t ex = block_excl_scan_u64(s, lds, &total);
+  for (int64_t i = lo; i < hi; i++) {
+    const uint64_t v = tile_sums[i];
+    tile_sums[i] = ex;
+    ex += v;
   }
-  if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+  if (threadIdx.x == 0) tile_sums[ntiles] = total;
 }
 
 __global__ __launch_bounds__(kScanBlock) void scan_apply_u32_kernel(const uint32_t *__restrict__ in, int64_t n,
@@ -230,6 +235,48 @@ __global__ __launch_bounds__(kScanBlock) void select_apply_kernel(const uint8_t 
   }
 }
 
+// The same two passes for a 16-byte aligned flag array: a thread's 16 flags (blocked arrangement, as in
+// select_apply_kernel) arrive in ONE 16-byte load instead of 16 byte loads (measured per 2^27 flags: DESIGN.md 4.5).  nonzero_bytes: bit 7 of every byte of w that is not zero.
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) { return (w | ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; }
+__device__ __forceinline__ uint32_t flag_bits16(const uint8_t *__restrict__ flags, int64_t first, int64_t n) {
+  // bit k = flags[first + k] != 0, k < 16; first is a multiple of 16
+  uint32_t f = 0;
+  if (first + 16 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(flags + first);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t nz = nonzero_bytes(w[q]);  // bits 7, 15, 23, 31 -> bits 4q .. 4q + 3
+      f |= (((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u)) << (4 * q);
+    }
+  } else {
+    for (int k = 0; k < 16; k++)
+      if (first + k < n && flags[first + k] != 0) f |= 1u << k;
+  }
+  return f;
+}
+__global__ __launch_bounds__(kScanBlock) void tile_sum_flags16_kernel(const uint8_t *__restrict__ flags, int64_t n, uint64_t *__restrict__ tile_sums) {
+  static_assert(kScanItems == 16, "a thread owns 16 flags");
+  __shared__ uint64_t lds[4];
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kScanTile + static_cast<int64_t>(threadIdx.x) * kScanItems;
+  const uint64_t s = first < n ? static_cast<uint64_t>(__popc(flag_bits16(flags, first, n))) : 0;
+  uint64_t total;
+  block_excl_scan_u64(s, lds, &total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanBlock) void select_apply_flags16_kernel(const uint8_t *__restrict__ flags, int64_t n,
+                                                                          const uint64_t *__restrict__ tile_sums, int32_t *__restrict__ idx_out) {
+  __shared__ uint64_t lds[4];
+  const int64_t first = static_cast<int64_t>(blockIdx.x) * kScanTile + static_cast<int64_t>(threadIdx.x) * kScanItems;
+  uint32_t f = first < n ? flag_bits16(flags, first, n) : 0;
+  uint64_t ex = block_excl_scan_u64(static_cast<uint64_t>(__popc(f)), lds, nullptr) + tile_sums[blockIdx.x];
+  while (f) {
+    const int k = __ffs(static_cast<int>(f)) - 1;
+    f &= f - 1;
+    idx_out[ex++] = static_cast<int32_t>(first + k);
+  }
+}
+
 crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, DevBuf &scratch, int64_t *count_host, bool skip_if_all) {
   if (n <= 0) {
     if (count_host) *count_host = 0;
@@ -238,7 +285,9 @@ crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, D
   int64_t ntiles = (n + kScanTile - 1) / kScanTile;
   CRGPU_TRY(scratch.ensure(static_cast<size_t>(ntiles + 1) * 8));
   uint64_t *ts = scratch.as<uint64_t>();
-  hipLaunchKernelGGL(tile_sum_kernel<uint8_t>, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts);
+  const bool vec = (reinterpret_cast<uintptr_t>(flags) & 15u) == 0;
+  if (vec) hipLaunchKernelGGL(tile_sum_flags16_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts);
+  else hipLaunchKernelGGL(tile_sum_kernel<uint8_t>, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts);
   hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(1), dim3(kScanBlock), 0, stream(), ts, ntiles);
   uint64_t total = 0;
   if (skip_if_all) {  // the count first: the positions of n flagged rows out of n are not worth writing
@@ -246,11 +295,15 @@ crgpu_status select_flagged(const uint8_t *flags, int64_t n, int32_t *idx_out, D
     CRGPU_HIP(hipMemcpyAsync(&total, ts + ntiles, 8, hipMemcpyDeviceToHost, stream()));
     CRGPU_HIP(hipStreamSynchronize(stream()));
     if (count_host) *count_host = static_cast<int64_t>(total);
-    if (total != static_cast<uint64_t>(n)) hipLaunchKernelGGL(select_apply_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
+    if (total != static_cast<uint64_t>(n)) {
+      if (vec) hipLaunchKernelGGL(select_apply_flags16_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
+      else hipLaunchKernelGGL(select_apply_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
+    }
     CRGPU_HIP(hipGetLastError());
     return CRGPU_OK;
   }
-  hipLaunchKernelGGL(select_apply_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
+  if (vec) hipLaunchKernelGGL(select_apply_flags16_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
+  else hipLaunchKernelGGL(select_apply_kernel, dim3(ntiles), dim3(kScanBlock), 0, stream(), flags, n, ts, idx_out);
   CRGPU_HIP(hipGetLastError());
   CRGPU_HIP(hipMemcpyAsync(&total, ts + ntiles, 8, hipMemcpyDeviceToHost, stream()));
   CRGPU_HIP(hipStreamSynchronize(stream()));
