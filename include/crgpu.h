@@ -129,7 +129,11 @@ crgpu_status crgpu_prof_get(const char *name, double *total_ms, int64_t *launche
 /* Raw device memory helpers for callers that do not bring their own allocator
  * (the Go shell stages coldata batches through these; torch callers pass
  * tensor.data_ptr() instead).  Copies are synchronous; crgpu_dev_memcpy_d2h and
- * crgpu_dev_synchronize wait for every stream of the thread's library device. */
+ * crgpu_dev_synchronize wait for every stream of the thread's library device.
+ * crgpu_dev_malloc / crgpu_dev_free share the library's per-device free list (crgpu_mem_cached / crgpu_mem_trim):
+ * a freed block is kept for the next allocation of about its size instead of going back to the driver, and
+ * crgpu_dev_free waits for the device first (as hipFree does).  These blocks are the caller's: crgpu_mem_usage and
+ * crgpu_handle_mem_usage do not count them. */
 crgpu_status crgpu_dev_malloc(void **out, size_t bytes);
 void crgpu_dev_free(void *p);
 crgpu_status crgpu_dev_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
