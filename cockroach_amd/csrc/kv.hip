@@ -825,7 +825,15 @@ struct crgpu_decoder : crgpu::Handle {
   std::vector<OutCol> out;
   std::vector<DevBuf> valid_bytes, lens, srcpos, offs64c;
   std::vector<crgpu_dcol> views;
+  // Pinned read-back area: copies into pageable memory complete one by one (a round trip each, ~25 us); into pinned
+  // memory they queue and one wait fetches them all.  [0, 8) the walk's verdict words, [8, 16) the record total,
+  // [16, 32) the walk's error word, [32, 48) the decode's error word, [64, ...) the byte totals of the BYTES columns
+  uint8_t *rb = nullptr;
+  ~crgpu_decoder() {
+    if (rb != nullptr) (void)hipHostFree(rb);
+  }
 };
+static constexpr size_t kKvReadbackBytes = 64 + 8 * static_cast<size_t>(kMaxOutFetch);
 
 // bitmap[c] bit i = bytes[c][i] != 0 for every output column c (blockIdx.y); rows past n read as present, like pack_bitmap
 struct KvPackArgs {
@@ -871,6 +879,15 @@ extern "C" crgpu_status crgpu_dev_decoder_create(const crgpu_fetch_spec *s, crgp
     if (_os != CRGPU_OK) { delete d; return _os; }
   }
   CRGPU_ENTER(d);
+  {
+    void *rb = nullptr;
+    const hipError_t e = hipHostMalloc(&rb, kKvReadbackBytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      delete d;
+      return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
+    d->rb = static_cast<uint8_t *>(rb);
+  }
   FetchSpec &f = d->spec;
   std::memset(&f, 0, sizeof(f));
   f.key_prefix_len = s->key_prefix_len;
@@ -937,10 +954,7 @@ extern "C" void crgpu_dev_decoder_destroy(crgpu_decoder *d) {
   delete d;
 }
 
-static crgpu_status kv_check_error(crgpu_decoder *d, const char *phase) {
-  KvError e;
-  CRGPU_HIP(hipMemcpyAsync(&e, d->err.p, sizeof(e), hipMemcpyDeviceToHost, stream()));
-  CRGPU_HIP(hipStreamSynchronize(stream()));
+static crgpu_status kv_report_error(const KvError &e, const char *phase) {
   if (e.first_row == ~0ull) return CRGPU_OK;
   static const char *names[] = {"", "truncated batch response", "invalid MVCC key", "key column decode error",
                                 "single entry value with no default column", "value column decode error"};
@@ -1022,14 +1036,17 @@ static crgpu_status crgpu_dev_decode_kv_impl(crgpu_decoder *d, const uint8_t *re
       CRGPU_TRY(exclusive_scan_u32(d->seg_count.as<uint32_t>(), nseg, d->seg_base.as<uint64_t>(), d->scratch, nullptr));
       unsigned int nb2[2] = {0, 0};
       KvError e;
-      CRGPU_HIP(hipMemcpyAsync(nb2, d->nbad.p, 8, hipMemcpyDeviceToHost, st));
-      CRGPU_HIP(hipMemcpyAsync(&total, d->seg_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, st));
-      CRGPU_HIP(hipMemcpyAsync(&e, d->err.p, sizeof(e), hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(d->rb, d->nbad.p, 8, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(d->rb + 8, d->seg_base.as<uint64_t>() + nseg, 8, hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipMemcpyAsync(d->rb + 16, d->err.p, sizeof(e), hipMemcpyDeviceToHost, st));
       CRGPU_HIP(hipStreamSynchronize(st));
+      std::memcpy(nb2, d->rb, 8);
+      std::memcpy(&total, d->rb + 8, 8);
+      std::memcpy(&e, d->rb + 16, sizeof(e));
       const unsigned int nbad = nb2[0];
       rel_overflow = nb2[1];
       if (nbad == 0) {
-        if (e.first_row != ~0ull) return kv_check_error(d, "batch");  // (formats the message)
+        if (e.first_row != ~0ull) return kv_report_error(e, "batch");
         break;
       }
       // errors seen by a walk that started at a wrong boundary mean nothing: clear the word, walk those segments again
@@ -1131,10 +1148,18 @@ static crgpu_status crgpu_dev_decode_kv_impl(crgpu_decoder *d, const uint8_t *re
         if (f.out_types[c] != CRGPU_BYTES) continue;
         CRGPU_TRY(d->offs64c[c].ensure(static_cast<size_t>(n + 1) * 8));
         CRGPU_TRY(exclusive_scan_u32(d->lens[c].as<uint32_t>(), n, d->offs64c[c].as<uint64_t>(), d->scratch, nullptr));
-        CRGPU_HIP(hipMemcpyAsync(&totals[c], d->offs64c[c].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        CRGPU_HIP(hipMemcpyAsync(d->rb + 64 + 8 * c, d->offs64c[c].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
       }
     }
-    CRGPU_TRY(kv_check_error(d, "row"));
+    {
+      KvError e;
+      CRGPU_HIP(hipMemcpyAsync(d->rb + 32, d->err.p, sizeof(e), hipMemcpyDeviceToHost, st));
+      CRGPU_HIP(hipStreamSynchronize(st));
+      std::memcpy(&e, d->rb + 32, sizeof(e));
+      for (int c = 0; c < f.n_out; c++)
+        if (f.out_types[c] == CRGPU_BYTES) std::memcpy(&totals[c], d->rb + 64 + 8 * c, 8);
+      CRGPU_TRY(kv_report_error(e, "row"));
+    }
     if (any_bytes) {
       for (int c = 0; c < f.n_out; c++) {
         if (f.out_types[c] != CRGPU_BYTES) continue;
