@@ -1977,6 +1977,7 @@ struct BulkArgs {
   uint32_t g0;
   uint32_t gmax;                // groups a region may hold (sized to the LDS the planes need)
   uint32_t slots;               // LDS index size (power of two, > gmax)
+  uint32_t lkey;                // the part form of narrow rows: the slots' keys sit in LDS too (see agg_bulk_kernel)
   // the all-distinct attempt (TRY): region q's groups are numbered from try_base[q] (prefix sums of the row counts: no
   // group-id atomic); *try_failed is raised by a region with a repeated key -- the attempt is then void as a whole
   const uint64_t *try_base;
@@ -1989,6 +1990,7 @@ template <>
 struct BulkRow<false> {
   typedef ulonglong2 T;
   static __device__ __forceinline__ bool same_key(const BulkArgs &, const T &a, const T &b) { return a.x == b.x; }
+  static __device__ __forceinline__ unsigned long long key_word(const T &r) { return r.x; }  // the whole key (LKEY)
   static __device__ __forceinline__ unsigned long long value(const T &r) { return r.y; }
   static __device__ __forceinline__ unsigned long long value2(const T &) { return 0ull; }
   static __device__ __forceinline__ uint32_t slot_hash(const BulkArgs &, const T &r) { return static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20); }
@@ -2007,6 +2009,7 @@ struct BulkRow<true> {
   static __device__ __forceinline__ bool same_key(const BulkArgs &g, const T &a, const T &b) {
     return a.x == b.x && a.y == b.y && ((a.w ^ b.w) & g.wmask) == 0;
   }
+  static __device__ __forceinline__ unsigned long long key_word(const T &r) { return r.x; }  // (never used: LKEY is narrow only)
   static __device__ __forceinline__ unsigned long long value(const T &r) { return r.z; }
   static __device__ __forceinline__ unsigned long long value2(const T &r) { return r.w; }
   static __device__ __forceinline__ uint32_t slot_hash(const BulkArgs &g, const T &r) {
@@ -2058,6 +2061,13 @@ struct BulkRow<true> {
 // while rows are compared) and the claimants store their groups' keys from registers -- so that the planes for 1280
 // groups, the index and the seen bytes fit 44 KiB: three 512-thread workgroups per CU instead of two of 1024 threads
 // (16-bit index entries, which make room for a fourth, gain nothing: 2.56 against 2.51 ms on config G's 4 x input).
+// LKEY (the part form, one INT64 key): the index holds the KEYS themselves.  A partition is walked in many tiles, and
+// the row that claimed a slot tiles ago is in HBM or L2 by now: comparing against it put a global load into every row's
+// chain of dependent steps.  A slot is claimed by a 64-bit compare-and-swap of its key against the empty marker (so a
+// claimed slot's key is there for whoever sees the claim); the one key equal to the marker gets a slot of its own.
+// (a.lkey, a launch-time flag of the narrow 1024-thread form: one more instantiation of this kernel could not have its
+// dynamic LDS limit raised -- hipFuncSetAttribute returned "invalid argument" for it on this ROCm --, and a uniform
+// branch per lookup costs nothing measurable)
 template <bool WIDE, int THREADS, bool TRY, bool SLIM = false>
 __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   typedef BulkRow<WIDE> R;
@@ -2066,11 +2076,16 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   // id, [gmax] local group id -> representative row, then the seen planes (bytes)
   extern __shared__ unsigned long long lds_words[];
   __shared__ uint32_t s_base, s_claims;
+  __shared__ uint32_t s_special;  // LKEY: the key equal to the empty marker has been claimed
   constexpr uint32_t kNone = 0xFFFFFFFFu;
+  constexpr unsigned long long kNoKey = ~0ull;
+  const bool LKEY = !WIDE && !TRY && !SLIM && a.lkey != 0;
   const uint32_t plane = a.gmax + 1;
+  // LKEY: [slots] keys instead of the slot -> row index, then [slots + 1] slot -> local group (the last one: the marker's key)
+  unsigned long long *kkey = lds_words + static_cast<size_t>(a.nwords) * plane;
   uint32_t *idx = TRY ? reinterpret_cast<uint32_t *>(lds_words) : reinterpret_cast<uint32_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
-  uint32_t *lid = idx + a.slots;
-  uint32_t *rep = lid + a.slots;
+  uint32_t *lid = LKEY ? reinterpret_cast<uint32_t *>(kkey + a.slots) : idx + a.slots;
+  uint32_t *rep = lid + a.slots + (LKEY ? 1 : 0);
   uint8_t *lds_seen = SLIM ? reinterpret_cast<uint8_t *>(idx + a.slots) : reinterpret_cast<uint8_t *>(rep + a.gmax);
   const int q = blockIdx.x;
   // TRY: the first ~1024 rows of the region (what a region holds on average; its capacity is kBulkRows) are requested
@@ -2106,13 +2121,29 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
     }
     for (uint32_t i = threadIdx.x; i < a.nseen * plane; i += blockDim.x) lds_seen[i] = 0;
   };
-  for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) idx[i] = kNone;
+  if (LKEY) {
+    for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) kkey[i] = kNoKey;
+    if (threadIdx.x == 0) s_special = 0;
+  } else {
+    for (uint32_t i = threadIdx.x; i < a.slots; i += blockDim.x) idx[i] = kNone;
+  }
   if (!TRY && !single) init_planes();
   if (threadIdx.x == 0) s_claims = 0;
   __syncthreads();
   constexpr int kRows = kBulkRows / THREADS;  // rows per thread and tile
   Row keep_rr[SLIM ? kRows : 1];        // SLIM: the claimants' rows and local group numbers, for the key stores at the end
   uint32_t keep_l[SLIM ? kRows : 1];
+  // The 1024-thread form walks partitions of many tiles (the part form): the next tile's rows are requested while this
+  // one is looked up and accumulated.  (Not in the 512-thread forms: one tile per region, and no registers to spare.)
+  constexpr bool PF = !TRY && !SLIM;
+  Row nxt[PF ? kRows : 1];
+  if (PF) {
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+      const uint32_t i = k * blockDim.x + threadIdx.x;
+      if (i < n) nxt[PF ? k : 0] = rows[i];
+    }
+  }
   for (uint32_t t0 = 0; t0 < n; t0 += kBulkRows) {
     // 1. find-or-insert by key: a slot holds the row that claimed it (its key is the group's key); the claimant
     //    numbers the group
@@ -2120,6 +2151,19 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
     uint32_t my_l[kRows];  // SLIM: the local group number a claimant gave its group (kNone: not a claimant)
     unsigned long long val[kRows], val2[kRows];
     Row rr[kRows];
+    // (all of the tile's rows are requested before the first one is looked up: the lookups are loops the loads of the
+    // later rows would otherwise wait behind)
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+      const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
+      if (PF) {
+        rr[k] = nxt[PF ? k : 0];
+        const uint32_t j = i + kBulkRows;
+        if (j < n) nxt[PF ? k : 0] = rows[j];
+      } else if (i < n) {
+        rr[k] = (TRY && k < kPre) ? pre[k < kPre ? k : 0] : rows[i];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < kRows; k++) {
       const uint32_t i = t0 + k * blockDim.x + threadIdx.x;
@@ -2129,27 +2173,52 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
       val2[k] = 0;
       bool claimed = false;
       if (i < n) {
-        const Row r = rr[k] = (TRY && k < kPre) ? pre[k < kPre ? k : 0] : rows[i];
+        const Row r = rr[k];
         val[k] = R::value(r);
         val2[k] = R::value2(r);
         uint32_t sl = R::slot_hash(a, r) & smask;
-        uint32_t probes = 0;
-        for (;; probes++) {
-          if (probes == a.slots) {  // the index is full of other keys: far more groups than the planes hold
-            atomicAdd(&s_claims, a.gmax + 1);
-            sl = kNone;
-            break;
-          }
-          uint32_t cur = idx[sl];
-          if (cur == kNone) {
-            cur = atomicCAS(&idx[sl], kNone, i);
-            if (cur == kNone) {
-              claimed = true;
-              break;
+        if (LKEY) {
+          const unsigned long long key = R::key_word(r);
+          if (key == kNoKey) {
+            sl = a.slots;
+            claimed = atomicCAS(&s_special, 0u, 1u) == 0u;
+          } else {
+            for (uint32_t probes = 0;; probes++) {
+              if (probes == a.slots) {  // the index is full of other keys: far more groups than the planes hold
+                atomicAdd(&s_claims, a.gmax + 1);
+                sl = kNone;
+                break;
+              }
+              unsigned long long old = kkey[sl];
+              if (old == kNoKey) {
+                old = atomicCAS(&kkey[sl], kNoKey, key);
+                if (old == kNoKey) {
+                  claimed = true;
+                  break;
+                }
+              }
+              if (old == key) break;
+              sl = (sl + 1) & smask;
             }
           }
-          if (R::same_key(a, rows[cur], r)) break;
-          sl = (sl + 1) & smask;
+        } else {
+          for (uint32_t probes = 0;; probes++) {
+            if (probes == a.slots) {  // the index is full of other keys: far more groups than the planes hold
+              atomicAdd(&s_claims, a.gmax + 1);
+              sl = kNone;
+              break;
+            }
+            uint32_t cur = idx[sl];
+            if (cur == kNone) {
+              cur = atomicCAS(&idx[sl], kNone, i);
+              if (cur == kNone) {
+                claimed = true;
+                break;
+              }
+            }
+            if (R::same_key(a, rows[cur], r)) break;
+            sl = (sl + 1) & smask;
+          }
         }
         slot_of[k] = sl;
       }
@@ -4635,15 +4704,18 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     static const double min_per_part = getenv("CRGPU_BULK_MIN_PER_PART") ? atof(getenv("CRGPU_BULK_MIN_PER_PART")) : 3.0;
     const double per_part = hi / kRadixP1;
     if (per_part < min_per_part) return CRGPU_OK;
+    // (12 bytes per slot: the key and the local group number, see LKEY)
     for (const size_t sl : {size_t(2048), size_t(4096), size_t(8192)}) {
-      if (kLdsMax < 64 + sl * 8 + bpg) continue;
-      size_t g = (kLdsMax - 64 - sl * 8 - bpg) / (bpg + 4);
+      if (kLdsMax < 64 + sl * 12 + bpg) continue;
+      size_t g = (kLdsMax - 64 - sl * 12 - bpg) / (bpg + 4);
       if (g > sl * 3 / 4) g = sl * 3 / 4;
       if (g > gmax) gmax = g, slots = sl;
     }
     if (per_part * 1.3 + 4.0 * std::sqrt(per_part) + 16.0 > static_cast<double>(gmax)) return CRGPU_OK;
   }
-  const size_t lds = (static_cast<size_t>(a->lds_words) * 8 * (gmax + 1) + slots * 8 + gmax * 4 +
+  static const bool lkey_on = getenv("CRGPU_BULK_LKEY") == nullptr || getenv("CRGPU_BULK_LKEY")[0] != '0';
+  const bool lkey = !sub_form && !wide && lkey_on;
+  const size_t lds = (static_cast<size_t>(a->lds_words) * 8 * (gmax + 1) + (lkey ? slots * 12 + 16 : slots * 8) + gmax * 4 +
                       static_cast<size_t>(a->lds_seen) * (gmax + 1) + 15) & ~size_t(15);
   // sub form: one region per ~1024 rows, whatever the row count -- the kernel's time follows the number of regions (one
   // workgroup each, bound by its chain of latencies), and a power-of-two count made an input just above 2^26 rows cost
@@ -4725,6 +4797,7 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   b.not16 = a->bulk_count.as<unsigned int>() + 2;
   b.wmask = two_vals ? 0ull : ~0ull;
   b.g0 = g0;
+  b.lkey = lkey ? 1u : 0u;
   b.gmax = static_cast<uint32_t>(gmax);
   b.slots = static_cast<uint32_t>(slots);
   const unsigned nregions = sub_form ? static_cast<unsigned>(kRadixP1) * a->radix.nsub : static_cast<unsigned>(kRadixP1);
