@@ -2079,10 +2079,12 @@ __global__ __launch_bounds__(THREADS) void agg_bulk_kernel(BulkArgs a) {
   __shared__ uint32_t s_special;  // LKEY: the key equal to the empty marker has been claimed
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   constexpr unsigned long long kNoKey = ~0ull;
-  const bool LKEY = !WIDE && !TRY && !SLIM && a.lkey != 0;
+  // (the part form and the all-distinct attempt over narrow rows; in the slim general form, whose compares hit rows its
+  // workgroup has just loaded, the key index changed nothing: 2.29 against 2.27 ms on config G's 4 x input)
+  const bool LKEY = !WIDE && !SLIM && a.lkey != 0;
   const uint32_t plane = a.gmax + 1;
   // LKEY: [slots] keys instead of the slot -> row index, then [slots + 1] slot -> local group (the last one: the marker's key)
-  unsigned long long *kkey = lds_words + static_cast<size_t>(a.nwords) * plane;
+  unsigned long long *kkey = TRY ? lds_words : lds_words + static_cast<size_t>(a.nwords) * plane;
   uint32_t *idx = TRY ? reinterpret_cast<uint32_t *>(lds_words) : reinterpret_cast<uint32_t *>(lds_words + static_cast<size_t>(a.nwords) * plane);
   uint32_t *lid = LKEY ? reinterpret_cast<uint32_t *>(kkey + a.slots) : idx + a.slots;
   uint32_t *rep = lid + a.slots + (LKEY ? 1 : 0);
@@ -4827,13 +4829,15 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     CRGPU_TRY(exclusive_scan_u32(b.counts, nregions, a->p_offsets.as<uint64_t>(), a->scratch, &total_rows));
     BulkArgs bt = b;
     bt.slots = 4096;
+    bt.lkey = !wide && lkey_on ? 1u : 0u;
+    const size_t try_lds = static_cast<size_t>(bt.slots) * (bt.lkey ? 8 : 4);
     bt.try_base = a->p_offsets.as<uint64_t>();
     bt.try_failed = a->p_flags.as<unsigned int>();
     {
       ProfScope prof("agg_bulk_distinct");
       // (512 threads: 1.59 ms; 256 threads, eight workgroups per CU: 1.71 ms)
-      if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, kBulkTryThreads, true>), dim3(nregions), dim3(kBulkTryThreads), bt.slots * 4, st, bt);
-      else hipLaunchKernelGGL((agg_bulk_kernel<false, kBulkTryThreads, true>), dim3(nregions), dim3(kBulkTryThreads), bt.slots * 4, st, bt);
+      if (wide) hipLaunchKernelGGL((agg_bulk_kernel<true, kBulkTryThreads, true>), dim3(nregions), dim3(kBulkTryThreads), try_lds, st, bt);
+      else hipLaunchKernelGGL((agg_bulk_kernel<false, kBulkTryThreads, true>), dim3(nregions), dim3(kBulkTryThreads), try_lds, st, bt);
       CRGPU_HIP(hipGetLastError());
     }
     unsigned int failed_try = 0;

@@ -313,38 +313,61 @@ static constexpr uint32_t kDPartSlots = 8192, kDPartMaxKeys = 6144;
 __global__ __launch_bounds__(1024) void distinct_bulk_part_kernel(const ulonglong2 *__restrict__ rows_all, const uint32_t *__restrict__ starts,
                                                                   const uint32_t *__restrict__ totals, uint8_t *__restrict__ flags,
                                                                   uint32_t *__restrict__ overflow) {
-  __shared__ uint32_t idx[kDPartSlots];
-  __shared__ uint32_t minpos[kDPartSlots];
-  __shared__ uint32_t s_claims;
+  // The index holds the KEYS (a slot is claimed by a 64-bit compare-and-swap against the empty marker; the one key equal
+  // to the marker has a slot of its own), a tile's rows are requested before the first is looked up and the next
+  // tile's while this one is processed -- as in agg_bulk_kernel's part form: comparing against the row
+  // that claimed a slot tiles ago put a global load into every row's chain.
+  __shared__ unsigned long long kkey[kDPartSlots];
+  __shared__ uint32_t minpos[kDPartSlots + 1];  // [kDPartSlots]: the key equal to the empty marker
+  __shared__ uint32_t s_claims, s_special;
+  constexpr unsigned long long kNoKey = ~0ull;
   const uint32_t n = totals[blockIdx.x];
   if (n == 0) return;
   const ulonglong2 *rows = rows_all + starts[blockIdx.x];
-  for (uint32_t i = threadIdx.x; i < kDPartSlots; i += blockDim.x) idx[i] = 0xFFFFFFFFu, minpos[i] = 0xFFFFFFFFu;
-  if (threadIdx.x == 0) s_claims = 0;
+  for (uint32_t i = threadIdx.x; i < kDPartSlots; i += blockDim.x) kkey[i] = kNoKey, minpos[i] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) s_claims = 0, s_special = 0, minpos[kDPartSlots] = 0xFFFFFFFFu;
+  ulonglong2 nxt[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t i = k * 1024 + threadIdx.x;
+    if (i < n) nxt[k] = rows[i];
+  }
   __syncthreads();
   for (uint32_t t0 = 0; t0 < n; t0 += 2048) {
+    ulonglong2 rr[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      rr[k] = nxt[k];
+      const uint32_t j = t0 + 2048 + k * 1024 + threadIdx.x;
+      if (j < n) nxt[k] = rows[j];
+    }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const uint32_t i = t0 + k * 1024 + threadIdx.x;
       if (i < n) {
-        const ulonglong2 r = rows[i];
+        const ulonglong2 r = rr[k];
         uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & (kDPartSlots - 1);
-        for (uint32_t probes = 0;; probes++) {
-          if (probes == kDPartSlots) {  // full of other keys
-            atomicAdd(&s_claims, kDPartMaxKeys + 1);
-            sl = 0xFFFFFFFFu;
-            break;
-          }
-          uint32_t cur = idx[sl];
-          if (cur == 0xFFFFFFFFu) {
-            cur = atomicCAS(&idx[sl], 0xFFFFFFFFu, i);
-            if (cur == 0xFFFFFFFFu) {
-              atomicAdd(&s_claims, 1u);
+        if (r.x == kNoKey) {
+          sl = kDPartSlots;
+          if (atomicCAS(&s_special, 0u, 1u) == 0u) atomicAdd(&s_claims, 1u);
+        } else {
+          for (uint32_t probes = 0;; probes++) {
+            if (probes == kDPartSlots) {  // full of other keys
+              atomicAdd(&s_claims, kDPartMaxKeys + 1);
+              sl = 0xFFFFFFFFu;
               break;
             }
+            unsigned long long old = kkey[sl];
+            if (old == kNoKey) {
+              old = atomicCAS(&kkey[sl], kNoKey, r.x);
+              if (old == kNoKey) {
+                atomicAdd(&s_claims, 1u);
+                break;
+              }
+            }
+            if (old == r.x) break;
+            sl = (sl + 1) & (kDPartSlots - 1);
           }
-          if (rows[cur].x == r.x) break;
-          sl = (sl + 1) & (kDPartSlots - 1);
         }
         if (sl != 0xFFFFFFFFu) atomicMin(&minpos[sl], static_cast<uint32_t>(r.y));
       }
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(1024) void distinct_bulk_part_kernel(const ulonglon
     if (threadIdx.x == 0) atomicOr(overflow, 1u);
     return;
   }
-  for (uint32_t i = threadIdx.x; i < kDPartSlots; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i < kDPartSlots + 1; i += blockDim.x)
     if (minpos[i] != 0xFFFFFFFFu) flags[minpos[i]] = 1;
 }
 
