@@ -270,31 +270,46 @@ static constexpr uint32_t kDBulkRows = 2048, kDBulkSlots = 4096;
 static constexpr int64_t kDBulkMinRows = int64_t(1) << 23, kDBulkMaxRows = int64_t(1) << 27;
 __global__ __launch_bounds__(1024) void distinct_bulk_kernel(const ulonglong2 *__restrict__ rows_all, const uint32_t *__restrict__ counts,
                                                              uint8_t *__restrict__ flags) {
-  __shared__ uint32_t idx[kDBulkSlots];     // slot -> a row of the region that holds the slot's key
-  __shared__ uint32_t minpos[kDBulkSlots];  // slot -> smallest input position of the key
+  // slot -> the slot's KEY, claimed by a 64-bit compare-and-swap against the empty marker (comparing against the row that
+  // claimed the slot was a global load in every lookup that met a taken slot, and nearly every wave has such a lane);
+  // the one key equal to the marker has the slot behind the others
+  __shared__ unsigned long long kkey[kDBulkSlots];
+  __shared__ uint32_t minpos[kDBulkSlots + 1];  // slot -> smallest input position of the key
+  constexpr unsigned long long kNoKey = ~0ull;
   const uint32_t n = counts[blockIdx.x] < kDBulkRows ? counts[blockIdx.x] : kDBulkRows;  // (overflow is reported by the split)
   if (n == 0) return;
   const ulonglong2 *rows = rows_all + static_cast<int64_t>(blockIdx.x) * kDBulkRows;
-  for (uint32_t i = threadIdx.x; i < kDBulkSlots; i += blockDim.x) idx[i] = 0xFFFFFFFFu, minpos[i] = 0xFFFFFFFFu;
-  __syncthreads();
   constexpr int kRows = kDBulkRows / 1024;
+  ulonglong2 rr[kRows];
+#pragma unroll
+  for (int k = 0; k < kRows; k++) {  // (requested before the index is cleared and before the first lookup)
+    const uint32_t i = k * 1024 + threadIdx.x;
+    if (i < n) rr[k] = rows[i];
+  }
+  for (uint32_t i = threadIdx.x; i < kDBulkSlots; i += blockDim.x) kkey[i] = kNoKey, minpos[i] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) minpos[kDBulkSlots] = 0xFFFFFFFFu;
+  __syncthreads();
   uint32_t slot[kRows], pos[kRows];
 #pragma unroll
   for (int k = 0; k < kRows; k++) {
     const uint32_t i = k * 1024 + threadIdx.x;
     slot[k] = 0xFFFFFFFFu;
     if (i < n) {
-      const ulonglong2 r = rows[i];
+      const ulonglong2 r = rr[k];
       pos[k] = static_cast<uint32_t>(r.y);
       uint32_t sl = static_cast<uint32_t>(fmix64(r.x ^ 0x5851F42D4C957F2Dull) >> 20) & (kDBulkSlots - 1);
-      for (;;) {  // ends: at most kDBulkRows keys in twice as many slots
-        uint32_t cur = idx[sl];
-        if (cur == 0xFFFFFFFFu) {
-          cur = atomicCAS(&idx[sl], 0xFFFFFFFFu, i);
-          if (cur == 0xFFFFFFFFu) break;
+      if (r.x == kNoKey) {
+        sl = kDBulkSlots;
+      } else {
+        for (;;) {  // ends: at most kDBulkRows keys in twice as many slots
+          unsigned long long old = kkey[sl];
+          if (old == kNoKey) {
+            old = atomicCAS(&kkey[sl], kNoKey, r.x);
+            if (old == kNoKey) break;
+          }
+          if (old == r.x) break;
+          sl = (sl + 1) & (kDBulkSlots - 1);
         }
-        if (rows[cur].x == r.x) break;
-        sl = (sl + 1) & (kDBulkSlots - 1);
       }
       atomicMin(&minpos[sl], pos[k]);
       slot[k] = sl;
