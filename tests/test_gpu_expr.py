@@ -245,3 +245,26 @@ def test_deselect_vs_oracle(oracle):
         for gv, wv in zip(got, want):
             assert gv.to_values() == wv.to_values()
         ds.close()
+
+
+@pytest.mark.parametrize("shift", [0, 1, 5, 16])
+@pytest.mark.parametrize("density", [0.0, 0.3, 1.0])
+def test_deselect_flag_array_at_any_alignment(oracle, shift, density):
+    """The stream compaction behind the deselector reads sixteen flags per load when the flag array is 16-byte aligned
+    and byte by byte otherwise (gather.hip: tile_sum_flags16_kernel / tile_sum_kernel): the same rows either way, for
+    no row kept, some and all of them, and a row count that ends inside a tile and inside a 16-flag group."""
+    from cockroach_amd import device as dev
+    rng = np.random.default_rng(shift * 10 + int(density * 10))
+    n = 3 * 4096 + 1234 + 7
+    vals = cd.Vec.from_numpy(cd.INT64, rng.integers(-10**12, 10**12, size=n, dtype=np.int64))
+    keep = (rng.random(n) < density).astype(np.uint8) if 0.0 < density < 1.0 else np.full(n, int(density), dtype=np.uint8)
+    keep[keep != 0] = rng.integers(1, 256, size=int((keep != 0).sum()), dtype=np.uint8)  # any nonzero byte is "true"
+    whole = dev.upload(cd.Vec.from_numpy(cd.BOOL, np.concatenate([np.zeros(shift, dtype=np.uint8), keep])))
+    flags = dev.DeviceColumn(cd.BOOL, n, whole.data_ptr + shift, None, None, keep=whole)
+    ds = dev.Deselector([cd.INT64])
+    res = ds.deselect([dev.upload(vals)], flags, n)
+    got = dev.result_to_vecs(res)
+    assert int(res.n) == int((keep != 0).sum())
+    assert np.array_equal(got[0].data, vals.data[keep != 0])
+    ds.close()
+

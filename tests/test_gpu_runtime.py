@@ -119,3 +119,33 @@ def test_shutdown_refused_under_live_handles():
     assert int(a.finish().n) == 10
     a.close()
     assert lib.crgpu_live_handles() == live - 1
+
+
+def test_caller_blocks_come_from_the_free_list():
+    """crgpu_dev_malloc / crgpu_dev_free share the per-device free list of the library's own buffers: a freed block is
+    kept (crgpu_mem_cached grows by its size) and handed to the next request of about that size; blocks the caller holds
+    are not part of crgpu_mem_usage; crgpu_mem_trim returns the idle ones to the driver; freeing NULL and a pointer the
+    library never handed out are harmless."""
+    import ctypes as C
+    lib = _lib.load()
+    _lib.check(lib.crgpu_init(0))
+    lib.crgpu_mem_cached.restype = C.c_int64
+    lib.crgpu_mem_usage.restype = C.c_int64
+    lib.crgpu_mem_trim()
+    used0, cached0 = lib.crgpu_mem_usage(), lib.crgpu_mem_cached()
+    size = (37 << 20) + 123
+    p = C.c_void_p()
+    _lib.check(lib.crgpu_dev_malloc(C.byref(p), C.c_size_t(size)))
+    assert p.value and lib.crgpu_mem_usage() == used0
+    first = p.value
+    lib.crgpu_dev_free(p)
+    grown = lib.crgpu_mem_cached() - cached0
+    assert size <= grown < size + 4096
+    q = C.c_void_p()
+    _lib.check(lib.crgpu_dev_malloc(C.byref(q), C.c_size_t(size - 1000)))  # within a quarter of the cached block
+    assert q.value == first and lib.crgpu_mem_cached() == cached0
+    lib.crgpu_dev_free(q)
+    lib.crgpu_dev_free(None)
+    lib.crgpu_mem_trim()
+    assert lib.crgpu_mem_cached() == 0
+
