@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void distinct_rebase_offsets_kernel(const uint
 // instead radix-partitioned with the join's build-side kernels (radix.hip: 1024 partitions, then sub-partitions of ~1024
 // rows in fixed regions of kDBulkRows) and one workgroup per sub-partition finds, entirely in LDS, the smallest position
 // of every key: rows that are not the first of their key clear their flag (the flags start out set, so an all-distinct
-// region writes nothing).  The batch then joins the key store whole, the hash words are written by a streaming pass, and
-// the index is rebuilt from them only if more input follows.
+// region writes nothing).  The batch then joins the key store whole (or, when fewer than half of its rows are emitted,
+// only those), and the hash words and the index are only written if more input follows.
 static constexpr uint32_t kDBulkRows = 2048, kDBulkSlots = 4096;
 static constexpr int64_t kDBulkMinRows = int64_t(1) << 23, kDBulkMaxRows = int64_t(1) << 27;
 __global__ __launch_bounds__(1024) void distinct_bulk_kernel(const ulonglong2 *__restrict__ rows_all, const uint32_t *__restrict__ counts,
@@ -559,8 +559,8 @@ extern "C" crgpu_status crgpu_dev_distinct_reset(crgpu_distinct *d) {
   return CRGPU_OK;
 }
 
-// Bulk path (see distinct_bulk_kernel).  *done = true: d->flags holds the emit flag of every row and the hash words of
-// the batch are written; the caller compacts, gathers and appends the batch to the store whole.
+// Bulk path (see distinct_bulk_kernel).  *done = true: d->flags holds the emit flag of every row; the caller compacts,
+// gathers, appends the emitted rows (or the whole batch) to the store and writes or defers their hash words.
 static crgpu_status distinct_try_bulk(crgpu_distinct *d, const std::vector<DCol> &in, int64_t n, bool *done) {
   *done = false;
   static const bool on = getenv("CRGPU_DISTINCT_BULK") == nullptr || getenv("CRGPU_DISTINCT_BULK")[0] != '0';

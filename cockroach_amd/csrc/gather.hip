@@ -236,7 +236,8 @@ __global__ __launch_bounds__(kScanBlock) void select_apply_kernel(const uint8_t 
 }
 
 // The same two passes for a 16-byte aligned flag array: a thread's 16 flags (blocked arrangement, as in
-// select_apply_kernel) arrive in ONE 16-byte load instead of 16 byte loads (measured per 2^27 flags: DESIGN.md 4.5).  nonzero_bytes: bit 7 of every byte of w that is not zero.
+// select_apply_kernel) arrive in ONE 16-byte load instead of 16 byte loads (measured per 2^27 flags: DESIGN.md 4.5).
+// nonzero_bytes: bit 7 of every byte of w that is not zero.
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) { return (w | ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; }
 __device__ __forceinline__ uint32_t flag_bits16(const uint8_t *__restrict__ flags, int64_t first, int64_t n) {
   // bit k = flags[first + k] != 0, k < 16; first is a multiple of 16
