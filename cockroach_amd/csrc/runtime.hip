@@ -509,8 +509,12 @@ void crgpu_dev_free(void *p) {
     return;
   }
   // a pooled block may be handed out again at once: whatever still reads or writes this one must be done first
-  // (hipFree waits for the device too)
+  // (hipFree waits for the device too) -- on the block's device, which need not be this thread's current one
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (info.second >= 0 && cur != info.second) (void)hipSetDevice(info.second);
   (void)hipDeviceSynchronize();
+  if (info.second >= 0 && cur >= 0 && cur != info.second) (void)hipSetDevice(cur);
   if (!pool_put(info.second, p, info.first)) (void)hipFree(p);
 }
 crgpu_status crgpu_dev_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes) {
