@@ -4642,22 +4642,30 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
   // Which form?  s keys sampled at a fixed stride: for G equally likely groups the sample holds G (1 - exp(-s / G))
   // distinct keys.  The small sample rejects low-cardinality inputs for ~30 us.
   int64_t distinct = 0, maxrun = 0;
-  constexpr int kBigSample = 8192;
-  for (const int kSample : {512, kBigSample}) {
-    std::vector<int64_t> sample(kSample);
-    const int64_t stride = n / kSample;
-    CRGPU_TRY(a->scratch.ensure(static_cast<size_t>(kSample + 1) * 8));
+  constexpr int kBigSample = 8192, kSmallSample = 512;
+  // both samples are taken at once and come back in ONE round trip (each read-back is a wait of ~30 us); the small one
+  // is looked at first
+  std::vector<int64_t> both(static_cast<size_t>(kSmallSample + 1 + kBigSample + 1));
+  CRGPU_TRY(a->scratch.ensure(both.size() * 8));
+  {
+    long long *dev_small = a->scratch.as<long long>(), *dev_big = dev_small + kSmallSample + 1;
     if (wide) {
-      sample.resize(kSample + 1);
-      CRGPU_HIP(hipMemsetAsync(a->scratch.as<long long>() + kSample, 0, 8, st));
-      hipLaunchKernelGGL(agg_sample_wide_kernel, dim3(kSample / 256), dim3(256), 0, st, key, key2, stride, kSample, a->scratch.as<long long>());
+      CRGPU_HIP(hipMemsetAsync(dev_small + kSmallSample, 0, 8, st));
+      CRGPU_HIP(hipMemsetAsync(dev_big + kBigSample, 0, 8, st));
+      hipLaunchKernelGGL(agg_sample_wide_kernel, dim3((kSmallSample + 255) / 256), dim3(256), 0, st, key, key2, n / kSmallSample, kSmallSample, dev_small);
+      hipLaunchKernelGGL(agg_sample_wide_kernel, dim3(kBigSample / 256), dim3(256), 0, st, key, key2, n / kBigSample, kBigSample, dev_big);
     } else {
-      hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data), stride,
-                         kSample, a->scratch.as<long long>());
+      hipLaunchKernelGGL(agg_sample_keys_kernel, dim3((kSmallSample + 255) / 256), dim3(256), 0, st, static_cast<const long long *>(key.data),
+                         n / kSmallSample, kSmallSample, dev_small);
+      hipLaunchKernelGGL(agg_sample_keys_kernel, dim3(kBigSample / 256), dim3(256), 0, st, static_cast<const long long *>(key.data),
+                         n / kBigSample, kBigSample, dev_big);
     }
     CRGPU_HIP(hipGetLastError());
-    CRGPU_HIP(hipMemcpyAsync(sample.data(), a->scratch.p, sample.size() * 8, hipMemcpyDeviceToHost, st));
+    CRGPU_HIP(hipMemcpyAsync(both.data(), a->scratch.p, both.size() * 8, hipMemcpyDeviceToHost, st));
     CRGPU_HIP(hipStreamSynchronize(st));
+  }
+  for (const int kSample : {kSmallSample, kBigSample}) {
+    const int64_t *sample = both.data() + (kSample == kBigSample ? kSmallSample + 1 : 0);
     if (wide && sample[kSample] != 0) return CRGPU_OK;  // keys longer than 16 bytes
     // distinct keys and the largest multiplicity of the sample, by open addressing (sorting 8192 keys took 0.3 ms)
     const size_t tab = static_cast<size_t>(kSample) * 4;
@@ -4825,8 +4833,9 @@ static crgpu_status try_bulk(crgpu_agg *a, const std::vector<DCol> &cols, int64_
     CRGPU_TRY(a->p_offsets.ensure(static_cast<size_t>(nregions + 1) * 8));
     CRGPU_TRY(a->p_flags.ensure(256));
     CRGPU_HIP(hipMemsetAsync(a->p_flags.p, 0, 256, st));
-    uint64_t total_rows = 0;
-    CRGPU_TRY(exclusive_scan_u32(b.counts, nregions, a->p_offsets.as<uint64_t>(), a->scratch, &total_rows));
+    // (the regions hold every row -- no NULL key, no region overflowed --, so their counts add up to n: no read-back)
+    const uint64_t total_rows = static_cast<uint64_t>(n);
+    CRGPU_TRY(exclusive_scan_u32(b.counts, nregions, a->p_offsets.as<uint64_t>(), a->scratch, nullptr));
     BulkArgs bt = b;
     bt.slots = 4096;
     bt.lkey = !wide && lkey_on ? 1u : 0u;
